@@ -1,0 +1,93 @@
+// Context, error reporting and raw device-memory helpers of the C ABI.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace amp {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace amp
+
+extern "C" {
+
+const char* amp_last_error(void) { return amp::g_err; }
+
+int amp_version(void) { return 100; }
+
+int amp_init(int device, void* hip_stream, amp_ctx** out) {
+    AMP_REQUIRE(out != nullptr, "amp_init: out is null");
+    int ndev = 0;
+    AMP_HIP_CHECK(hipGetDeviceCount(&ndev));
+    AMP_REQUIRE(device >= 0 && device < ndev, "amp_init: device %d out of range (found %d HIP devices)", device, ndev);
+    AMP_HIP_CHECK(hipSetDevice(device));
+    amp_ctx* c = new amp_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            amp::set_error("amp_init: hipStreamCreate -> %s", hipGetErrorString(e));
+            delete c;
+            return AMP_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return AMP_OK;
+}
+
+void amp_destroy(amp_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int amp_sync(amp_ctx* ctx) {
+    AMP_REQUIRE(ctx, "amp_sync: null ctx");
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AMP_OK;
+}
+
+void* amp_stream(amp_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int amp_malloc(amp_ctx* ctx, size_t bytes, void** out) {
+    AMP_REQUIRE(ctx && out, "amp_malloc: null argument");
+    AMP_HIP_CHECK(hipSetDevice(ctx->device));
+    AMP_HIP_CHECK(hipMalloc(out, bytes ? bytes : 16));
+    return AMP_OK;
+}
+
+int amp_free(amp_ctx* ctx, void* p) {
+    AMP_REQUIRE(ctx, "amp_free: null ctx");
+    if (p) AMP_HIP_CHECK(hipFree(p));
+    return AMP_OK;
+}
+
+int amp_memcpy_h2d(amp_ctx* ctx, void* dst, const void* src_h, size_t bytes) {
+    AMP_REQUIRE(ctx && dst && src_h, "amp_memcpy_h2d: null argument");
+    AMP_HIP_CHECK(hipMemcpyAsync(dst, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AMP_OK;
+}
+
+int amp_memcpy_d2h(amp_ctx* ctx, void* dst_h, const void* src, size_t bytes) {
+    AMP_REQUIRE(ctx && dst_h && src, "amp_memcpy_d2h: null argument");
+    AMP_HIP_CHECK(hipMemcpyAsync(dst_h, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return AMP_OK;
+}
+
+int amp_memset(amp_ctx* ctx, void* dst, int value, size_t bytes) {
+    AMP_REQUIRE(ctx && dst, "amp_memset: null argument");
+    AMP_HIP_CHECK(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return AMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// Implicit-GEMM convolution, fp32 in / fp32 accumulate on the gfx950 f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the cuDNN convolutions detectron2 runs for AMPIS:
+// ResNet-50 stem+res2..res5, FPN lateral/output convs, the RPN head, the box-head FCs (as 1x1 convs over
+// "pixels" = RoIs) and the mask head (3x3 convs, ConvTranspose 2x2 s2, 1x1 predictor).
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, activations NHWC so a K-slice of 32 input
+// channels of one tap is 128 contiguous bytes.  Block tile BM x BN x 32, 4 waves (2x2), each wave a
+// (BM/2)x(BN/2) tile of 32x32 MFMA accumulators.  Both operand tiles sit in LDS as [row][k] with k contiguous
+// and rows padded to 36 floats, so a lane fetches 4 consecutive k with one conflict-free ds_read_b128 and
+// feeds 4 MFMAs from it (the k order inside a tile is permuted identically for A and B, which a sum over k
+// does not see).  Register-staged double buffering: the global loads of K-step s+1 are issued before the MFMAs
+// of step s and written to the other LDS buffer after them; one barrier per step.
+//
+// Epilogue (fused): y = acc*scale[n] + shift[n] (FrozenBN affine or conv bias), optional residual (same shape,
+// or nearest-x2-upsampled for the FPN top-down path), optional ReLU, optional ConvTranspose2x2 scatter.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;      // K-slice per step (floats)
+constexpr int LDS_LD = 36;  // padded row length in LDS (floats): 144 B rows -> conflict-free ds_read_b128
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    float* y;
+    int B, H, W, Cin;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad;
+    int M, K, nsteps;
+    int relu, res_mode, out_mode;
+    int ntn;  // number of N tiles
+    int nblk;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per step
+    constexpr int TILE_FLOATS = (BM + BN) * LDS_LD;
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = tile % a.ntn;
+    const int tile_m = tile / a.ntn;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- per-thread staging geometry: thread loads float4 #col4 of rows lrow + 32*r ----
+    const int col4 = tid & 7;
+    const int lrow = tid >> 3;
+
+    int a_iy0[RA], a_ix0[RA], a_pb[RA];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+        const int m = m0 + lrow + 32 * r;
+        if (m < a.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            a_iy0[r] = oy * a.stride - a.pad;
+            a_ix0[r] = ox * a.stride - a.pad;
+            a_pb[r] = b * a.H * a.W;
+        } else {
+            a_iy0[r] = -(1 << 28);
+            a_ix0[r] = 0;
+            a_pb[r] = 0;
+        }
+    }
+
+    f32x4 ra[RA], rb[RB];
+
+    auto load_tiles = [&](int step) {
+        const int kidx = step * BK + col4 * 4;
+        const int t = kidx / a.Cin;
+        const int c = kidx - t * a.Cin;
+        const int ky = t / a.KW;
+        const int kx = t - ky * a.KW;
+        const bool kv = kidx < a.K;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int iy = a_iy0[r] + ky;
+            const int ix = a_ix0[r] + kx;
+            const bool v = kv && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v) {
+                const size_t off = (size_t)(a_pb[r] + iy * a.W + ix) * a.Cin + c;
+                val = *reinterpret_cast<const f32x4*>(a.x + off);
+            }
+            ra[r] = val;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int n = n0 + lrow + 32 * r;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (kv && n < a.Cout) {
+                val = *reinterpret_cast<const f32x4*>(a.w + (size_t)n * a.K + kidx);
+            }
+            rb[r] = val;
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + BM * LDS_LD;
+#pragma unroll
+        for (int r = 0; r < RA; ++r)
+            *reinterpret_cast<f32x4*>(As + (lrow + 32 * r) * LDS_LD + col4 * 4) = ra[r];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * r) * LDS_LD + col4 * 4) = rb[r];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int step = 0; step < a.nsteps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < a.nsteps;
+        if (more) load_tiles(step + 1);
+
+        const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * LDS_LD + 4 * lh;
+        const float* Bs = lds + cur * TILE_FLOATS + BM * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * q);
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int C2 = a.Cout >> 2;  // deconv scatter only
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+        const bool nv = n < a.Cout;
+        const float sc = (a.scale && nv) ? a.scale[n] : 1.f;
+        const float sh = (a.shift && nv) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (!nv || m >= a.M) continue;
+                float v = __fadd_rn(__fmul_rn(acc[i][j][e], sc), sh);
+                size_t yoff;
+                if (a.res_mode == 0 && a.out_mode == 0) {
+                    yoff = (size_t)m * a.Cout + n;
+                } else {
+                    const int b = m / HoWo;
+                    const int rem = m - b * HoWo;
+                    const int oy = rem / a.Wo;
+                    const int ox = rem - oy * a.Wo;
+                    if (a.res_mode == 1) {
+                        v = __fadd_rn(v, a.res[(size_t)m * a.Cout + n]);
+                    } else if (a.res_mode == 2) {
+                        const size_t roff =
+                            ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+                        v = __fadd_rn(v, a.res[roff]);
+                    }
+                    if (a.out_mode == 1) {
+                        const int kk = n / C2;
+                        const int co = n - kk * C2;
+                        const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
+                        yoff = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
+                    } else {
+                        yoff = (size_t)m * a.Cout + n;
+                    }
+                }
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.y[yoff] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
+                               const float* scale, const float* shift, const float* res, float* y) {
+    AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
+    AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
+    AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
+    AMP_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "amp_conv2d_nhwc: bad window");
+    AMP_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && d->out_mode >= 0 && d->out_mode <= 1,
+                "amp_conv2d_nhwc: bad res_mode/out_mode");
+    AMP_REQUIRE(d->res_mode == 0 || res != nullptr, "amp_conv2d_nhwc: res_mode=%d needs res", d->res_mode);
+    ConvArgs a;
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    AMP_REQUIRE(a.Ho > 0 && a.Wo > 0, "amp_conv2d_nhwc: empty output");
+    AMP_REQUIRE(d->res_mode != 2 || (a.Ho % 2 == 0 && a.Wo % 2 == 0),
+                "amp_conv2d_nhwc: res_mode=2 needs even output size, got %dx%d", a.Ho, a.Wo);
+    AMP_REQUIRE(d->out_mode != 1 || d->Cout % 4 == 0, "amp_conv2d_nhwc: out_mode=1 needs Cout %% 4 == 0");
+    const long long Mll = (long long)a.B * a.Ho * a.Wo;
+    AMP_REQUIRE(Mll < (1ll << 31) / 4 && (long long)a.B * a.H * a.W < (1ll << 31),
+                "amp_conv2d_nhwc: tensor too large for 32-bit pixel indices");
+    a.M = (int)Mll;
+    a.K = a.KH * a.KW * a.Cin;
+    a.nsteps = amp::cdiv(a.K, BK);
+    a.relu = d->relu; a.res_mode = d->res_mode; a.out_mode = d->out_mode;
+
+    constexpr int BM = 128;
+    const int ntm = amp::cdiv(a.M, BM);
+    if (a.Cout > 64) {
+        a.ntn = amp::cdiv(a.Cout, 128);
+        a.nblk = ntm * a.ntn;
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, 128>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+    } else {
+        a.ntn = 1;
+        a.nblk = ntm;
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, 64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+    }
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
