@@ -18,6 +18,32 @@ class ConvDesc(C.Structure):
                 ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad", "relu", "res_mode", "out_mode")]
 
 
+class RpnLevels(C.Structure):
+    _fields_ = [("nlevels", C.c_int), ("A", C.c_int), ("ld", C.c_int), ("pred", C.c_void_p * 5),
+                ("h", C.c_int * 5), ("w", C.c_int * 5), ("stride", C.c_int * 5), ("anchor_size", C.c_int * 5)]
+
+
+class FpnFeats(C.Structure):
+    _fields_ = [("feat", C.c_void_p * 4), ("h", C.c_int * 4), ("w", C.c_int * 4), ("stride", C.c_int * 4),
+                ("C", C.c_int)]
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [("num_classes", C.c_int), ("pixel_mean", C.c_float * 3), ("pixel_std", C.c_float * 3),
+                ("pre_nms_topk", C.c_int), ("post_nms_topk", C.c_int), ("rpn_nms_thresh", C.c_float),
+                ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("detections_per_image", C.c_int),
+                ("bbox_reg_weights", C.c_float * 4), ("mask_threshold", C.c_float),
+                ("max_batch", C.c_int), ("max_h", C.c_int), ("max_w", C.c_int), ("max_out_hw", C.c_int),
+                ("rle_pool_counts", C.c_size_t)]
+
+
+class Dets(C.Structure):
+    _fields_ = [("B", C.c_int), ("D", C.c_int), ("n", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
+                ("scores", C.POINTER(C.c_float)), ("classes", C.POINTER(C.c_int)),
+                ("rle_off", C.POINTER(C.c_ulonglong)), ("rle_len", C.POINTER(C.c_int)),
+                ("rle_counts", C.POINTER(C.c_uint32)), ("out_h", C.POINTER(C.c_int)), ("out_w", C.POINTER(C.c_int))]
+
+
 _lib = None
 
 
@@ -42,7 +68,9 @@ def _declare(L):
     vp, i, f = C.c_void_p, C.c_int, C.c_float
     sig = {
         "amp_version": ([], i),
-        "amp_init": ([i, vp, C.POINTER(vp)], i),
+        "amp_init": ([i, vp, i, C.POINTER(vp)], i),
+        "amp_timer_start": ([vp], i),
+        "amp_timer_stop": ([vp, C.POINTER(f)], i),
         "amp_destroy": ([vp], None),
         "amp_sync": ([vp], i),
         "amp_malloc": ([vp, C.c_size_t, C.POINTER(vp)], i),
@@ -51,6 +79,35 @@ def _declare(L):
         "amp_memcpy_d2h": ([vp, vp, vp, C.c_size_t], i),
         "amp_memset": ([vp, vp, i, C.c_size_t], i),
         "amp_conv2d_nhwc": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp], i),
+        "amp_preprocess": ([vp, vp, i, i, i, i, i, C.POINTER(f), C.POINTER(f), vp], i),
+        "amp_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),
+        "amp_subsample2": ([vp, vp, i, i, i, i, vp], i),
+        "amp_rpn_topk": ([vp, C.POINTER(RpnLevels), i, i, vp, i, vp, vp, vp], i),
+        "amp_rpn_decode": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, i, vp, vp], i),
+        "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_nms": ([vp, i, i, vp, vp, vp, f, i, vp, vp, vp], i),
+        "amp_roi_align": ([vp, C.POINTER(FpnFeats), vp, vp, vp, i, i, vp, vp], i),
+        "amp_box_candidates": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, i, vp, vp], i),
+        "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_mask_prob": ([vp, vp, vp, i, i, vp], i),
+        "amp_paste_rle": ([vp, vp, vp, vp, i, vp, vp, i, i, i, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp], i),
+        "amp_rle_to_string": ([vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)], i),
+        "amp_rle_from_string": ([vp, C.c_size_t, vp, i, C.POINTER(i)], i),
+        "amp_rle_encode": ([vp, i, i, vp, i, C.POINTER(i)], i),
+        "amp_rle_decode": ([vp, i, i, i, vp], i),
+        "amp_rle_area": ([vp, i, C.POINTER(C.c_ulonglong)], i),
+        "amp_rle_iou": ([vp, i, vp, i, i, C.POINTER(C.c_double)], i),
+        "amp_rle_merge2": ([vp, i, vp, i, i, vp, i, C.POINTER(i)], i),
+        "amp_model_cfg_default": ([C.POINTER(ModelCfg)], i),
+        "amp_model_create": ([vp, C.POINTER(ModelCfg), C.POINTER(vp)], i),
+        "amp_model_destroy": ([vp], None),
+        "amp_model_workspace_bytes": ([vp], C.c_size_t),
+        "amp_model_num_tensors": ([vp], i),
+        "amp_model_tensor_name": ([vp, i], C.c_char_p),
+        "amp_model_load_tensor": ([vp, C.c_char_p, vp, C.POINTER(C.c_longlong), i], i),
+        "amp_model_finalize": ([vp], i),
+        "amp_model_infer": ([vp, vp, i, i, i, i, vp, vp, C.POINTER(Dets)], i),
+        "amp_model_get_tap": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_longlong)], i),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)
@@ -66,12 +123,25 @@ def check(status, what=""):
 
 
 class Context:
-    """One amp_ctx (one HIP stream). `stream` may be a raw hipStream_t (e.g. torch's current stream)."""
+    """One amp_ctx (one HIP stream). borrow_stream=<hipStream_t int> (0 = legacy default stream) launches on
+    that stream (e.g. torch's current stream); borrow_stream=None lets the library own a non-blocking stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, borrow_stream=None):
         self._h = C.c_void_p()
-        check(lib().amp_init(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)), "amp_init")
+        if borrow_stream is None:
+            st = lib().amp_init(int(device), None, 0, C.byref(self._h))
+        else:
+            st = lib().amp_init(int(device), C.c_void_p(int(borrow_stream)), 1, C.byref(self._h))
+        check(st, "amp_init")
         self.device = int(device)
+
+    def timer_start(self):
+        check(lib().amp_timer_start(self._h), "amp_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().amp_timer_stop(self._h, C.byref(ms)), "amp_timer_stop")
+        return ms.value
 
     @property
     def handle(self):

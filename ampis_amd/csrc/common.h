@@ -41,10 +41,31 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + k;
 }
 
+// Order-preserving float <-> uint32 (ascending float order == ascending unsigned order).
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// 64-bit sort word: [63:32] ordered score, [31:8] ~position (ties -> smaller position first when sorting
+// descending), [7:0] category payload (below the tie-break, positions are unique). 0 = invalid / unused slot.
+__device__ __forceinline__ unsigned long long make_sortkey(uint32_t ord_score, int pos, int cat) {
+    unsigned long long k = ((unsigned long long)ord_score << 32) |
+                           ((unsigned long long)(0xffffffu - (uint32_t)pos) << 8) | (uint32_t)(cat & 0xff);
+    if ((k >> 32) == 0ull) k |= (1ull << 32);
+    return k;
+}
+__device__ __forceinline__ int sortkey_pos(unsigned long long k) { return (int)(0xffffffu - (uint32_t)((k >> 8) & 0xffffffu)); }
+__device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(k & 0xffu); }
+
 }  // namespace amp
 
 struct amp_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    hipEvent_t ev0, ev1;
 };

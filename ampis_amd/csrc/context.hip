@@ -19,7 +19,7 @@ const char* amp_last_error(void) { return amp::g_err; }
 
 int amp_version(void) { return 100; }
 
-int amp_init(int device, void* hip_stream, amp_ctx** out) {
+int amp_init(int device, void* hip_stream, int flags, amp_ctx** out) {
     AMP_REQUIRE(out != nullptr, "amp_init: out is null");
     int ndev = 0;
     AMP_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -27,7 +27,7 @@ int amp_init(int device, void* hip_stream, amp_ctx** out) {
     AMP_HIP_CHECK(hipSetDevice(device));
     amp_ctx* c = new amp_ctx();
     c->device = device;
-    if (hip_stream) {
+    if (flags & AMP_STREAM_BORROW) {
         c->stream = (hipStream_t)hip_stream;
         c->own_stream = false;
     } else {
@@ -39,12 +39,33 @@ int amp_init(int device, void* hip_stream, amp_ctx** out) {
         }
         c->own_stream = true;
     }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        amp::set_error("amp_init: hipEventCreate failed");
+        delete c;
+        return AMP_ERR_HIP;
+    }
     *out = c;
+    return AMP_OK;
+}
+
+int amp_timer_start(amp_ctx* ctx) {
+    AMP_REQUIRE(ctx, "amp_timer_start: null ctx");
+    AMP_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+    return AMP_OK;
+}
+
+int amp_timer_stop(amp_ctx* ctx, float* ms_h) {
+    AMP_REQUIRE(ctx && ms_h, "amp_timer_stop: null argument");
+    AMP_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+    AMP_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    AMP_HIP_CHECK(hipEventElapsedTime(ms_h, ctx->ev0, ctx->ev1));
     return AMP_OK;
 }
 
 void amp_destroy(amp_ctx* ctx) {
     if (!ctx) return;
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1,0 +1,736 @@
+// amp_model: Mask R-CNN R50-FPN inference orchestration (what `DefaultPredictor.__call__` -> GeneralizedRCNN.inference
+// does for AMPIS, notebook cells 24-28).  Host C++ only plans buffers and launches the HIP
+// stages of this library on the context's stream; there is no CPU compute path.
+//
+// Parameters arrive under their detectron2 state_dict names (amp_model_load_tensor) in torch layouts and are re-laid for
+// the kernels here: conv OIHW -> [Cout][KH][KW][Cin]; stem padded to Cin 4 / KW 8; FrozenBN -> per-channel (scale, shift);
+// fc1 columns permuted from (c,ph,pw) to (ph,pw,c); cls_score+bbox_pred and objectness+anchor_deltas fused row-wise;
+// ConvTranspose IOHW -> [(ky,kx,co)][Cin].
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct ConvW {
+    float* w = nullptr;      // device [Cout][KH][KW][Cin]
+    float* scale = nullptr;  // device [Cout] or null
+    float* shift = nullptr;  // device [Cout] or null
+    int cout = 0, cin = 0, kh = 0, kw = 0;
+};
+
+struct NamedBuf {
+    void* ptr;
+    int dtype;   // 0 f32, 1 i32, 2 u64
+    int ndim;
+    long long shape[5];
+};
+
+struct Bump {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        if (off > peak) peak = off;
+        if (dry) return reinterpret_cast<void*>(a + 256);   // non-null fake
+        return (off <= cap) ? base + a : nullptr;
+    }
+    template <class T>
+    T* get(size_t n) { return reinterpret_cast<T*>(alloc(n * sizeof(T))); }
+};
+
+const char* kStage[4] = {"res2", "res3", "res4", "res5"};
+const int kBlocks[4] = {3, 4, 6, 3};
+const int kMid[4] = {64, 128, 256, 512};
+const int kOut[4] = {256, 512, 1024, 2048};
+const int kStride[4] = {1, 2, 2, 2};
+
+}  // namespace
+
+struct amp_model {
+    amp_ctx* ctx = nullptr;
+    amp_model_cfg cfg;
+    // ---- parameters ----
+    float* parena = nullptr;
+    size_t parena_floats = 0, parena_used = 0;
+    std::map<std::string, ConvW> conv;                     // keyed by detectron2 module prefix
+    std::map<std::string, std::vector<float>> host_raw;    // raw host copies needed at finalize (BN stats, fused parts)
+    std::map<std::string, bool> loaded;
+    std::vector<std::string> expected;
+    bool finalized = false;
+    // ---- workspace ----
+    Bump ws;
+    std::map<std::string, NamedBuf> taps;
+    int* d_batch_iota = nullptr;        // [max_batch * post_nms_topk] roi -> image
+    int* d_flags = nullptr;             // [4] overflow flags
+    // pinned host staging
+    int* h_counts = nullptr;            // [max_batch] (pinned)
+    int* h_small = nullptr;             // pinned scratch for small uploads
+    std::vector<char> host_out;         // result storage
+    // host results of the last call
+    std::vector<int> r_n, r_classes, r_rle_len;
+    std::vector<float> r_boxes, r_scores;
+    std::vector<unsigned long long> r_rle_off;
+    std::vector<uint32_t> r_pool;
+    std::vector<int> r_out_h, r_out_w;
+    float last_stage_ms[8];
+};
+
+namespace {
+
+float* palloc(amp_model* m, size_t n) {
+    const size_t a = (m->parena_used + 63) & ~(size_t)63;
+    if (a + n > m->parena_floats) return nullptr;
+    m->parena_used = a + n;
+    return m->parena + a;
+}
+
+int upload(amp_model* m, float* dst, const std::vector<float>& v) {
+    AMP_HIP_CHECK(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+    AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    return AMP_OK;
+}
+
+void expect_conv_bn(amp_model* m, const std::string& p) {
+    m->expected.push_back(p + ".weight");
+    for (const char* f : {"weight", "bias", "running_mean", "running_var"}) m->expected.push_back(p + ".norm." + f);
+}
+
+void build_expected(amp_model* m) {
+    expect_conv_bn(m, "backbone.bottom_up.stem.conv1");
+    for (int s = 0; s < 4; ++s)
+        for (int b = 0; b < kBlocks[s]; ++b) {
+            const std::string p = std::string("backbone.bottom_up.") + kStage[s] + "." + std::to_string(b);
+            if (b == 0) expect_conv_bn(m, p + ".shortcut");
+            expect_conv_bn(m, p + ".conv1");
+            expect_conv_bn(m, p + ".conv2");
+            expect_conv_bn(m, p + ".conv3");
+        }
+    auto wb = [&](const std::string& p) { m->expected.push_back(p + ".weight"); m->expected.push_back(p + ".bias"); };
+    for (int l = 2; l <= 5; ++l) { wb("backbone.fpn_lateral" + std::to_string(l)); wb("backbone.fpn_output" + std::to_string(l)); }
+    wb("proposal_generator.rpn_head.conv");
+    wb("proposal_generator.rpn_head.objectness_logits");
+    wb("proposal_generator.rpn_head.anchor_deltas");
+    wb("roi_heads.box_head.fc1"); wb("roi_heads.box_head.fc2");
+    wb("roi_heads.box_predictor.cls_score"); wb("roi_heads.box_predictor.bbox_pred");
+    for (int i = 1; i <= 4; ++i) wb("roi_heads.mask_head.mask_fcn" + std::to_string(i));
+    wb("roi_heads.mask_head.deconv"); wb("roi_heads.mask_head.predictor");
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// OIHW -> [O][KH][KWp][Cp] with zero padding of the extra taps / channels
+std::vector<float> oihw_to_ohwi(const float* w, int O, int I, int KH, int KW, int Cp, int KWp) {
+    std::vector<float> out((size_t)O * KH * KWp * Cp, 0.f);
+    for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+            for (int y = 0; y < KH; ++y)
+                for (int x = 0; x < KW; ++x)
+                    out[(((size_t)o * KH + y) * KWp + x) * Cp + i] = w[(((size_t)o * I + i) * KH + y) * KW + x];
+    return out;
+}
+
+int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int W, int stride, int pad, bool relu,
+                int res_mode, const float* res, int out_mode, float* y) {
+    amp_conv_desc d;
+    d.B = B; d.H = H; d.W = W; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw;
+    d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
+    return amp_conv2d_nhwc(m->ctx, &d, x, cw.w, cw.scale, cw.shift, res, y);
+}
+
+void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_list<long long> shape) {
+    NamedBuf nb;
+    nb.ptr = p; nb.dtype = dtype; nb.ndim = (int)shape.size();
+    int i = 0;
+    for (long long s : shape) nb.shape[i++] = s;
+    m->taps[name] = nb;
+}
+
+#define AMP_TRY(expr) do { int _s = (expr); if (_s != AMP_OK) return _s; } while (0)
+#define AMP_ALLOC(var, T, n)                                                                  \
+    T* var = ws.get<T>((size_t)(n));                                                          \
+    if (!var) { amp::set_error("amp_model: workspace exhausted allocating %s (%zu bytes, cap %zu)", #var, \
+                               (size_t)(n) * sizeof(T), ws.cap); return AMP_ERR_NOMEM; }
+
+// The whole forward. With ws.dry == true nothing is launched: only the workspace peak is measured.
+int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out_h, const int* out_w) {
+    Bump& ws = m->ws;
+    const bool dry = ws.dry;
+    const amp_model_cfg& c = m->cfg;
+    amp_ctx* ctx = m->ctx;
+    ws.off = 0;
+    if (!dry) m->taps.clear();
+    const int K = c.num_classes;
+    const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+    auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
+
+    // ---------------- backbone ----------------
+    AMP_ALLOC(x0, float, (size_t)B * Hp * Wp * 4);
+    if (!dry) AMP_TRY(amp_preprocess(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, x0));
+    int h = Hp / 2, w = Wp / 2;
+    AMP_ALLOC(stem, float, (size_t)B * h * w * 64);
+    if (!dry) AMP_TRY(launch_conv(m, CONV("backbone.bottom_up.stem.conv1"), x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
+    const int h4 = (h + 2 - 3) / 2 + 1, w4 = (w + 2 - 3) / 2 + 1;
+    AMP_ALLOC(pool, float, (size_t)B * h4 * w4 * 64);
+    if (!dry) AMP_TRY(amp_maxpool3x3s2(ctx, stem, B, h, w, 64, pool));
+    if (!dry) tap(m, "stem_pool", pool, 0, {B, h4, w4, 64});
+
+    float* cur = pool;
+    int ch = h4, cw_ = w4;
+    float* res_out[4];
+    int res_h[4], res_w[4];
+    for (int s = 0; s < 4; ++s) {
+        for (int b = 0; b < kBlocks[s]; ++b) {
+            const std::string p = std::string("backbone.bottom_up.") + kStage[s] + "." + std::to_string(b);
+            const int st = (b == 0) ? kStride[s] : 1;
+            const int oh = (ch - 1) / st + 1, ow = (cw_ - 1) / st + 1;
+            const size_t mark = ws.off;
+            // block output first so it survives the release of the temporaries below it... allocate temporaries after
+            AMP_ALLOC(out, float, (size_t)B * oh * ow * kOut[s]);
+            const size_t keep = ws.off;
+            const float* shortcut = cur;
+            if (b == 0) {
+                AMP_ALLOC(sc, float, (size_t)B * oh * ow * kOut[s]);
+                if (!dry) AMP_TRY(launch_conv(m, CONV((p + ".shortcut").c_str()), cur, B, ch, cw_, st, 0, false, 0, nullptr, 0, sc));
+                shortcut = sc;
+            }
+            AMP_ALLOC(t1, float, (size_t)B * oh * ow * kMid[s]);
+            AMP_ALLOC(t2, float, (size_t)B * oh * ow * kMid[s]);
+            if (!dry) {
+                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st, 0, true, 0, nullptr, 0, t1));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, oh, ow, 1, 1, true, 0, nullptr, 0, t2));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out));
+            }
+            (void)mark;
+            ws.off = keep;   // release sc/t1/t2 (stream order makes reuse safe)
+            cur = out;
+            ch = oh; cw_ = ow;
+        }
+        res_out[s] = cur; res_h[s] = ch; res_w[s] = cw_;
+        if (!dry) tap(m, kStage[s], cur, 0, {B, ch, cw_, kOut[s]});
+    }
+
+    // ---------------- FPN ----------------
+    float* feat[5];
+    int fh[5], fw[5];
+    const int fstride[5] = {4, 8, 16, 32, 64};
+    float* prev_lat = nullptr;
+    for (int l = 5; l >= 2; --l) {
+        const int s = l - 2;
+        const std::string ln = "backbone.fpn_lateral" + std::to_string(l), on = "backbone.fpn_output" + std::to_string(l);
+        AMP_ALLOC(lat, float, (size_t)B * res_h[s] * res_w[s] * 256);
+        AMP_ALLOC(outp, float, (size_t)B * res_h[s] * res_w[s] * 256);
+        if (!dry) {
+            AMP_TRY(launch_conv(m, CONV(ln.c_str()), res_out[s], B, res_h[s], res_w[s], 1, 0, false, prev_lat ? 2 : 0, prev_lat, 0, lat));
+            AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp));
+        }
+        prev_lat = lat;
+        feat[s] = outp; fh[s] = res_h[s]; fw[s] = res_w[s];
+    }
+    fh[4] = (fh[3] - 1) / 2 + 1; fw[4] = (fw[3] - 1) / 2 + 1;
+    AMP_ALLOC(p6, float, (size_t)B * fh[4] * fw[4] * 256);
+    if (!dry) AMP_TRY(amp_subsample2(ctx, feat[3], B, fh[3], fw[3], 256, p6));
+    feat[4] = p6;
+    if (!dry) {
+        const char* fn[5] = {"p2", "p3", "p4", "p5", "p6"};
+        for (int l = 0; l < 5; ++l) tap(m, fn[l], feat[l], 0, {B, fh[l], fw[l], 256});
+    }
+
+    // ---------------- RPN head ----------------
+    const int ld_rpn = 15;
+    amp_rpn_levels lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.nlevels = 5; lv.A = 3; lv.ld = ld_rpn;
+    const int asz[5] = {32, 64, 128, 256, 512};
+    int max_n = 0;
+    for (int l = 0; l < 5; ++l) {
+        const size_t mark = ws.off;
+        AMP_ALLOC(pred, float, (size_t)B * fh[l] * fw[l] * ld_rpn);
+        const size_t keep = ws.off;
+        AMP_ALLOC(t, float, (size_t)B * fh[l] * fw[l] * 256);
+        if (!dry) {
+            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.conv"), feat[l], B, fh[l], fw[l], 1, 1, true, 0, nullptr, 0, t));
+            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.pred"), t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred));
+        }
+        (void)mark;
+        ws.off = keep;
+        lv.pred[l] = pred; lv.h[l] = fh[l]; lv.w[l] = fw[l]; lv.stride[l] = fstride[l]; lv.anchor_size[l] = asz[l];
+        max_n = std::max(max_n, fh[l] * fw[l] * 3);
+        if (!dry) {
+            const char* pn[5] = {"rpn_pred2", "rpn_pred3", "rpn_pred4", "rpn_pred5", "rpn_pred6"};
+            tap(m, pn[l], pred, 0, {B, fh[l] * fw[l], ld_rpn});
+        }
+    }
+
+    // ---------------- proposals ----------------
+    const int k = c.pre_nms_topk;
+    const int cap = 5 * k;                 // candidates per image
+    const int Rcap = c.post_nms_topk;
+    AMP_ALLOC(keys_scratch, uint32_t, (size_t)B * 5 * max_n);
+    AMP_ALLOC(sel_idx, int, (size_t)B * 5 * k);
+    AMP_ALLOC(sel_logit, float, (size_t)B * 5 * k);
+    AMP_ALLOC(sel_count, int, (size_t)B * 5);
+    AMP_ALLOC(cand_boxes, float, (size_t)B * cap * 4);
+    AMP_ALLOC(cand_keys, unsigned long long, (size_t)B * cap);
+    AMP_ALLOC(s_boxes, float, (size_t)B * cap * 4);
+    AMP_ALLOC(s_scores, float, (size_t)B * cap);
+    AMP_ALLOC(s_cats, int, (size_t)B * cap);
+    AMP_ALLOC(s_count, int, (size_t)B);
+    AMP_ALLOC(nms_mask, unsigned long long, (size_t)B * cap * ((cap + 63) / 64));
+    AMP_ALLOC(keep_idx, int, (size_t)B * Rcap);
+    AMP_ALLOC(prop_count, int, (size_t)B);
+    AMP_ALLOC(prop_boxes, float, (size_t)B * Rcap * 4);
+    AMP_ALLOC(prop_logits, float, (size_t)B * Rcap);
+    AMP_ALLOC(prop_lvl, int, (size_t)B * Rcap);
+    if (!dry) {
+        AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
+        AMP_TRY(amp_rpn_decode(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, cap, cand_boxes, cand_keys));
+        AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr));
+        AMP_TRY(amp_nms(ctx, B, cap, s_boxes, s_cats, s_count, c.rpn_nms_thresh, Rcap, nms_mask, keep_idx, prop_count));
+        AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl));
+        tap(m, "rpn_sel_idx", sel_idx, 1, {B, 5, k});
+        tap(m, "rpn_sel_logit", sel_logit, 0, {B, 5, k});
+        tap(m, "rpn_cand_sorted_boxes", s_boxes, 0, {B, cap, 4});
+        tap(m, "rpn_cand_sorted_scores", s_scores, 0, {B, cap});
+        tap(m, "rpn_cand_sorted_lvl", s_cats, 1, {B, cap});
+        tap(m, "rpn_cand_count", s_count, 1, {B});
+        tap(m, "prop_boxes", prop_boxes, 0, {B, Rcap, 4});
+        tap(m, "prop_logits", prop_logits, 0, {B, Rcap});
+        tap(m, "prop_count", prop_count, 1, {B});
+    }
+
+    // ---------------- box head ----------------
+    amp_fpn_feats ff;
+    memset(&ff, 0, sizeof(ff));
+    ff.C = 256;
+    for (int l = 0; l < 4; ++l) { ff.feat[l] = feat[l]; ff.h[l] = fh[l]; ff.w[l] = fw[l]; ff.stride[l] = fstride[l]; }
+    const int R = B * Rcap;
+    const int ld_box = 5 * K + 1;
+    AMP_ALLOC(pooled, float, (size_t)R * 49 * 256);
+    AMP_ALLOC(fc1, float, (size_t)R * 1024);
+    AMP_ALLOC(fc2, float, (size_t)R * 1024);
+    AMP_ALLOC(box_pred, float, (size_t)R * ld_box);
+    const int ccap = 8192;
+    const int D = c.detections_per_image;
+    AMP_ALLOC(dense_boxes, float, (size_t)R * K * 4);
+    AMP_ALLOC(bkeys, unsigned long long, (size_t)B * ccap);
+    AMP_ALLOC(bcount, int, (size_t)B);
+    AMP_ALLOC(bs_boxes, float, (size_t)B * ccap * 4);
+    AMP_ALLOC(bs_scores, float, (size_t)B * ccap);
+    AMP_ALLOC(bs_cats, int, (size_t)B * ccap);
+    AMP_ALLOC(bs_count, int, (size_t)B);
+    AMP_ALLOC(bnms_mask, unsigned long long, (size_t)B * ccap * (ccap / 64));
+    AMP_ALLOC(bkeep_idx, int, (size_t)B * D);
+    AMP_ALLOC(det_count, int, (size_t)B);
+    AMP_ALLOC(det_boxes, float, (size_t)B * D * 4);
+    AMP_ALLOC(det_scores, float, (size_t)B * D);
+    AMP_ALLOC(det_classes, int, (size_t)B * D);
+    if (!dry) {
+        AMP_TRY(amp_roi_align(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
+        AMP_TRY(amp_box_candidates(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
+                                   H, W, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
+        AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr));
+        AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
+        AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes));
+        tap(m, "box_pooled", pooled, 0, {R, 7, 7, 256});
+        tap(m, "box_pred", box_pred, 0, {R, ld_box});
+        tap(m, "det_boxes", det_boxes, 0, {B, D, 4});
+        tap(m, "det_scores", det_scores, 0, {B, D});
+        tap(m, "det_classes", det_classes, 1, {B, D});
+        tap(m, "det_count", det_count, 1, {B});
+    }
+
+    // ---------------- sync point: detection counts decide the mask-branch GEMM sizes ----------------
+    int N = B * D;   // dry run: worst case
+    std::vector<int> off(B + 1, 0);
+    if (!dry) {
+        AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts, det_count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (m->h_counts[B + 0]) { amp::set_error("amp_model_infer: more than %d box candidates above SCORE_THRESH_TEST in one image", ccap); return AMP_ERR_NOMEM; }
+        for (int b = 0; b < B; ++b) off[b + 1] = off[b] + std::min(m->h_counts[b], D);
+        N = off[B];
+    }
+
+    // compact detection list over the batch
+    AMP_ALLOC(m_boxes, float, (size_t)std::max(N, 1) * 4);
+    AMP_ALLOC(m_batch, int, (size_t)std::max(N, 1));
+    AMP_ALLOC(m_classes, int, (size_t)std::max(N, 1));
+    AMP_ALLOC(m_scores, float, (size_t)std::max(N, 1));
+    AMP_ALLOC(d_out_hw, int, (size_t)2 * B);
+    AMP_ALLOC(mpooled, float, (size_t)std::max(N, 1) * 196 * 256);
+    AMP_ALLOC(mt_a, float, (size_t)std::max(N, 1) * 196 * 256);
+    AMP_ALLOC(mt_b, float, (size_t)std::max(N, 1) * 784 * 256);
+    AMP_ALLOC(mlogits, float, (size_t)std::max(N, 1) * 784 * K);
+    AMP_ALLOC(mprob, float, (size_t)std::max(N, 1) * 784);
+    AMP_ALLOC(o_boxes, float, (size_t)std::max(N, 1) * 4);
+    AMP_ALLOC(o_valid, int, (size_t)std::max(N, 1));
+    AMP_ALLOC(o_off, unsigned long long, (size_t)std::max(N, 1));
+    AMP_ALLOC(o_len, int, (size_t)std::max(N, 1));
+    AMP_ALLOC(pool_used, unsigned long long, 1);
+    AMP_ALLOC(rle_pool, unsigned int, (size_t)c.rle_pool_counts);
+    if (dry) return AMP_OK;
+
+    m->r_out_h.assign(out_h, out_h + B);
+    m->r_out_w.assign(out_w, out_w + B);
+    int max_hw = 1;
+    for (int b = 0; b < B; ++b) max_hw = std::max(max_hw, std::max(out_h[b], out_w[b]));
+    AMP_REQUIRE(max_hw <= c.max_out_hw, "amp_model_infer: output size %d exceeds cfg.max_out_hw=%d", max_hw, c.max_out_hw);
+    for (int b = 0; b < B; ++b) { m->h_small[b] = out_h[b]; m->h_small[B + b] = out_w[b]; }
+    AMP_HIP_CHECK(hipMemcpyAsync(d_out_hw, m->h_small, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    AMP_HIP_CHECK(hipMemsetAsync(pool_used, 0, sizeof(unsigned long long), ctx->stream));
+    if (N > 0) {
+        for (int b = 0; b < B; ++b) {
+            const int nb = off[b + 1] - off[b];
+            if (!nb) continue;
+            AMP_HIP_CHECK(hipMemcpyAsync(m_boxes + (size_t)off[b] * 4, det_boxes + (size_t)b * D * 4, (size_t)nb * 16, hipMemcpyDeviceToDevice, ctx->stream));
+            AMP_HIP_CHECK(hipMemcpyAsync(m_classes + off[b], det_classes + (size_t)b * D, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            AMP_HIP_CHECK(hipMemcpyAsync(m_scores + off[b], det_scores + (size_t)b * D, (size_t)nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            for (int i = 0; i < nb; ++i) m->h_small[2 * B + off[b] + i] = b;
+        }
+        AMP_HIP_CHECK(hipMemcpyAsync(m_batch, m->h_small + 2 * B, (size_t)N * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        // ---------------- mask head ----------------
+        AMP_TRY(amp_roi_align(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
+        AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, K, mprob));
+        AMP_TRY(amp_paste_rle(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, c.mask_threshold, o_boxes,
+                              o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1));
+        tap(m, "mask_prob", mprob, 0, {N, 28, 28});
+        tap(m, "mask_rois", m_boxes, 0, {N, 4});
+    }
+
+    // ---------------- results to the host ----------------
+    std::vector<float> hb((size_t)N * 4), hs(N);
+    std::vector<int> hv(N), hc(N), hl(N);
+    std::vector<unsigned long long> ho(N);
+    unsigned long long used = 0;
+    if (N > 0) {
+        AMP_HIP_CHECK(hipMemcpyAsync(hb.data(), o_boxes, (size_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(hs.data(), m_scores, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(hc.data(), m_classes, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(hv.data(), o_valid, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(hl.data(), o_len, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(ho.data(), o_off, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(&used, pool_used, 8, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (m->h_counts[B + 1]) { amp::set_error("amp_model_infer: RLE pool (%zu counts) exhausted; raise cfg.rle_pool_counts", (size_t)c.rle_pool_counts); return AMP_ERR_NOMEM; }
+        // only the count halves of the pool are needed, but they are interleaved with the position scratch: copy the used prefix
+        m->r_pool.resize((size_t)used);
+        if (used) AMP_HIP_CHECK(hipMemcpy(m->r_pool.data(), rle_pool, (size_t)used * 4, hipMemcpyDeviceToHost));
+    } else {
+        m->r_pool.clear();
+    }
+    m->r_n.assign(B, 0);
+    m->r_boxes.assign((size_t)B * D * 4, 0.f);
+    m->r_scores.assign((size_t)B * D, 0.f);
+    m->r_classes.assign((size_t)B * D, -1);
+    m->r_rle_off.assign((size_t)B * D, 0ull);
+    m->r_rle_len.assign((size_t)B * D, 0);
+    for (int b = 0; b < B; ++b) {
+        int n = 0;
+        for (int i = off[b]; i < off[b + 1]; ++i) {
+            if (!hv[i]) continue;   // detector_postprocess drops boxes that are empty after rescale + clip
+            const size_t o = (size_t)b * D + n;
+            memcpy(&m->r_boxes[o * 4], &hb[(size_t)i * 4], 16);
+            m->r_scores[o] = hs[i];
+            m->r_classes[o] = hc[i];
+            m->r_rle_off[o] = ho[i];
+            m->r_rle_len[o] = hl[i];
+            ++n;
+        }
+        m->r_n[b] = n;
+    }
+    return AMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amp_model_cfg_default(amp_model_cfg* c) {
+    AMP_REQUIRE(c, "amp_model_cfg_default: null");
+    memset(c, 0, sizeof(*c));
+    c->num_classes = 80;
+    c->pixel_mean[0] = 103.530f; c->pixel_mean[1] = 116.280f; c->pixel_mean[2] = 123.675f;
+    c->pixel_std[0] = c->pixel_std[1] = c->pixel_std[2] = 1.0f;
+    c->pre_nms_topk = 1000; c->post_nms_topk = 1000; c->rpn_nms_thresh = 0.7f;
+    c->score_thresh = 0.05f; c->nms_thresh = 0.5f; c->detections_per_image = 100;
+    c->bbox_reg_weights[0] = c->bbox_reg_weights[1] = 10.f; c->bbox_reg_weights[2] = c->bbox_reg_weights[3] = 5.f;
+    c->mask_threshold = 0.5f;
+    c->max_batch = 1; c->max_h = 1344; c->max_w = 1344; c->max_out_hw = 4096;
+    c->rle_pool_counts = 0;
+    return AMP_OK;
+}
+
+int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
+    AMP_REQUIRE(ctx && cfg && out, "amp_model_create: null argument");
+    AMP_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 255, "amp_model_create: num_classes out of range");
+    AMP_REQUIRE(cfg->pre_nms_topk >= 1 && cfg->pre_nms_topk <= 1638, "amp_model_create: pre_nms_topk must be in [1,1638] (5 levels <= 8192 candidates)");
+    AMP_REQUIRE(cfg->post_nms_topk >= 1 && cfg->detections_per_image >= 1, "amp_model_create: bad topk");
+    AMP_REQUIRE(cfg->max_batch >= 1 && cfg->max_h >= 32 && cfg->max_w >= 32, "amp_model_create: bad capacity");
+    amp_model* m = new amp_model();
+    m->ctx = ctx;
+    m->cfg = *cfg;
+    if (m->cfg.rle_pool_counts == 0)
+        m->cfg.rle_pool_counts = (size_t)m->cfg.max_batch * m->cfg.detections_per_image * 16384;
+    const int K = cfg->num_classes;
+    build_expected(m);
+    // parameter arena: ~44.5 M floats + padding
+    m->parena_floats = (size_t)46 * 1000 * 1000 + (size_t)K * 6 * 1024 + 65536;
+    if (hipMalloc(&m->parena, m->parena_floats * sizeof(float)) != hipSuccess) {
+        amp::set_error("amp_model_create: hipMalloc of the parameter arena failed");
+        delete m;
+        return AMP_ERR_HIP;
+    }
+    // workspace: dry-run the plan at the maximum shape
+    m->ws.dry = true;
+    std::vector<int> oh(cfg->max_batch, cfg->max_out_hw), ow(cfg->max_batch, cfg->max_out_hw);
+    int st = run(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, oh.data(), ow.data());
+    if (st != AMP_OK) { (void)hipFree(m->parena); delete m; return st; }
+    m->ws.dry = false;
+    m->ws.cap = m->ws.peak + (1 << 20);
+    if (hipMalloc(&m->ws.base, m->ws.cap) != hipSuccess) {
+        amp::set_error("amp_model_create: hipMalloc of the %zu-byte workspace failed", m->ws.cap);
+        (void)hipFree(m->parena);
+        delete m;
+        return AMP_ERR_HIP;
+    }
+    const int R = cfg->max_batch * cfg->post_nms_topk;
+    std::vector<int> iota(R);
+    for (int i = 0; i < R; ++i) iota[i] = i / cfg->post_nms_topk;
+    (void)hipMalloc(&m->d_batch_iota, (size_t)R * sizeof(int));
+    (void)hipMemcpy(m->d_batch_iota, iota.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice);
+    (void)hipMalloc(&m->d_flags, 4 * sizeof(int));
+    (void)hipMemset(m->d_flags, 0, 4 * sizeof(int));
+    (void)hipHostMalloc(&m->h_counts, (size_t)(cfg->max_batch + 8) * sizeof(int));
+    (void)hipHostMalloc(&m->h_small, (size_t)(2 * cfg->max_batch + cfg->max_batch * cfg->detections_per_image + 8) * sizeof(int));
+    *out = m;
+    return AMP_OK;
+}
+
+void amp_model_destroy(amp_model* m) {
+    if (!m) return;
+    (void)hipFree(m->parena);
+    (void)hipFree(m->ws.base);
+    (void)hipFree(m->d_batch_iota);
+    (void)hipFree(m->d_flags);
+    (void)hipHostFree(m->h_counts);
+    (void)hipHostFree(m->h_small);
+    delete m;
+}
+
+size_t amp_model_workspace_bytes(amp_model* m) { return m ? m->ws.cap : 0; }
+
+int amp_model_num_tensors(amp_model* m) { return m ? (int)m->expected.size() : 0; }
+const char* amp_model_tensor_name(amp_model* m, int i) {
+    return (m && i >= 0 && i < (int)m->expected.size()) ? m->expected[i].c_str() : nullptr;
+}
+
+int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, const long long* shape, int ndim) {
+    AMP_REQUIRE(m && name_c && data && shape && ndim >= 1 && ndim <= 4, "amp_model_load_tensor: bad argument");
+    const std::string name(name_c);
+    bool known = false;
+    for (auto& e : m->expected) if (e == name) { known = true; break; }
+    AMP_REQUIRE(known, "amp_model_load_tensor: unknown tensor '%s'", name_c);
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    const int K = m->cfg.num_classes;
+    const std::string prefix = name.substr(0, name.rfind('.'));
+    const bool is_w = ends_with(name, ".weight");
+
+    auto put_conv = [&](const std::string& key, std::vector<float>&& v, int cout, int cin, int kh, int kw) -> int {
+        ConvW& cw = m->conv[key];
+        if (!cw.w) {
+            cw.w = palloc(m, v.size());
+            AMP_REQUIRE(cw.w, "amp_model_load_tensor: parameter arena exhausted at %s", name_c);
+        }
+        cw.cout = cout; cw.cin = cin; cw.kh = kh; cw.kw = kw;
+        return upload(m, cw.w, v);
+    };
+    auto put_shift = [&](const std::string& key, const std::vector<float>& v) -> int {
+        ConvW& cw = m->conv[key];
+        if (!cw.shift) {
+            cw.shift = palloc(m, v.size());
+            AMP_REQUIRE(cw.shift, "amp_model_load_tensor: parameter arena exhausted at %s", name_c);
+        }
+        return upload(m, cw.shift, v);
+    };
+
+    if (name.find(".norm.") != std::string::npos) {
+        m->host_raw[name].assign(data, data + numel);           // folded at finalize
+    } else if (name == "backbone.bottom_up.stem.conv1.weight") {
+        AMP_REQUIRE(ndim == 4 && shape[0] == 64 && shape[1] == 3 && shape[2] == 7 && shape[3] == 7, "%s: expected [64,3,7,7]", name_c);
+        AMP_TRY(put_conv(prefix, oihw_to_ohwi(data, 64, 3, 7, 7, 4, 8), 64, 4, 7, 8));
+    } else if (prefix == "roi_heads.box_head.fc1") {
+        if (is_w) {
+            AMP_REQUIRE(ndim == 2 && shape[0] == 1024 && shape[1] == 12544, "%s: expected [1024,12544]", name_c);
+            std::vector<float> v(numel);
+            for (int o = 0; o < 1024; ++o)
+                for (int ch = 0; ch < 256; ++ch)
+                    for (int p = 0; p < 49; ++p) v[(size_t)o * 12544 + p * 256 + ch] = data[(size_t)o * 12544 + ch * 49 + p];
+            AMP_TRY(put_conv(prefix, std::move(v), 1024, 12544, 1, 1));
+        } else {
+            AMP_REQUIRE(numel == 1024, "%s: expected [1024]", name_c);
+            AMP_TRY(put_shift(prefix, std::vector<float>(data, data + numel)));
+        }
+    } else if (prefix == "roi_heads.box_head.fc2") {
+        if (is_w) {
+            AMP_REQUIRE(ndim == 2 && shape[0] == 1024 && shape[1] == 1024, "%s: expected [1024,1024]", name_c);
+            AMP_TRY(put_conv(prefix, std::vector<float>(data, data + numel), 1024, 1024, 1, 1));
+        } else {
+            AMP_TRY(put_shift(prefix, std::vector<float>(data, data + numel)));
+        }
+    } else if (prefix == "roi_heads.box_predictor.cls_score" || prefix == "roi_heads.box_predictor.bbox_pred" ||
+               prefix == "proposal_generator.rpn_head.objectness_logits" || prefix == "proposal_generator.rpn_head.anchor_deltas") {
+        const bool first = prefix.find("cls_score") != std::string::npos || prefix.find("objectness") != std::string::npos;
+        const bool box = prefix.find("box_predictor") != std::string::npos;
+        const size_t rows = box ? (first ? K + 1 : 4 * K) : (first ? 3 : 12);
+        const size_t cols = box ? 1024 : 256;
+        AMP_REQUIRE(numel == rows * (is_w ? cols : 1), "%s: unexpected size %zu", name_c, numel);
+        m->host_raw[name].assign(data, data + numel);           // fused at finalize
+    } else if (prefix == "roi_heads.mask_head.deconv") {
+        if (is_w) {
+            AMP_REQUIRE(ndim == 4 && shape[0] == 256 && shape[1] == 256 && shape[2] == 2 && shape[3] == 2, "%s: expected [256,256,2,2]", name_c);
+            std::vector<float> v(numel);
+            for (int ci = 0; ci < 256; ++ci)
+                for (int co = 0; co < 256; ++co)
+                    for (int ky = 0; ky < 2; ++ky)
+                        for (int kx = 0; kx < 2; ++kx)
+                            v[((size_t)(ky * 2 + kx) * 256 + co) * 256 + ci] = data[(((size_t)ci * 256 + co) * 2 + ky) * 2 + kx];
+            AMP_TRY(put_conv(prefix, std::move(v), 1024, 256, 1, 1));
+        } else {
+            AMP_REQUIRE(numel == 256, "%s: expected [256]", name_c);
+            std::vector<float> v(1024);
+            for (int q = 0; q < 4; ++q) for (int co = 0; co < 256; ++co) v[q * 256 + co] = data[co];
+            AMP_TRY(put_shift(prefix, v));
+        }
+    } else if (is_w) {
+        AMP_REQUIRE(ndim == 4, "%s: expected a 4-d conv weight", name_c);
+        const int O = (int)shape[0], I = (int)shape[1], KH = (int)shape[2], KW = (int)shape[3];
+        AMP_REQUIRE(I % 4 == 0, "%s: Cin %% 4 != 0", name_c);
+        AMP_TRY(put_conv(prefix, oihw_to_ohwi(data, O, I, KH, KW, I, KW), O, I, KH, KW));
+    } else {
+        AMP_TRY(put_shift(prefix, std::vector<float>(data, data + numel)));
+    }
+    m->loaded[name] = true;
+    m->finalized = false;
+    return AMP_OK;
+}
+
+int amp_model_finalize(amp_model* m) {
+    AMP_REQUIRE(m, "amp_model_finalize: null");
+    for (auto& e : m->expected)
+        AMP_REQUIRE(m->loaded.count(e), "amp_model_finalize: tensor '%s' was never loaded", e.c_str());
+    const int K = m->cfg.num_classes;
+    // FrozenBN -> scale = w * rsqrt(var + eps), shift = b - mean * scale (detectron2 FrozenBatchNorm2d, fp32)
+    for (auto& kv : m->conv) {
+        const std::string& p = kv.first;
+        auto it = m->host_raw.find(p + ".norm.weight");
+        if (it == m->host_raw.end()) continue;
+        const auto& g = it->second;
+        const auto& be = m->host_raw.at(p + ".norm.bias");
+        const auto& mu = m->host_raw.at(p + ".norm.running_mean");
+        const auto& var = m->host_raw.at(p + ".norm.running_var");
+        const size_t n = g.size();
+        AMP_REQUIRE((int)n == kv.second.cout && be.size() == n && mu.size() == n && var.size() == n, "amp_model_finalize: BN size mismatch at %s", p.c_str());
+        std::vector<float> sc(n), sh(n);
+        for (size_t i = 0; i < n; ++i) {
+            sc[i] = g[i] * (1.0f / sqrtf(var[i] + 1e-5f));
+            sh[i] = be[i] - mu[i] * sc[i];
+        }
+        ConvW& cw = kv.second;
+        if (!cw.scale) { cw.scale = palloc(m, n); AMP_REQUIRE(cw.scale, "amp_model_finalize: parameter arena exhausted"); }
+        if (!cw.shift) { cw.shift = palloc(m, n); AMP_REQUIRE(cw.shift, "amp_model_finalize: parameter arena exhausted"); }
+        AMP_TRY(upload(m, cw.scale, sc));
+        AMP_TRY(upload(m, cw.shift, sh));
+    }
+    auto fuse = [&](const char* key, const char* a, const char* b, int ra, int rb, int cols) -> int {
+        std::vector<float> w((size_t)(ra + rb) * cols), bias(ra + rb);
+        const auto& wa = m->host_raw.at(std::string(a) + ".weight");
+        const auto& wb = m->host_raw.at(std::string(b) + ".weight");
+        const auto& ba = m->host_raw.at(std::string(a) + ".bias");
+        const auto& bb = m->host_raw.at(std::string(b) + ".bias");
+        memcpy(w.data(), wa.data(), wa.size() * 4);
+        memcpy(w.data() + wa.size(), wb.data(), wb.size() * 4);
+        memcpy(bias.data(), ba.data(), ba.size() * 4);
+        memcpy(bias.data() + ba.size(), bb.data(), bb.size() * 4);
+        ConvW& cw = m->conv[key];
+        if (!cw.w) { cw.w = palloc(m, w.size()); cw.shift = palloc(m, bias.size()); }
+        AMP_REQUIRE(cw.w && cw.shift, "amp_model_finalize: parameter arena exhausted");
+        cw.cout = ra + rb; cw.cin = cols; cw.kh = cw.kw = 1;
+        AMP_TRY(upload(m, cw.w, w));
+        return upload(m, cw.shift, bias);
+    };
+    AMP_TRY(fuse("proposal_generator.rpn_head.pred", "proposal_generator.rpn_head.objectness_logits",
+                 "proposal_generator.rpn_head.anchor_deltas", 3, 12, 256));
+    AMP_TRY(fuse("roi_heads.box_predictor", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred", K + 1, 4 * K, 1024));
+    m->finalized = true;
+    return AMP_OK;
+}
+
+int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const int* out_h_h,
+                    const int* out_w_h, amp_dets* out) {
+    AMP_REQUIRE(m && imgs_bgr && out, "amp_model_infer: null argument");
+    AMP_REQUIRE(m->finalized, "amp_model_infer: call amp_model_finalize after loading every tensor");
+    const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+    AMP_REQUIRE(B >= 1 && B <= m->cfg.max_batch && H >= 1 && W >= 1 && Hp <= m->cfg.max_h && Wp <= m->cfg.max_w &&
+                (size_t)Hp * Wp <= (size_t)m->cfg.max_h * m->cfg.max_w,
+                "amp_model_infer: batch %dx%dx%d exceeds the capacity the model was created with (%dx%dx%d)", B, H, W,
+                m->cfg.max_batch, m->cfg.max_h, m->cfg.max_w);
+    std::vector<int> oh(B, H), ow(B, W);
+    if (out_h_h && out_w_h) { oh.assign(out_h_h, out_h_h + B); ow.assign(out_w_h, out_w_h + B); }
+    AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
+    AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, 4 * sizeof(int), m->ctx->stream));
+    const uint8_t* imgs_d = imgs_bgr;
+    uint8_t* staged = nullptr;
+    if (imgs_on_host) {
+        AMP_HIP_CHECK(hipMalloc(&staged, (size_t)B * H * W * 3));
+        AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
+        imgs_d = staged;
+    }
+    const int st = run(m, imgs_d, B, H, W, oh.data(), ow.data());
+    if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
+    if (st != AMP_OK) return st;
+    out->B = B;
+    out->D = m->cfg.detections_per_image;
+    out->n = m->r_n.data();
+    out->boxes = m->r_boxes.data();
+    out->scores = m->r_scores.data();
+    out->classes = m->r_classes.data();
+    out->rle_off = m->r_rle_off.data();
+    out->rle_len = m->r_rle_len.data();
+    out->rle_counts = m->r_pool.data();
+    out->out_h = m->r_out_h.data();
+    out->out_w = m->r_out_w.data();
+    return AMP_OK;
+}
+
+int amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]) {
+    AMP_REQUIRE(m && name && ptr && dtype && ndim && shape, "amp_model_get_tap: null argument");
+    auto it = m->taps.find(name);
+    AMP_REQUIRE(it != m->taps.end(), "amp_model_get_tap: no buffer named '%s' (run amp_model_infer first)", name);
+    *ptr = it->second.ptr; *dtype = it->second.dtype; *ndim = it->second.ndim;
+    for (int i = 0; i < 5; ++i) shape[i] = i < it->second.ndim ? it->second.shape[i] : 1;
+    return AMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// Host-side COCO RLE codec of the C ABI.  Replaces the pycocotools.mask calls AMPIS makes on the
+// output of the hot path: encode (ampis/data_utils.py:275), decode/area (ampis/structures.py:465-468,568,752),
+// iou (ampis/analyze.py:108,158), merge (ampis/analyze.py:315-321, ampis/applications/powder.py:82-83).
+// pycocotools 2.0.4 (docker/env.yml:21) is not vendored in the reference; this follows its published format:
+// column-major runs alternating 0/1 starting with a 0-run; the `counts` string stores each run as 5-bit groups, LSB first,
+// char = group + 48, bit 0x20 = continuation, bit 0x10 of the last group = sign, runs i > 2 stored as a delta against
+// run i-2.  Byte format pinned by the reference's five result pickles (tests/golden/rle_pickles.json).
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+extern "C" {
+
+int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t* len) {
+    AMP_REQUIRE((cnts || m == 0) && out && len && m >= 0, "amp_rle_to_string: bad argument");
+    size_t p = 0;
+    for (int i = 0; i < m; ++i) {
+        long long x = (long long)cnts[i];
+        if (i > 2) x -= (long long)cnts[i - 2];
+        bool more = true;
+        while (more) {
+            int c = (int)(x & 0x1f);
+            x >>= 5;   // arithmetic shift keeps the sign
+            more = (c & 0x10) ? (x != -1) : (x != 0);
+            if (more) c |= 0x20;
+            AMP_REQUIRE(p + 1 < cap, "amp_rle_to_string: output buffer too small (cap=%zu)", cap);
+            out[p++] = (char)(c + 48);
+        }
+    }
+    out[p] = 0;
+    *len = p;
+    return AMP_OK;
+}
+
+int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int* m_out) {
+    AMP_REQUIRE((s || len == 0) && cnts && m_out, "amp_rle_from_string: null argument");
+    int m = 0;
+    size_t p = 0;
+    while (p < len) {
+        long long x = 0;
+        int k = 0;
+        bool more = true;
+        while (more) {
+            AMP_REQUIRE(p < len, "amp_rle_from_string: truncated counts string");
+            const int c = (int)(unsigned char)s[p] - 48;
+            x |= (long long)(c & 0x1f) << (5 * k);
+            more = (c & 0x20) != 0;
+            ++p;
+            ++k;
+            if (!more && (c & 0x10)) x |= -1ll << (5 * k);
+        }
+        if (m > 2) x += (long long)cnts[m - 2];
+        AMP_REQUIRE(m < cap, "amp_rle_from_string: more than cap=%d runs", cap);
+        cnts[m++] = (uint32_t)x;
+    }
+    *m_out = m;
+    return AMP_OK;
+}
+
+// mask: column-major (Fortran order) h*w bytes, non-zero = foreground.
+int amp_rle_encode(const uint8_t* mask_colmajor, int h, int w, uint32_t* cnts, int cap, int* m_out) {
+    AMP_REQUIRE(mask_colmajor && cnts && m_out && h >= 0 && w >= 0, "amp_rle_encode: bad argument");
+    const size_t a = (size_t)h * w;
+    int m = 0;
+    uint32_t c = 0;
+    uint8_t p = 0;
+    for (size_t j = 0; j < a; ++j) {
+        const uint8_t v = mask_colmajor[j] ? 1 : 0;
+        if (v != p) {
+            AMP_REQUIRE(m < cap, "amp_rle_encode: more than cap=%d runs", cap);
+            cnts[m++] = c;
+            c = 0;
+            p = v;
+        }
+        ++c;
+    }
+    AMP_REQUIRE(m < cap, "amp_rle_encode: more than cap=%d runs", cap);
+    cnts[m++] = c;
+    *m_out = m;
+    return AMP_OK;
+}
+
+int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colmajor) {
+    AMP_REQUIRE((cnts || m == 0) && mask_colmajor, "amp_rle_decode: null argument");
+    const size_t a = (size_t)h * w;
+    size_t pos = 0;
+    uint8_t v = 0;
+    for (int i = 0; i < m; ++i) {
+        AMP_REQUIRE(pos + cnts[i] <= a, "amp_rle_decode: runs exceed h*w");
+        std::fill(mask_colmajor + pos, mask_colmajor + pos + cnts[i], v);
+        pos += cnts[i];
+        v = !v;
+    }
+    AMP_REQUIRE(pos == a, "amp_rle_decode: runs sum to %zu, expected %zu", pos, a);
+    return AMP_OK;
+}
+
+int amp_rle_area(const uint32_t* cnts, int m, unsigned long long* area) {
+    AMP_REQUIRE((cnts || m == 0) && area, "amp_rle_area: null argument");
+    unsigned long long s = 0;
+    for (int i = 1; i < m; i += 2) s += cnts[i];
+    *area = s;
+    return AMP_OK;
+}
+
+}  // extern "C"
+
+// Walk two run lists in lock step; fn(len, va, vb) for each maximal stretch where both values are constant.
+template <class F>
+static void rle_zip(const uint32_t* A, int ka, const uint32_t* B, int kb, F fn) {
+    unsigned long long ca = ka ? A[0] : 0, cb = kb ? B[0] : 0;
+    int a = 1, b = 1;
+    bool va = false, vb = false;
+    unsigned long long ct = 1;
+    while (ct > 0) {
+        const unsigned long long c = std::min(ca, cb);
+        fn(c, va, vb);
+        ct = 0;
+        ca -= c;
+        if (!ca && a < ka) { ca = A[a++]; va = !va; }
+        ct += ca;
+        cb -= c;
+        if (!cb && b < kb) { cb = B[b++]; vb = !vb; }
+        ct += cb;
+    }
+}
+
+extern "C" {
+
+// IoU of mask d (dt) against mask g (gt); iscrowd: union replaced by area(dt). Same values as pycocotools rleIou
+// (0 when the intersection is empty).
+int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscrowd, double* iou) {
+    AMP_REQUIRE(dt && gt && iou && md > 0 && mg > 0, "amp_rle_iou: bad argument");
+    unsigned long long i = 0, u = 0;
+    rle_zip(dt, md, gt, mg, [&](unsigned long long c, bool va, bool vb) {
+        if (va || vb) {
+            u += c;
+            if (va && vb) i += c;
+        }
+    });
+    if (i == 0) u = 1;
+    else if (iscrowd) (void)amp_rle_area(dt, md, &u);
+    *iou = (double)i / (double)u;
+    return AMP_OK;
+}
+
+// out = A & B (intersect != 0) or A | B, both over the same h*w. Returns the number of runs in *m_out.
+int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out) {
+    AMP_REQUIRE(A && B && out && m_out && ka > 0 && kb > 0, "amp_rle_merge2: bad argument");
+    int m = 0;
+    bool v = false;
+    unsigned long long cc = 0;
+    bool overflow = false;
+    unsigned long long ca = A[0], cb = B[0];
+    int a = 1, b = 1;
+    bool va = false, vb = false;
+    unsigned long long ct = 1;
+    while (ct > 0) {
+        const unsigned long long c = std::min(ca, cb);
+        cc += c;
+        ct = 0;
+        ca -= c;
+        if (!ca && a < ka) { ca = A[a++]; va = !va; }
+        ct += ca;
+        cb -= c;
+        if (!cb && b < kb) { cb = B[b++]; vb = !vb; }
+        ct += cb;
+        const bool vp = v;
+        v = intersect ? (va && vb) : (va || vb);
+        if (v != vp || ct == 0) {
+            if (m < cap) out[m++] = (uint32_t)cc; else overflow = true;
+            cc = 0;
+        }
+    }
+    AMP_REQUIRE(!overflow, "amp_rle_merge2: more than cap=%d runs", cap);
+    *m_out = m;
+    return AMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,126 @@
+// RoIAlign (aligned=True, sampling_ratio=0) over the FPN levels p2..p5 with the level assignment fused.
+//
+// Replaces detectron2 ROIPooler.forward -> torchvision.ops.roi_align (App. A.4):
+//   level = clamp(floor(4 + log2(sqrt(area) / 224 + 1e-8)), 2, 5)
+//   roi*scale - 0.5, bin = roi_size / P, sampling grid ceil(roi_h / P) x ceil(roi_w / P), bilinear taps with the
+//   torchvision edge rules, mean over the grid.  Arithmetic order follows roi_align_kernel (fp32, no contraction):
+//   acc += ((w1*v1 + w2*v2) + w3*v3) + w4*v4, iy outer / ix inner, then acc / count.
+//
+// Layout: features NHWC; output [R][P][P][C].  One wavefront per output bin: 64 lanes x float4 = 256 channels, so
+// every tap is one fully coalesced 1 KiB read; HBM/L2-gather bound, no LDS needed.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RoiArgs {
+    const float* feat[4];
+    int fh[4], fw[4];
+    float scale[4];
+    const float* rois;      // [R,4] x1,y1,x2,y2
+    const int* batch_idx;   // [R] (may be null -> all 0)
+    const int* roi_count;   // device int: number of valid rois (may be null -> R)
+    float* out;             // [R,P,P,C]
+    int* level_out;         // [R] (may be null)
+    int R, P, C;
+};
+
+__device__ __forceinline__ int assign_level(float x1, float y1, float x2, float y2) {
+    const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    const float sz = sqrtf(area);
+    float lv = floorf(__fadd_rn(4.0f, log2f(__fadd_rn(__fdiv_rn(sz, 224.0f), 1e-8f))));
+    lv = fminf(fmaxf(lv, 2.0f), 5.0f);   // NaN (negative area) -> fmaxf picks 2
+    return (int)lv - 2;
+}
+
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
+    const long long nbins = (long long)nvalid * a.P * a.P;
+    const int C4 = a.C >> 2;
+    for (long long bin = (long long)blockIdx.x * 4 + wave; bin < nbins; bin += (long long)gridDim.x * 4) {
+        const int pw = (int)(bin % a.P);
+        const int ph = (int)((bin / a.P) % a.P);
+        const int r = (int)(bin / (a.P * a.P));
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        if (a.level_out && ph == 0 && pw == 0 && lane == 0) a.level_out[r] = lv;
+        const int b = a.batch_idx ? a.batch_idx[r] : 0;
+        const int H = a.fh[lv], W = a.fw[lv];
+        const float sc = a.scale[lv];
+        const float sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f);
+        const float sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+        const float ew = __fsub_rn(__fmul_rn(x2, sc), 0.5f);
+        const float eh = __fsub_rn(__fmul_rn(y2, sc), 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)a.P), bw = __fdiv_rn(rw, (float)a.P);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
+        const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
+        const float count = (float)max(gh * gw, 1);
+        const f32x4* f4 = reinterpret_cast<const f32x4*>(a.feat[lv]) + (size_t)b * H * W * C4;
+        f32x4* o4 = reinterpret_cast<f32x4*>(a.out) + (size_t)bin * C4;
+        for (int c = lane; c < C4; c += 64) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int iy = 0; iy < gh; ++iy) {
+                float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)),
+                                    __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+                const bool ybad = (y < -1.0f) || (y > (float)H);
+                if (y <= 0.f) y = 0.f;
+                int ylo = (int)y, yhi;
+                if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+                const float ly = __fsub_rn(y, (float)ylo), hy = __fsub_rn(1.0f, ly);
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)),
+                                        __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                    const bool bad = ybad || (x < -1.0f) || (x > (float)W);
+                    if (bad) continue;
+                    if (x <= 0.f) x = 0.f;
+                    int xlo = (int)x, xhi;
+                    if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+                    const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
+                    const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                    const f32x4 v1 = f4[((size_t)ylo * W + xlo) * C4 + c];
+                    const f32x4 v2 = f4[((size_t)ylo * W + xhi) * C4 + c];
+                    const f32x4 v3 = f4[((size_t)yhi * W + xlo) * C4 + c];
+                    const f32x4 v4 = f4[((size_t)yhi * W + xhi) * C4 + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])),
+                                                            __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
+                        acc[e] = __fadd_rn(acc[e], s);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __fdiv_rn(acc[e], count);
+            o4[c] = acc;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx,
+                             const int* roi_count, int R, int P, float* out, int* level_out) {
+    AMP_REQUIRE(ctx && f && rois && out, "amp_roi_align: null argument");
+    AMP_REQUIRE(R >= 0 && P > 0 && f->C % 4 == 0, "amp_roi_align: bad shape");
+    if (R == 0) return AMP_OK;
+    RoiArgs a;
+    for (int l = 0; l < 4; ++l) {
+        AMP_REQUIRE(f->feat[l] && f->h[l] > 0 && f->w[l] > 0, "amp_roi_align: missing level %d", l + 2);
+        a.feat[l] = f->feat[l];
+        a.fh[l] = f->h[l];
+        a.fw[l] = f->w[l];
+        a.scale[l] = 1.0f / (float)f->stride[l];
+    }
+    a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
+    a.R = R; a.P = P; a.C = f->C;
+    const long long nbins = (long long)R * P * P;
+    long long g = (nbins + 3) / 4;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}

@@ -1,0 +1,329 @@
+// RPN proposal candidate selection (detectron2 proposal_utils.find_top_rpn_proposals, first half):
+//   1. per (image, level): top-k anchors by objectness logit (k = min(PRE_NMS_TOPK, H*W*A)), order = logit descending,
+//      ties by ascending anchor index (the order oracle/maskrcnn.py fixes; torch.topk leaves ties unspecified)
+//   2. decode the selected anchors (Box2BoxTransform.apply_deltas, weights 1,1,1,1, scale clamp ln(1000/16)), clip to the
+//      image, mark non-finite / empty (w <= 0 or h <= 0) boxes invalid
+//   3. per image: order all levels' candidates by (logit desc, concatenated position asc), invalid last
+// Integer / ordering work is exact; the decode arithmetic follows the oracle's fp32 op order (no contraction).
+//
+// Kernel 1 is a radix select (4 x 8-bit digits on the order-preserving uint32 image of the logit) done by one 1024-thread
+// workgroup per segment with LDS histograms, then a wave-ballot compaction in index order and an LDS bitonic sort of the
+// <= 2048 survivors.  Kernel 3 is an LDS bitonic sort of 64-bit (key, ~position) words, <= 8192 per image.
+#include "common.h"
+
+namespace {
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int MAX_K = 2048;
+constexpr int MAX_LEVELS = 5;
+
+using amp::f2ord;
+using amp::ord2f;
+
+struct TopkArgs {
+    const float* pred[MAX_LEVELS];   // RPN predictor output per level: [B, H*W, ld] with logits in columns [0, A)
+    int hw[MAX_LEVELS];
+    int nlevels, A, ld, k;
+    uint32_t* keys_scratch;          // [B*nlevels][max_n] ordered keys (coalesced re-reads)
+    int max_n;
+    int* sel_idx;                    // [B][nlevels][k] anchor index within the level, sorted
+    float* sel_logit;                // [B][nlevels][k]
+    int* sel_count;                  // [B][nlevels]
+};
+
+// In-LDS bitonic sort, descending, of N (power of two) 64-bit words by all threads of the block.
+template <int NT>
+__device__ void bitonic_desc(unsigned long long* s, int N) {
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (N >> 1); t += NT) {
+                const int lo = (t / stride) * (stride << 1) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = s[lo], b = s[hi];
+                if ((a < b) == desc) { s[lo] = b; s[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int s_prefix, s_remaining;
+    __shared__ unsigned int wave_gt[16], wave_eq[16];
+    __shared__ unsigned long long sorted[MAX_K];
+
+    const int seg = blockIdx.x;
+    const int b = seg / a.nlevels, lvl = seg % a.nlevels;
+    const int n = a.hw[lvl] * a.A;
+    const int k = min(a.k, n);
+    const float* pred = a.pred[lvl] + (size_t)b * a.hw[lvl] * a.ld;
+    uint32_t* keys = a.keys_scratch + (size_t)seg * a.max_n;
+    const int tid = threadIdx.x;
+
+    // pass 0: strided gather of the logits -> compact ordered keys, histogram of the top digit
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += TOPK_THREADS) {
+        const int pix = i / a.A, an = i - pix * a.A;
+        const uint32_t key = f2ord(pred[(size_t)pix * a.ld + an]);
+        keys[i] = key;
+        atomicAdd(&hist[key >> 24], 1u);
+    }
+    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)k; }
+    __syncthreads();
+
+    // 4 digit rounds: find the k-th largest key T
+    for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        if (round > 0) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const uint32_t himask = 0xffffffffu << (shift + 8);
+            for (int i = tid; i < n; i += TOPK_THREADS) {
+                const uint32_t key = keys[i];
+                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            unsigned int rem = s_remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                const unsigned int c = hist[d];
+                if (c >= rem) break;
+                rem -= c;
+            }
+            s_prefix |= ((uint32_t)d << shift);
+            s_remaining = rem;   // how many are still needed from keys sharing the chosen prefix
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;
+    const unsigned int need_eq = s_remaining;   // number of keys == T to take (smallest indices first)
+
+    // compaction in index order: wave w owns the contiguous range [w*chunk, (w+1)*chunk)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int chunk = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
+    const int beg = wave * chunk, end = min(n, beg + chunk);
+    unsigned int cgt = 0, ceq = 0;
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = (i < end) ? keys[i] : 0u;
+        const bool gt = (i < end) && key > T, eq = (i < end) && key == T;
+        cgt += __popcll(__ballot(gt));
+        ceq += __popcll(__ballot(eq));
+    }
+    if (lane == 0) { wave_gt[wave] = cgt; wave_eq[wave] = ceq; }
+    __syncthreads();
+    unsigned int gt_before = 0, eq_before = 0, gt_total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { gt_before += wave_gt[w]; eq_before += wave_eq[w]; }
+        gt_total += wave_gt[w];
+    }
+    // slot layout: [0, gt_total) = keys > T in index order, [gt_total, k) = first need_eq keys == T in index order
+    for (int i = tid; i < MAX_K; i += TOPK_THREADS) sorted[i] = 0ull;
+    __syncthreads();
+    unsigned int rgt = gt_before, req = eq_before;
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = (i < end) ? keys[i] : 0u;
+        const bool gt = (i < end) && key > T, eq = (i < end) && key == T;
+        const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+        if (gt) sorted[rgt + __popcll(mgt & below)] = word;
+        if (eq) {
+            const unsigned int r = req + __popcll(meq & below);
+            if (r < need_eq) sorted[gt_total + r] = word;
+        }
+        rgt += __popcll(mgt);
+        req += __popcll(meq);
+    }
+    __syncthreads();
+    int N = 64;
+    while (N < k) N <<= 1;
+    bitonic_desc<TOPK_THREADS>(sorted, N);
+    for (int i = tid; i < k; i += TOPK_THREADS) {
+        const unsigned long long wv = sorted[i];
+        a.sel_idx[(size_t)seg * a.k + i] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
+        a.sel_logit[(size_t)seg * a.k + i] = ord2f((uint32_t)(wv >> 32));
+    }
+    if (tid == 0) a.sel_count[seg] = k;
+}
+
+struct DecodeArgs {
+    const float* pred[MAX_LEVELS];
+    int hw[MAX_LEVELS], fw[MAX_LEVELS], stride[MAX_LEVELS];
+    float cell[MAX_LEVELS][3][4];    // cell anchors per level (A = 3)
+    int nlevels, A, ld, k;
+    const int* sel_idx;
+    const float* sel_logit;
+    const int* sel_count;
+    float img_h, img_w;
+    float scale_clamp;
+    int cap;                         // capacity per image of the outputs (>= nlevels*k)
+    float* boxes;                    // [B][cap][4] clipped boxes
+    unsigned long long* sortkey;     // [B][cap]: (ord(logit) << 32) | ~pos, 0 when invalid / unused
+};
+
+__global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
+    const int per_img = a.nlevels * a.k;
+    const int total = B * a.cap;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int b = t / a.cap, pos = t - b * a.cap;
+        unsigned long long key = 0ull;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        // position in the level-major concatenation: level lvl contributes sel_count[b][lvl] entries
+        if (pos < per_img) {
+            int lvl = 0, off = pos;
+            while (lvl < a.nlevels && off >= a.sel_count[b * a.nlevels + lvl]) { off -= a.sel_count[b * a.nlevels + lvl]; ++lvl; }
+            if (lvl < a.nlevels) {
+                const int seg = b * a.nlevels + lvl;
+                const int idx = a.sel_idx[(size_t)seg * a.k + off];
+                const float logit = a.sel_logit[(size_t)seg * a.k + off];
+                const int pix = idx / a.A, an = idx - pix * a.A;
+                const int py = pix / a.fw[lvl], px = pix - py * a.fw[lvl];
+                const float sx = (float)(px * a.stride[lvl]), sy = (float)(py * a.stride[lvl]);
+                const float ax1 = __fadd_rn(sx, a.cell[lvl][an][0]), ay1 = __fadd_rn(sy, a.cell[lvl][an][1]);
+                const float ax2 = __fadd_rn(sx, a.cell[lvl][an][2]), ay2 = __fadd_rn(sy, a.cell[lvl][an][3]);
+                const float* d = a.pred[lvl] + ((size_t)b * a.hw[lvl] + pix) * a.ld + a.A + an * 4;
+                const float w = __fsub_rn(ax2, ax1), h = __fsub_rn(ay2, ay1);
+                const float cx = __fadd_rn(ax1, __fmul_rn(0.5f, w)), cy = __fadd_rn(ay1, __fmul_rn(0.5f, h));
+                const float dx = d[0], dy = d[1];
+                const float dw = fminf(d[2], a.scale_clamp), dh = fminf(d[3], a.scale_clamp);
+                const float pcx = __fadd_rn(__fmul_rn(dx, w), cx), pcy = __fadd_rn(__fmul_rn(dy, h), cy);
+                const float pw = __fmul_rn(expf(dw), w), ph = __fmul_rn(expf(dh), h);
+                x1 = __fsub_rn(pcx, __fmul_rn(0.5f, pw));
+                y1 = __fsub_rn(pcy, __fmul_rn(0.5f, ph));
+                x2 = __fadd_rn(pcx, __fmul_rn(0.5f, pw));
+                y2 = __fadd_rn(pcy, __fmul_rn(0.5f, ph));
+                const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(logit);
+                x1 = fminf(fmaxf(x1, 0.f), a.img_w); x2 = fminf(fmaxf(x2, 0.f), a.img_w);
+                y1 = fminf(fmaxf(y1, 0.f), a.img_h); y2 = fminf(fmaxf(y2, 0.f), a.img_h);
+                const bool nonempty = (__fsub_rn(x2, x1) > 0.f) && (__fsub_rn(y2, y1) > 0.f);
+                if (finite && nonempty) {
+                    key = amp::make_sortkey(f2ord(logit), pos, lvl);
+                }
+            }
+        }
+        float* o = a.boxes + (size_t)t * 4;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        a.sortkey[t] = key;
+    }
+}
+
+// Per image: sort cap (<= 8192) 64-bit keys descending; emit sorted boxes / scores / categories and the valid count.
+constexpr int SORT_THREADS = 1024;
+__global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(const unsigned long long* sortkey, const float* boxes_in,
+                                                                  int cap, int box_stride, int N, float* boxes_out,
+                                                                  float* score_out, int* cat_out, int* count_out,
+                                                                  int* pos_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < N; i += SORT_THREADS) skeys[i] = (i < cap) ? sortkey[(size_t)b * cap + i] : 0ull;
+    __syncthreads();
+    bitonic_desc<SORT_THREADS>(skeys, N);
+    int cnt = 0;
+    for (int i = threadIdx.x; i < cap; i += SORT_THREADS) {
+        const unsigned long long kv = skeys[i];
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, sc = 0.f;
+        int cat = -1, pos = -1;
+        if (kv != 0ull) {
+            pos = amp::sortkey_pos(kv);
+            cat = amp::sortkey_cat(kv);
+            sc = ord2f((uint32_t)(kv >> 32));
+            const float* s = boxes_in + ((size_t)b * box_stride + pos) * 4;
+            x1 = s[0]; y1 = s[1]; x2 = s[2]; y2 = s[3];
+            ++cnt;
+        }
+        float* o = boxes_out + ((size_t)b * cap + i) * 4;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        score_out[(size_t)b * cap + i] = sc;
+        cat_out[(size_t)b * cap + i] = cat;
+        if (pos_out) pos_out[(size_t)b * cap + i] = pos;
+    }
+    // block reduce of the valid count (counter lives behind the keys: keep all LDS in the one dynamic region)
+    int* s_cnt = reinterpret_cast<int*>(skeys + N);
+    __syncthreads();
+    if (threadIdx.x == 0) *s_cnt = 0;
+    __syncthreads();
+    atomicAdd(s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) count_out[b] = *s_cnt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t* keys_scratch, int max_n, int* sel_idx,
+                 float* sel_logit, int* sel_count) {
+    AMP_REQUIRE(ctx && lv && keys_scratch && sel_idx && sel_logit && sel_count, "amp_rpn_topk: null argument");
+    AMP_REQUIRE(lv->nlevels >= 1 && lv->nlevels <= MAX_LEVELS && lv->A == 3, "amp_rpn_topk: need 1..5 levels, A == 3");
+    AMP_REQUIRE(k >= 1 && k <= MAX_K, "amp_rpn_topk: k=%d out of range [1,%d]", k, MAX_K);
+    TopkArgs a;
+    for (int l = 0; l < lv->nlevels; ++l) {
+        AMP_REQUIRE(lv->pred[l] && lv->h[l] > 0 && lv->w[l] > 0, "amp_rpn_topk: missing level %d", l);
+        AMP_REQUIRE(lv->h[l] * lv->w[l] * lv->A <= max_n, "amp_rpn_topk: max_n=%d too small for level %d", max_n, l);
+        a.pred[l] = lv->pred[l];
+        a.hw[l] = lv->h[l] * lv->w[l];
+    }
+    a.nlevels = lv->nlevels; a.A = lv->A; a.ld = lv->ld; a.k = k;
+    a.keys_scratch = keys_scratch; a.max_n = max_n;
+    a.sel_idx = sel_idx; a.sel_logit = sel_logit; a.sel_count = sel_count;
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(B * lv->nlevels), dim3(TOPK_THREADS), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
+                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey) {
+    AMP_REQUIRE(ctx && lv && sel_idx && sel_logit && sel_count && boxes && sortkey, "amp_rpn_decode: null argument");
+    AMP_REQUIRE(lv->nlevels >= 1 && lv->nlevels <= MAX_LEVELS && lv->A == 3, "amp_rpn_decode: need 1..5 levels, A == 3");
+    AMP_REQUIRE(cap >= lv->nlevels * k, "amp_rpn_decode: cap=%d < nlevels*k", cap);
+    DecodeArgs a;
+    for (int l = 0; l < lv->nlevels; ++l) {
+        a.pred[l] = lv->pred[l];
+        a.hw[l] = lv->h[l] * lv->w[l];
+        a.fw[l] = lv->w[l];
+        a.stride[l] = lv->stride[l];
+        for (int r = 0; r < 3; ++r) {
+            // detectron2 generate_cell_anchors: python-float math, stored fp32
+            const double ratio = (r == 0) ? 0.5 : (r == 1 ? 1.0 : 2.0);
+            const double area = (double)lv->anchor_size[l] * (double)lv->anchor_size[l];
+            const double w = sqrt(area / ratio), h = ratio * w;
+            a.cell[l][r][0] = (float)(-w / 2.0); a.cell[l][r][1] = (float)(-h / 2.0);
+            a.cell[l][r][2] = (float)(w / 2.0);  a.cell[l][r][3] = (float)(h / 2.0);
+        }
+    }
+    a.nlevels = lv->nlevels; a.A = lv->A; a.ld = lv->ld; a.k = k;
+    a.sel_idx = sel_idx; a.sel_logit = sel_logit; a.sel_count = sel_count;
+    a.img_h = (float)img_h; a.img_w = (float)img_w;
+    a.scale_clamp = (float)log(1000.0 / 16.0);
+    a.cap = cap; a.boxes = boxes; a.sortkey = sortkey;
+    const int total = B * cap;
+    hipLaunchKernelGGL(rpn_decode_kernel, dim3(amp::cdiv(total, 256)), dim3(256), 0, ctx->stream, a, B);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
+                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out) {
+    AMP_REQUIRE(ctx && sortkey && boxes_in && boxes_out && score_out && cat_out && count_out, "amp_sort_gather: null argument");
+    AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 8192, "amp_sort_gather: cap=%d out of range [1,8192]", cap);
+    int N = 64;
+    while (N < cap) N <<= 1;
+    const size_t smem = (size_t)N * 8 + 16;
+    AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_gather_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(sort_gather_kernel, dim3(B), dim3(SORT_THREADS), smem, ctx->stream, sortkey, boxes_in, cap, box_stride, N,
+                       boxes_out, score_out, cat_out, count_out, pos_out);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+}  // extern "C"

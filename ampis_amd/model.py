@@ -1,0 +1,132 @@
+"""Python handle on amp_model (the C-ABI Mask R-CNN R50-FPN inference engine of libampis_hip.so).
+
+Mirrors what `DefaultPredictor(cfg)` builds for AMPIS (notebook cell 24): a model with loaded weights that maps
+BGR uint8 images to boxes / scores / classes / RLE masks.  No torch needed; numpy only marshals host buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Dets, ModelCfg, check, lib
+from . import rle as _rle
+
+_TAP_DTYPES = {0: np.float32, 1: np.int32, 2: np.uint64}
+
+
+class MaskRCNN:
+    def __init__(self, ctx, num_classes, max_batch=1, max_h=1344, max_w=1344, max_out_hw=4096,
+                 detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
+                 score_thresh=0.05, nms_thresh=0.5, mask_threshold=0.5, pixel_mean=(103.530, 116.280, 123.675),
+                 pixel_std=(1.0, 1.0, 1.0), rle_pool_counts=0):
+        self.ctx = ctx
+        cfg = ModelCfg()
+        check(lib().amp_model_cfg_default(C.byref(cfg)), "amp_model_cfg_default")
+        cfg.num_classes = int(num_classes)
+        for i in range(3):
+            cfg.pixel_mean[i] = float(pixel_mean[i])
+            cfg.pixel_std[i] = float(pixel_std[i])
+        cfg.pre_nms_topk, cfg.post_nms_topk = int(pre_nms_topk), int(post_nms_topk)
+        cfg.rpn_nms_thresh, cfg.score_thresh, cfg.nms_thresh = float(rpn_nms_thresh), float(score_thresh), float(nms_thresh)
+        cfg.detections_per_image = int(detections_per_image)
+        cfg.mask_threshold = float(mask_threshold)
+        pad = lambda v: (int(v) + 31) // 32 * 32
+        cfg.max_batch, cfg.max_h, cfg.max_w, cfg.max_out_hw = int(max_batch), pad(max_h), pad(max_w), int(max_out_hw)
+        cfg.rle_pool_counts = int(rle_pool_counts)
+        self.cfg = cfg
+        self.num_classes = int(num_classes)
+        self._h = C.c_void_p()
+        check(lib().amp_model_create(ctx.handle, C.byref(cfg), C.byref(self._h)), "amp_model_create")
+        self._finalized = False
+
+    # ---- parameters ----
+    def tensor_names(self):
+        n = lib().amp_model_num_tensors(self._h)
+        return [lib().amp_model_tensor_name(self._h, i).decode() for i in range(n)]
+
+    def load_params(self, params):
+        """params: mapping detectron2 state_dict name -> array-like (torch layout). Unknown keys are rejected."""
+        for name in self.tensor_names():
+            if name not in params:
+                raise _lib.AmpError(f"missing parameter tensor {name!r}")
+            a = np.ascontiguousarray(np.asarray(params[name]), dtype=np.float32)
+            shape = (C.c_longlong * a.ndim)(*a.shape)
+            check(lib().amp_model_load_tensor(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim),
+                  f"amp_model_load_tensor({name})")
+        check(lib().amp_model_finalize(self._h), "amp_model_finalize")
+        self._finalized = True
+
+    @property
+    def workspace_bytes(self):
+        return lib().amp_model_workspace_bytes(self._h)
+
+    # ---- inference ----
+    def infer_raw(self, images, out_sizes=None, device_ptr=None, shape=None):
+        """Run the hot path. `images`: uint8 ndarray [B,H,W,3] (host) or None with device_ptr + shape=(B,H,W).
+        Returns the ctypes Dets view (valid until the next call)."""
+        if device_ptr is not None:
+            B, H, W = shape
+            p, on_host = C.c_void_p(int(device_ptr)), 0
+        else:
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+            assert images.ndim == 4 and images.shape[3] == 3, "images must be [B,H,W,3] uint8 BGR"
+            B, H, W, _ = images.shape
+            p, on_host = images.ctypes.data_as(C.c_void_p), 1
+        oh = ow = None
+        if out_sizes is not None:
+            oh = (C.c_int * B)(*[int(s[0]) for s in out_sizes])
+            ow = (C.c_int * B)(*[int(s[1]) for s in out_sizes])
+        d = Dets()
+        check(lib().amp_model_infer(self._h, p, on_host, B, H, W, oh, ow, C.byref(d)), "amp_model_infer")
+        return d
+
+    def infer(self, images=None, out_sizes=None, device_ptr=None, shape=None, rle="bytes"):
+        """Returns a list (one per image) of dict(boxes f32[N,4], scores f32[N], classes i64[N],
+        masks = list of COCO RLE dicts {'size':[h,w], 'counts': bytes}) -- the content compress_pred produces
+        (ampis/data_utils.py:275-278). rle='counts' keeps the uncompressed uint32 run lengths instead."""
+        d = self.infer_raw(images, out_sizes, device_ptr, shape)
+        B, D = d.B, d.D
+        n = np.ctypeslib.as_array(d.n, (B,)).copy()
+        boxes = np.ctypeslib.as_array(d.boxes, (B, D, 4))
+        scores = np.ctypeslib.as_array(d.scores, (B, D))
+        classes = np.ctypeslib.as_array(d.classes, (B, D))
+        off = np.ctypeslib.as_array(d.rle_off, (B, D))
+        ln = np.ctypeslib.as_array(d.rle_len, (B, D))
+        total = int((off[ln > 0] + ln[ln > 0]).max()) if (ln > 0).any() else 0
+        pool = np.ctypeslib.as_array(d.rle_counts, (max(total, 1),))
+        out = []
+        for b in range(B):
+            k = int(n[b])
+            h, w = int(d.out_h[b]), int(d.out_w[b])
+            masks = []
+            for i in range(k):
+                cnts = pool[int(off[b, i]): int(off[b, i]) + int(ln[b, i])]
+                if rle == "counts":
+                    masks.append({"size": [h, w], "counts": cnts.copy()})
+                else:
+                    masks.append({"size": [h, w], "counts": _rle.counts_to_string(cnts)})
+            out.append(dict(boxes=boxes[b, :k].copy(), scores=scores[b, :k].copy(),
+                            classes=classes[b, :k].astype(np.int64), masks=masks, image_size=(h, w)))
+        return out
+
+    def tap(self, name):
+        """Copy an intermediate device buffer of the last infer call to the host (parity tests)."""
+        ptr, dt, nd = C.c_void_p(), C.c_int(), C.c_int()
+        shape = (C.c_longlong * 5)()
+        check(lib().amp_model_get_tap(self._h, name.encode(), C.byref(ptr), C.byref(dt), C.byref(nd), shape), "amp_model_get_tap")
+        shp = tuple(int(shape[i]) for i in range(nd.value))
+        a = np.empty(shp, dtype=_TAP_DTYPES[dt.value])
+        if a.size:
+            check(lib().amp_memcpy_d2h(self.ctx.handle, a.ctypes.data_as(C.c_void_p), ptr, a.nbytes), "amp_memcpy_d2h")
+        return a
+
+    def close(self):
+        if self._h:
+            lib().amp_model_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

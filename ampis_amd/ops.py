@@ -16,7 +16,7 @@ def torch_context(device=0):
     if not torch.cuda.is_available():
         raise _lib.AmpError("no HIP device visible: the ampis_amd hot path has no CPU fallback")
     with torch.cuda.device(device):
-        return _lib.Context(device, torch.cuda.current_stream().cuda_stream)
+        return _lib.Context(device, borrow_stream=torch.cuda.current_stream().cuda_stream)
 
 
 def _f32c(t):

@@ -1,0 +1,96 @@
+"""COCO RLE codec on the C ABI (amp_rle_* of libampis_hip.so, host C++): the drop-in for the pycocotools.mask
+calls AMPIS makes around the hot path (ampis/data_utils.py:275; ampis/analyze.py:108,158,315-321;
+ampis/structures.py:465-468,568,752).  RLE dicts are pycocotools' compressed form {'size':[h,w], 'counts': bytes}."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def counts_to_string(cnts):
+    cnts = np.ascontiguousarray(cnts, dtype=np.uint32)
+    cap = 7 * len(cnts) + 8
+    buf = C.create_string_buffer(cap)
+    n = C.c_size_t()
+    check(lib().amp_rle_to_string(cnts.ctypes.data_as(C.c_void_p), len(cnts), buf, cap, C.byref(n)), "amp_rle_to_string")
+    return buf.raw[: n.value]
+
+
+def string_to_counts(s):
+    if isinstance(s, str):
+        s = s.encode("ascii")
+    out = np.empty(len(s) + 1, dtype=np.uint32)
+    m = C.c_int()
+    check(lib().amp_rle_from_string(C.c_char_p(s), len(s), out.ctypes.data_as(C.c_void_p), len(out), C.byref(m)),
+          "amp_rle_from_string")
+    return out[: m.value].copy()
+
+
+def _counts(r):
+    c = r["counts"]
+    return string_to_counts(c) if isinstance(c, (bytes, str)) else np.ascontiguousarray(c, dtype=np.uint32)
+
+
+def encode(mask):
+    """mask: [H,W] (or [H,W,N]) bool/uint8 -> RLE dict (or list), like pycocotools.mask.encode."""
+    mask = np.asarray(mask)
+    if mask.ndim == 3:
+        return [encode(mask[:, :, i]) for i in range(mask.shape[2])]
+    h, w = mask.shape
+    f = np.asfortranarray(mask.astype(np.uint8))
+    cap = h * w + 2
+    out = np.empty(cap, dtype=np.uint32)
+    m = C.c_int()
+    check(lib().amp_rle_encode(f.ctypes.data_as(C.c_void_p), h, w, out.ctypes.data_as(C.c_void_p), cap, C.byref(m)),
+          "amp_rle_encode")
+    return {"size": [h, w], "counts": counts_to_string(out[: m.value])}
+
+
+def decode(r):
+    if isinstance(r, (list, tuple)):
+        return np.stack([decode(x) for x in r], axis=2)
+    h, w = r["size"]
+    c = _counts(r)
+    out = np.empty((h, w), dtype=np.uint8, order="F")
+    check(lib().amp_rle_decode(c.ctypes.data_as(C.c_void_p), len(c), h, w, out.ctypes.data_as(C.c_void_p)), "amp_rle_decode")
+    return out
+
+
+def area(r):
+    if isinstance(r, (list, tuple)):
+        return np.array([area(x) for x in r], dtype=np.uint32)
+    c = _counts(r)
+    a = C.c_ulonglong()
+    check(lib().amp_rle_area(c.ctypes.data_as(C.c_void_p), len(c), C.byref(a)), "amp_rle_area")
+    return int(a.value)
+
+
+def iou(dt, gt, iscrowd):
+    """len(dt) x len(gt) float64 matrix, like pycocotools.mask.iou on RLE lists."""
+    out = np.zeros((len(dt), len(gt)), dtype=np.float64)
+    dc = [_counts(x) for x in dt]
+    gc = [_counts(x) for x in gt]
+    v = C.c_double()
+    for j, g in enumerate(gc):
+        crowd = int(bool(iscrowd[j])) if len(iscrowd) else 0
+        for i, d in enumerate(dc):
+            check(lib().amp_rle_iou(d.ctypes.data_as(C.c_void_p), len(d), g.ctypes.data_as(C.c_void_p), len(g), crowd,
+                                    C.byref(v)), "amp_rle_iou")
+            out[i, j] = v.value
+    return out
+
+
+def merge(rles, intersect=False):
+    assert len(rles) >= 1
+    h, w = rles[0]["size"]
+    cur = _counts(rles[0])
+    for r in rles[1:]:
+        b = _counts(r)
+        cap = len(cur) + len(b) + 2
+        out = np.empty(cap, dtype=np.uint32)
+        m = C.c_int()
+        check(lib().amp_rle_merge2(cur.ctypes.data_as(C.c_void_p), len(cur), b.ctypes.data_as(C.c_void_p), len(b),
+                                   int(bool(intersect)), out.ctypes.data_as(C.c_void_p), cap, C.byref(m)), "amp_rle_merge2")
+        cur = out[: m.value].copy()
+    return {"size": [h, w], "counts": counts_to_string(cur)}

@@ -42,11 +42,17 @@ typedef struct amp_ctx amp_ctx;
 /* Library / context -------------------------------------------------------------------------- */
 const char* amp_last_error(void);
 int  amp_version(void);
-/* stream may be NULL: the context then creates (and owns) a non-blocking HIP stream. */
-int  amp_init(int device, void* hip_stream, amp_ctx** out);
+/* flags & AMP_STREAM_BORROW: launch on `hip_stream` (a hipStream_t; NULL = the legacy default stream) and never
+ * destroy it; otherwise hip_stream is ignored and the context creates (and owns) a non-blocking HIP stream. */
+#define AMP_STREAM_BORROW 1
+int  amp_init(int device, void* hip_stream, int flags, amp_ctx** out);
 void amp_destroy(amp_ctx* ctx);
 int  amp_sync(amp_ctx* ctx);
 void* amp_stream(amp_ctx* ctx);
+/* HIP-event stopwatch on the context's stream: start records an event, stop records a second one, waits for it
+ * and returns the elapsed milliseconds between the two (bench.py times kernels with this, not with torch events). */
+int  amp_timer_start(amp_ctx* ctx);
+int  amp_timer_stop(amp_ctx* ctx, float* ms_h);
 
 /* Device memory helpers (so that hosts without torch can drive the library) ----------------- */
 int amp_malloc(amp_ctx* ctx, size_t bytes, void** out);
@@ -67,6 +73,114 @@ typedef struct amp_conv_desc {
 /* y = act( conv(x, w) * scale[c] + shift[c] (+ res) ); scale may be NULL (= 1), shift may be NULL (= 0). */
 int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                     const float* scale, const float* shift, const float* res, float* y);
+
+
+/* Stage a8 / a9 / a10: memory-bound NHWC helpers --------------------------------------------- */
+/* uint8 BGR [B,H,W,3] -> fp32 [B,Hp,Wp,4] = (x - mean) / std, zero padded (4th channel 0). */
+int amp_preprocess(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3],
+                   const float std[3], float* out);
+int amp_maxpool3x3s2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y);   /* k3 s2 p1 */
+int amp_subsample2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y);     /* x[:, ::2, ::2] */
+
+/* Stage a12: RPN candidate selection ----------------------------------------------------------- */
+typedef struct amp_rpn_levels {
+    int nlevels;               /* <= 5 */
+    int A;                     /* anchors per location (3) */
+    int ld;                    /* row length of pred: A logits then A*4 deltas (15) */
+    const float* pred[5];      /* per level [B, h*w, ld] */
+    int h[5], w[5], stride[5], anchor_size[5];
+} amp_rpn_levels;
+/* per (image, level) top-k by logit, descending, ties by ascending anchor index. keys_scratch: [B*nlevels*max_n] u32. */
+int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t* keys_scratch, int max_n, int* sel_idx,
+                 float* sel_logit, int* sel_count);
+/* decode + clip the selected anchors; sortkey = 0 for non-finite / empty boxes. boxes [B,cap,4], sortkey [B,cap]. */
+int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
+                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey);
+/* per image: order `cap` (<= 8192) 64-bit sort words descending; gather boxes_in[b][pos] (box_stride entries per image);
+ * outputs sorted boxes/scores/categories [B,cap], the number of valid entries [B], optionally the source positions. */
+int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
+                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out);
+
+/* Stages a12 / a15: batched greedy NMS on score-sorted boxes (cap <= 8192 per image) ---------- */
+/* mask_scratch: [B*cap*ceil(cap/64)] u64. keep_idx [B,max_keep] (positions, ascending), keep_count [B]. */
+int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const int* cats, const int* counts, float thresh,
+            int max_keep, unsigned long long* mask_scratch, int* keep_idx, int* keep_count);
+
+/* Stages a13 / a16: RoIAlign (aligned, sampling_ratio 0) with FPN level assignment ------------- */
+typedef struct amp_fpn_feats {
+    const float* feat[4];      /* p2..p5, NHWC [B,h,w,C] */
+    int h[4], w[4], stride[4];
+    int C;
+} amp_fpn_feats;
+/* rois [R,4] (x1,y1,x2,y2 in image coordinates), batch_idx [R] or NULL, roi_count device int or NULL -> out [R,P,P,C]. */
+int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count,
+                  int R, int P, float* out, int* level_out);
+
+/* Stage a15: box-head inference ------------------------------------------------------------------ */
+int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
+                       int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,
+                       float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
+int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
+                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes);
+
+/* Stages a16 / a17 / a3: mask probability, paste + threshold + RLE counts ----------------------- */
+int amp_mask_prob(amp_ctx* ctx, const float* logits, const int* classes, int N, int K, float* prob);
+int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
+                  const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
+                  unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
+                  int* rle_len, int* overflow);
+
+/* Host-side COCO RLE codec (all pointers HOST) --------------------------------------------------- */
+int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t* len);
+int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int* m_out);
+int amp_rle_encode(const uint8_t* mask_colmajor, int h, int w, uint32_t* cnts, int cap, int* m_out);
+int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colmajor);
+int amp_rle_area(const uint32_t* cnts, int m, unsigned long long* area);
+int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscrowd, double* iou);
+int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out);
+
+/* The model: DefaultPredictor(cfg) / predictor(img) ---------------------------------------------- */
+typedef struct amp_model amp_model;
+typedef struct amp_model_cfg {
+    int num_classes;                 /* MODEL.ROI_HEADS.NUM_CLASSES */
+    float pixel_mean[3], pixel_std[3];
+    int pre_nms_topk, post_nms_topk; /* MODEL.RPN.{PRE,POST}_NMS_TOPK_TEST */
+    float rpn_nms_thresh;            /* MODEL.RPN.NMS_THRESH */
+    float score_thresh, nms_thresh;  /* MODEL.ROI_HEADS.{SCORE,NMS}_THRESH_TEST */
+    int detections_per_image;        /* TEST.DETECTIONS_PER_IMAGE */
+    float bbox_reg_weights[4];
+    float mask_threshold;
+    int max_batch, max_h, max_w;     /* capacity: largest (padded) network input */
+    int max_out_hw;                  /* capacity: largest side of an output (original) image */
+    size_t rle_pool_counts;          /* capacity of the RLE run pool in uint32 (0 = default) */
+} amp_model_cfg;
+/* Host view of the detections of the last amp_model_infer call; pointers stay valid until the next call. */
+typedef struct amp_dets {
+    int B, D;                        /* images, capacity per image (detections_per_image) */
+    const int* n;                    /* [B] detections per image, sorted by descending score */
+    const float* boxes;              /* [B,D,4] XYXY in output-image pixels */
+    const float* scores;             /* [B,D] */
+    const int* classes;              /* [B,D] */
+    const unsigned long long* rle_off; /* [B,D] offset of the mask's run lengths in rle_counts */
+    const int* rle_len;              /* [B,D] number of runs (column-major, first run counts zeros) */
+    const uint32_t* rle_counts;
+    const int* out_h; const int* out_w; /* [B] mask size */
+} amp_dets;
+int  amp_model_cfg_default(amp_model_cfg* cfg);
+int  amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out);
+void amp_model_destroy(amp_model* m);
+size_t amp_model_workspace_bytes(amp_model* m);
+int  amp_model_num_tensors(amp_model* m);
+const char* amp_model_tensor_name(amp_model* m, int i);
+/* data_h: host fp32 in the torch layout of detectron2's state_dict entry `name` (conv OIHW, linear [out,in]). */
+int  amp_model_load_tensor(amp_model* m, const char* name, const float* data_h, const long long* shape, int ndim);
+int  amp_model_finalize(amp_model* m);
+/* imgs_bgr: uint8 [B,H,W,3], device pointer (imgs_on_host = 0) or host pointer (1). out_h_h/out_w_h: host [B] original
+ * image sizes the boxes/masks are rescaled to (NULL = network input size). */
+int  amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const int* out_h_h,
+                     const int* out_w_h, amp_dets* out);
+/* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
+int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
 
 #ifdef __cplusplus
 }

@@ -38,13 +38,11 @@ def main():
         for _ in range(2):
             ops.conv2d_nhwc(ctx, x, w, sc, sh, stride=s, pad=p, relu=True)
         torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         n = 5
-        e0.record()
+        ctx.timer_start()
         for _ in range(n):
             ops.conv2d_nhwc(ctx, x, w, sc, sh, stride=s, pad=p, relu=True)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
+        ms = ctx.timer_stop() / n
         tf = flops / ms / 1e9
         out.append((name, ms, tf))
         print(f"{name:18s} {ms:8.3f} ms  {tf:7.1f} TFLOP/s  (M={B*Ho*Wo}, N={Cout}, K={kh*kw*Cin})", flush=True)
