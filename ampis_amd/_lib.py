@@ -37,6 +37,10 @@ class ModelCfg(C.Structure):
                 ("rle_pool_counts", C.c_size_t)]
 
 
+class ProfSummary(C.Structure):
+    _fields_ = [("launches", C.c_longlong * 2), ("ms", C.c_double * 2), ("flops", C.c_double * 2), ("truncated", C.c_int)]
+
+
 class Dets(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("n", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
                 ("scores", C.POINTER(C.c_float)), ("classes", C.POINTER(C.c_int)),
@@ -70,6 +74,8 @@ def _declare(L):
         "amp_version": ([], i),
         "amp_init": ([i, vp, i, C.POINTER(vp)], i),
         "amp_timer_start": ([vp], i),
+        "amp_prof_begin": ([vp, i], i),
+        "amp_prof_end": ([vp, C.POINTER(ProfSummary)], i),
         "amp_timer_stop": ([vp, C.POINTER(f)], i),
         "amp_destroy": ([vp], None),
         "amp_sync": ([vp], i),
@@ -142,6 +148,25 @@ class Context:
         ms = C.c_float()
         check(lib().amp_timer_stop(self._h, C.byref(ms)), "amp_timer_stop")
         return ms.value
+
+    def prof_begin(self, max_launches=8192):
+        check(lib().amp_prof_begin(self._h, int(max_launches)), "amp_prof_begin")
+
+    def prof_end(self):
+        s = ProfSummary()
+        check(lib().amp_prof_end(self._h, C.byref(s)), "amp_prof_end")
+        return {"launches": list(s.launches), "ms": list(s.ms), "flops": list(s.flops), "truncated": bool(s.truncated)}
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().amp_malloc(self._h, int(nbytes), C.byref(p)), "amp_malloc")
+        return p.value
+
+    def free(self, p):
+        check(lib().amp_free(self._h, C.c_void_p(p)), "amp_free")
+
+    def h2d(self, dst, arr):
+        check(lib().amp_memcpy_h2d(self._h, C.c_void_p(dst), arr.ctypes.data_as(C.c_void_p), arr.nbytes), "amp_memcpy_h2d")
 
     @property
     def handle(self):

@@ -63,9 +63,16 @@ __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(
 
 }  // namespace amp
 
+#include <vector>
+struct amp_prof_rec { hipEvent_t e0, e1; double flops; int variant; };
 struct amp_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
+    // live kernel profile (amp_prof_begin/end): HIP-event pairs around every conv launch on this stream
+    bool prof_on = false;
+    std::vector<amp_prof_rec> prof_pool;   // pre-created events
+    size_t prof_used = 0;
+    bool prof_truncated = false;
 };

@@ -1,5 +1,6 @@
 // Context, error reporting and raw device-memory helpers of the C ABI.
 #include <stdarg.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -62,8 +63,42 @@ int amp_timer_stop(amp_ctx* ctx, float* ms_h) {
     return AMP_OK;
 }
 
+int amp_prof_begin(amp_ctx* ctx, int max_launches) {
+    AMP_REQUIRE(ctx && max_launches > 0, "amp_prof_begin: bad argument");
+    while ((int)ctx->prof_pool.size() < max_launches) {
+        amp_prof_rec r;
+        AMP_HIP_CHECK(hipEventCreate(&r.e0));
+        AMP_HIP_CHECK(hipEventCreate(&r.e1));
+        r.flops = 0; r.variant = 0;
+        ctx->prof_pool.push_back(r);
+    }
+    ctx->prof_used = 0;
+    ctx->prof_truncated = false;
+    ctx->prof_on = true;
+    return AMP_OK;
+}
+
+int amp_prof_end(amp_ctx* ctx, amp_prof_summary* out) {
+    AMP_REQUIRE(ctx && out, "amp_prof_end: null argument");
+    ctx->prof_on = false;
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof(*out));
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        const amp_prof_rec& r = ctx->prof_pool[i];
+        float ms = 0.f;
+        AMP_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        const int v = r.variant ? 1 : 0;
+        out->launches[v] += 1;
+        out->ms[v] += ms;
+        out->flops[v] += r.flops;
+    }
+    out->truncated = ctx->prof_truncated ? 1 : 0;
+    return AMP_OK;
+}
+
 void amp_destroy(amp_ctx* ctx) {
     if (!ctx) return;
+    for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -246,6 +246,17 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
 
     constexpr int BM = 128;
     const int ntm = amp::cdiv(a.M, BM);
+    amp_prof_rec* rec = nullptr;
+    if (ctx->prof_on) {
+        if (ctx->prof_used < ctx->prof_pool.size()) {
+            rec = &ctx->prof_pool[ctx->prof_used++];
+            rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)d->Cin;
+            rec->variant = a.Cout > 64 ? 0 : 1;
+            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
+        } else {
+            ctx->prof_truncated = true;
+        }
+    }
     if (a.Cout > 64) {
         a.ntn = amp::cdiv(a.Cout, 128);
         a.nblk = ntm * a.ntn;
@@ -256,5 +267,6 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
         hipLaunchKernelGGL((conv_mfma_kernel<BM, 64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
     }
     AMP_HIP_CHECK(hipGetLastError());
+    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     return AMP_OK;
 }

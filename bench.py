@@ -1,0 +1,132 @@
+"""bench.py — images/s of Mask R-CNN R50-FPN inference on synthetic 1024x1024 micrographs (BASELINE.json configs[1]).
+
+python bench.py --gpus N --steps K --warmup W       (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path (amp_model_infer: preprocess -> backbone -> FPN -> RPN -> proposals -> box head ->
+detections -> mask head -> paste -> RLE counts on the host) over one batch of 8 images that is already resident in HBM.
+Image-parallel replicas: every rank runs the same per-GPU batch, no data-path collective ("weak" scaling); RCCL is only
+used for the barrier and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from ampis_amd import _lib, params as P, synth
+from ampis_amd.model import MaskRCNN
+
+BATCH, SIZE, K, DETS = 8, 1024, 2, 200
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+
+
+def cpu_baseline(n_images):
+    """The torch-CPU oracle ("port": the reference's detectron2 path cannot run here) on a bounded sample of
+    the same workload: n_images single 1024x1024 micrographs, same weights and cfg."""
+    from oracle import maskrcnn as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs, _ = synth.batch(n_images, SIZE, SIZE)
+    p = O.to_torch_params(P.init_params(K, seed=0, style="spread"))
+    cfg = O.Cfg(num_classes=K, detections_per_image=DETS)
+    O.infer(imgs[:1, :256, :256], p, cfg)   # warm the thread pool
+    t = time.perf_counter()
+    for i in range(n_images):
+        O.infer(imgs[i:i + 1], p, cfg)
+    dt = time.perf_counter() - t
+    return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n_images} x 1024x1024 synthetic micrographs, batch 1, torch-CPU oracle (oracle/maskrcnn.py), "
+                      f"{DETS} detections/image, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU fallback for the hot path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    ctx = _lib.Context(local_rank)
+    model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
+    model.load_params(P.init_params(K, seed=0, style="spread"))
+    imgs, _ = synth.batch(BATCH, SIZE, SIZE, first_index=rank * BATCH)
+    d_imgs = ctx.malloc(imgs.nbytes)
+    ctx.h2d(d_imgs, imgs)
+
+    def step():
+        return model.infer_raw(None, device_ptr=d_imgs, shape=(BATCH, SIZE, SIZE))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.prof_begin(max_launches=args.steps * 96)
+    t0 = time.perf_counter()
+    ndet = 0
+    for _ in range(args.steps):
+        d = step()
+        ndet += sum(d.n[b] for b in range(BATCH))
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_end()
+    barrier()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * BATCH * args.steps / elapsed
+        ach = prof["flops"][0] / (prof["ms"][0] * 1e-3) / 1e12 if prof["ms"][0] > 0 else 0.0
+        conv_all = (prof["flops"][0] + prof["flops"][1]) / ((prof["ms"][0] + prof["ms"][1]) * 1e-3) / 1e12
+        out = {
+            "metric": "images/sec Mask R-CNN R50-FPN @1024x1024 inference", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: R50-FPN inference, batch=8 synthetic 1024x1024 micrographs per GPU, "
+                                   "K=2, 1000 proposals/img, TEST.DETECTIONS_PER_IMAGE=200, seeded random-init weights, "
+                                   "outputs boxes+scores+classes+COCO-RLE counts on host",
+                       "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
+                       "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
+                       "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<128,128> (fp32 MFMA implicit-GEMM conv)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": prof["launches"][0] / args.steps,
+                         "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
+                         "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
+                         "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_images)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

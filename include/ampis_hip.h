@@ -54,6 +54,18 @@ void* amp_stream(amp_ctx* ctx);
 int  amp_timer_start(amp_ctx* ctx);
 int  amp_timer_stop(amp_ctx* ctx, float* ms_h);
 
+/* Live profile of the dominant kernel: between begin and end every amp_conv2d_nhwc launch on this context is bracketed
+ * by a HIP-event pair on the context's stream; end waits for the stream and sums duration and algorithmic FLOPs
+ * (2*M*Cout*KH*KW*Cin) per kernel variant: [0] = conv_mfma_kernel<128,128>, [1] = conv_mfma_kernel<128,64>. */
+typedef struct amp_prof_summary {
+    long long launches[2];
+    double ms[2];
+    double flops[2];
+    int truncated;            /* 1 when more launches happened than max_launches */
+} amp_prof_summary;
+int  amp_prof_begin(amp_ctx* ctx, int max_launches);
+int  amp_prof_end(amp_ctx* ctx, amp_prof_summary* out);
+
 /* Device memory helpers (so that hosts without torch can drive the library) ----------------- */
 int amp_malloc(amp_ctx* ctx, size_t bytes, void** out);
 int amp_free(amp_ctx* ctx, void* p);
