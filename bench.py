@@ -26,12 +26,33 @@ BATCH, SIZE, K, DETS = 8, 1024, 2, 200
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU box's 16-per-GPU share."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(n_images):
     """The torch-CPU oracle ("port": the reference's detectron2 path cannot run here) on a bounded sample of
     the same workload: n_images single 1024x1024 micrographs, same weights and cfg."""
     from oracle import maskrcnn as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {n_images} image(s) with {cores} threads")
     imgs, _ = synth.batch(n_images, SIZE, SIZE)
     p = O.to_torch_params(P.init_params(K, seed=0, style="spread"))
     cfg = O.Cfg(num_classes=K, detections_per_image=DETS)
@@ -39,6 +60,7 @@ def cpu_baseline(n_images):
     t = time.perf_counter()
     for i in range(n_images):
         O.infer(imgs[i:i + 1], p, cfg)
+        log(f"cpu_baseline: image {i + 1}/{n_images} done at {time.perf_counter() - t:.1f} s")
     dt = time.perf_counter() - t
     return {"value": n_images / dt, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n_images} x 1024x1024 synthetic micrographs, batch 1, torch-CPU oracle (oracle/maskrcnn.py), "
@@ -51,7 +73,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=3)
+    ap.add_argument("--cpu-images", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,9 +87,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
+    log(f"rank {rank}/{world}: creating model")
     ctx = _lib.Context(local_rank)
     model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     model.load_params(P.init_params(K, seed=0, style="spread"))
+    log(f"workspace {model.workspace_bytes / 2**30:.2f} GiB; weights loaded; generating {BATCH} micrographs")
     imgs, _ = synth.batch(BATCH, SIZE, SIZE, first_index=rank * BATCH)
     d_imgs = ctx.malloc(imgs.nbytes)
     ctx.h2d(d_imgs, imgs)
@@ -80,8 +104,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t = time.perf_counter()
         step()
+        log(f"warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
     barrier()
     ctx.prof_begin(max_launches=args.steps * 96)
     t0 = time.perf_counter()
@@ -92,6 +118,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_end()
+    log(f"timed {args.steps} steps in {elapsed:.3f} s")
     barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
