@@ -43,7 +43,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Order-preserving float <-> uint32 (ascending float order == ascending unsigned order).
 __device__ __forceinline__ uint32_t f2ord(float f) {
-    const uint32_t u = __float_as_uint(f);
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;   // -0.0 ties with +0.0 (as in torch / numpy comparisons)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float ord2f(uint32_t o) {

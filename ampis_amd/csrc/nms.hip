@@ -79,8 +79,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
     int* out = keep_idx + (size_t)b * max_keep;
     for (int c = 0; c < Wn && nkept < max_keep; ++c) {
         const unsigned long long rsel = (c < 64) ? rem0 : rem1;
-        const unsigned int rlo = __builtin_amdgcn_readlane((unsigned int)(rsel & 0xffffffffu), c & 63);
-        const unsigned int rhi = __builtin_amdgcn_readlane((unsigned int)(rsel >> 32), c & 63);
+        const unsigned int rlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel & 0xffffffffu), c & 63);
+        const unsigned int rhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel >> 32), c & 63);
         const unsigned long long removed = ((unsigned long long)rhi << 32) | rlo;
         const int row = c * 64 + lane;
         const unsigned long long diag = (row < n) ? M[(size_t)row * a.W + c] : 0ull;
@@ -92,8 +92,10 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         while (cur != 0ull) {   // wave-uniform scalar loop over alive boxes of this chunk, in score order
             const int bit = __builtin_ctzll(cur);
             keep |= (1ull << bit);
-            const unsigned long long dm = ((unsigned long long)__builtin_amdgcn_readlane(dhi, bit) << 32) |
-                                          __builtin_amdgcn_readlane(dlo, bit);
+            // readlane returns a signed int: cast both halves to unsigned before widening (no sign extension)
+            const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
+            const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
+            const unsigned long long dm = ((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo;
             cur &= ~dm;
             cur &= ~(1ull << bit);
         }

@@ -43,3 +43,123 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
     check(lib().amp_conv2d_nhwc(ctx.handle, C.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y)),
           "amp_conv2d_nhwc")
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Selection / pooling / mask stages (device tensors in, device tensors out). Integer tensors are int32.
+# ------------------------------------------------------------------------------------------------------------------
+def _i32(*shape, device="cuda:0"):
+    return torch.empty(shape, dtype=torch.int32, device=device)
+
+
+def _u64(*shape, device="cuda:0"):
+    return torch.empty(shape, dtype=torch.int64, device=device)   # same bits; viewed as u64 by the library
+
+
+def make_rpn_levels(preds, shapes, strides=(4, 8, 16, 32, 64), sizes=(32, 64, 128, 256, 512)):
+    lv = _lib.RpnLevels()
+    lv.nlevels, lv.A, lv.ld = len(preds), 3, 15
+    for i, (p, (h, w)) in enumerate(zip(preds, shapes)):
+        _f32c(p)
+        lv.pred[i] = p.data_ptr()
+        lv.h[i], lv.w[i], lv.stride[i], lv.anchor_size[i] = h, w, strides[i], sizes[i]
+    return lv
+
+
+def rpn_topk(ctx, preds, shapes, B, k):
+    """preds: per level [B, h*w, 15]. Returns sel_idx [B,L,k] i32, sel_logit [B,L,k] f32, sel_count [B,L] i32."""
+    lv = make_rpn_levels(preds, shapes)
+    L = len(preds)
+    dev = preds[0].device
+    max_n = max(h * w * 3 for h, w in shapes)
+    scratch = torch.empty((B * L * max_n,), dtype=torch.int32, device=dev)
+    sel_idx, sel_logit, sel_count = _i32(B, L, k, device=dev), torch.zeros((B, L, k), device=dev), _i32(B, L, device=dev)
+    check(lib().amp_rpn_topk(ctx.handle, C.byref(lv), B, k, ptr(scratch), max_n, ptr(sel_idx), ptr(sel_logit), ptr(sel_count)),
+          "amp_rpn_topk")
+    return sel_idx, sel_logit, sel_count
+
+
+def rpn_decode(ctx, preds, shapes, B, k, sel_idx, sel_logit, sel_count, img_h, img_w):
+    lv = make_rpn_levels(preds, shapes)
+    cap = len(preds) * k
+    dev = preds[0].device
+    boxes, keys = torch.empty((B, cap, 4), device=dev), _u64(B, cap, device=dev)
+    check(lib().amp_rpn_decode(ctx.handle, C.byref(lv), B, k, ptr(sel_idx), ptr(sel_logit), ptr(sel_count), img_h, img_w, cap,
+                               ptr(boxes), ptr(keys)), "amp_rpn_decode")
+    return boxes, keys
+
+
+def sort_gather(ctx, keys, boxes_in, box_stride=None):
+    B, cap = keys.shape
+    dev = keys.device
+    sb, ss, sc, cnt, pos = torch.empty((B, cap, 4), device=dev), torch.empty((B, cap), device=dev), _i32(B, cap, device=dev), \
+        _i32(B, device=dev), _i32(B, cap, device=dev)
+    check(lib().amp_sort_gather(ctx.handle, B, cap, box_stride or boxes_in.shape[1], ptr(keys), ptr(boxes_in), ptr(sb), ptr(ss),
+                                ptr(sc), ptr(cnt), ptr(pos)), "amp_sort_gather")
+    return sb, ss, sc, cnt, pos
+
+
+def nms(ctx, boxes, cats, counts, thresh, max_keep):
+    """boxes [B,cap,4] sorted by descending score, cats [B,cap] i32, counts [B] i32 -> keep_idx [B,max_keep], keep_count [B]."""
+    B, cap, _ = boxes.shape
+    dev = boxes.device
+    W = (cap + 63) // 64
+    mask = _u64(B * cap * W, device=dev)
+    keep, kc = _i32(B, max_keep, device=dev), _i32(B, device=dev)
+    check(lib().amp_nms(ctx.handle, B, cap, ptr(boxes), ptr(cats), ptr(counts), float(thresh), max_keep, ptr(mask), ptr(keep),
+                        ptr(kc)), "amp_nms")
+    return keep, kc
+
+
+def make_fpn_feats(feats, strides=(4, 8, 16, 32)):
+    f = _lib.FpnFeats()
+    for i, t in enumerate(feats):
+        _f32c(t)
+        f.feat[i] = t.data_ptr()
+        f.h[i], f.w[i], f.stride[i] = t.shape[1], t.shape[2], strides[i]
+    f.C = feats[0].shape[3]
+    return f
+
+
+def roi_align(ctx, feats, rois, batch_idx, P):
+    """feats: [p2..p5] NHWC; rois [R,4]; batch_idx [R] i32 -> ([R,P,P,C], level [R] i32)."""
+    f = make_fpn_feats(feats)
+    R = rois.shape[0]
+    out = torch.empty((R, P, P, f.C), device=rois.device)
+    lvl = _i32(R, device=rois.device)
+    check(lib().amp_roi_align(ctx.handle, C.byref(f), ptr(_f32c(rois)), ptr(batch_idx), None, R, P, ptr(out), ptr(lvl)),
+          "amp_roi_align")
+    return out, lvl
+
+
+def box_candidates(ctx, pred, proposals, prop_count, K, score_thresh, img_h, img_w, weights=(10., 10., 5., 5.), ccap=8192):
+    B, Rcap, _ = proposals.shape
+    dev = pred.device
+    dense = torch.empty((B, Rcap * K, 4), device=dev)
+    keys, cnt, ovf = _u64(B, ccap, device=dev), _i32(B, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    w = (C.c_float * 4)(*weights)
+    check(lib().amp_box_candidates(ctx.handle, ptr(_f32c(pred)), pred.shape[-1], ptr(_f32c(proposals)), ptr(prop_count), B, Rcap,
+                                   K, w, float(score_thresh), img_h, img_w, ptr(dense), ptr(keys), ccap, ptr(cnt), ptr(ovf)),
+          "amp_box_candidates")
+    return dense, keys, cnt, ovf
+
+
+def paste_rle(ctx, prob, det_boxes, det_batch, out_h, out_w, in_h, in_w, threshold=0.5, pool_counts=1 << 22):
+    """prob [N,28,28], det_boxes [N,4], det_batch [N] i32, out_h/out_w [B] i32 (device).
+    Returns (out_boxes [N,4], valid [N], list of uint32 run-length arrays)."""
+    N = prob.shape[0]
+    dev = prob.device
+    ob, valid = torch.empty((N, 4), device=dev), _i32(N, device=dev)
+    pool = torch.empty((pool_counts,), dtype=torch.int32, device=dev)
+    used, off, ln = torch.zeros(1, dtype=torch.int64, device=dev), _u64(N, device=dev), _i32(N, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    max_hw = int(max(out_h.max().item(), out_w.max().item()))
+    check(lib().amp_paste_rle(ctx.handle, ptr(_f32c(prob)), ptr(_f32c(det_boxes)), ptr(det_batch), N, ptr(out_h), ptr(out_w), max_hw,
+                              in_h, in_w, float(threshold), ptr(ob), ptr(valid), ptr(pool), pool_counts, ptr(used), ptr(off),
+                              ptr(ln), ptr(ovf)), "amp_paste_rle")
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 0, "RLE pool overflow"
+    pool_h = pool.cpu().numpy().view("uint32")
+    off_h, ln_h = off.cpu().numpy(), ln.cpu().numpy()
+    runs = [pool_h[int(o): int(o) + int(l)].copy() for o, l in zip(off_h, ln_h)]
+    return ob, valid, runs

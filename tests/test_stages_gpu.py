@@ -1,0 +1,199 @@
+"""Stage-level parity on IDENTICAL inputs (through the C ABI per-kernel entry points) against the oracle.
+
+Selection stages are integer / ordering work: bit-exact (same indices, same kept sets, same run lengths).  Stages with
+fp32 arithmetic that the oracle evaluates in the same op order (IoU, RoIAlign, paste) are compared exactly or to 1 ulp-level
+tolerances; stages that call expf (decode, softmax, sigmoid) to 1e-4 px / 1e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _levels(B, rng, shapes, ties=False):
+    preds = []
+    for (h, w) in shapes:
+        p = rng.normal(0, 2, (B, h * w, 15)).astype(np.float32)
+        if ties:   # heavy exact ties: quantise logits so the index tie-break is exercised everywhere
+            p[:, :, :3] = np.round(p[:, :, :3] * 2) / 2
+        p[:, :, 3:] *= 0.3
+        preds.append(torch.from_numpy(p))
+    return preds
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_rpn_topk_exact(gpu_ctx, ties):
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(1 + ties)
+    B, k = 2, 1000
+    shapes = [(64, 48), (32, 24), (16, 12), (8, 6), (4, 3)]
+    preds = _levels(B, rng, shapes, ties)
+    si, sl, sc = ops.rpn_topk(gpu_ctx, [p.to(DEV) for p in preds], shapes, B, k)
+    torch.cuda.synchronize()
+    si, sl, sc = si.cpu().numpy(), sl.cpu().numpy(), sc.cpu().numpy()
+    for b in range(B):
+        for l, p in enumerate(preds):
+            logits = p[b, :, :3].reshape(-1)
+            kk = min(k, logits.numel())
+            assert sc[b, l] == kk
+            order = O.sort_desc_stable(logits)[:kk].numpy()
+            assert np.array_equal(si[b, l, :kk], order)
+            assert np.array_equal(sl[b, l, :kk], logits.numpy()[order])
+
+
+def test_rpn_decode_and_sort(gpu_ctx):
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(3)
+    B, k, H, W = 2, 300, 200, 176
+    shapes = [(50, 44), (25, 22), (13, 11), (7, 6), (4, 3)]
+    preds = _levels(B, rng, shapes)
+    dp = [p.to(DEV) for p in preds]
+    si, sl, sc = ops.rpn_topk(gpu_ctx, dp, shapes, B, k)
+    boxes, keys = ops.rpn_decode(gpu_ctx, dp, shapes, B, k, si, sl, sc, H, W)
+    sb, ss, scat, cnt, pos = ops.sort_gather(gpu_ctx, keys, boxes)
+    torch.cuda.synchronize()
+    cfg = O.Cfg(num_classes=2, pre_nms_topk=k)
+    outs = [(p[:, :, :3].reshape(B, -1), p[:, :, 3:].reshape(B, -1, 4)) for p in preds]
+    cands = O.rpn_select_candidates(outs, shapes, cfg)
+    for b in range(B):
+        cb, cl, clv = cands[b][0], cands[b][1], cands[b][2]
+        cb = O.clip_boxes(cb, H, W)
+        keep = ((cb[:, 2] - cb[:, 0]) > 0) & ((cb[:, 3] - cb[:, 1]) > 0) & torch.isfinite(cb).all(1)
+        order = O.sort_desc_stable(cl[keep])
+        rb, rl, rv = cb[keep][order].numpy(), cl[keep][order].numpy(), clv[keep][order].numpy()
+        n = int(cnt[b].item())
+        assert n == len(rb)
+        assert np.array_equal(ss[b, :n].cpu().numpy(), rl)           # logits exact, order exact
+        assert np.array_equal(scat[b, :n].cpu().numpy(), rv)
+        assert np.abs(sb[b, :n].cpu().numpy() - rb).max() < 1e-4     # expf: <= a few ulp of the box size
+
+
+@pytest.mark.parametrize("n,ncat,thresh", [(700, 3, 0.5), (3000, 5, 0.7), (64, 1, 0.3), (1, 1, 0.5), (0, 1, 0.5)])
+def test_nms_exact(gpu_ctx, n, ncat, thresh):
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(n + 7)
+    B, cap = 2, 3072
+    boxes = np.zeros((B, cap, 4), np.float32)
+    cats = np.full((B, cap), -1, np.int32)
+    ns = [n, max(n - 5, 0)]
+    for b in range(B):
+        c = rng.uniform(0, 300, (ns[b], 2))
+        s = rng.uniform(4, 80, (ns[b], 2))
+        boxes[b, :ns[b]] = np.concatenate([c - s / 2, c + s / 2], 1)
+        cats[b, :ns[b]] = rng.integers(0, ncat, ns[b])
+    keep, kc = ops.nms(gpu_ctx, torch.from_numpy(boxes).to(DEV), torch.from_numpy(cats).to(DEV),
+                       torch.tensor(ns, dtype=torch.int32, device=DEV), thresh, max_keep=1000)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = O.nms_sorted(torch.from_numpy(boxes[b, :ns[b]]), torch.from_numpy(cats[b, :ns[b]].astype(np.int64)), thresh,
+                           max_keep=1000).numpy()
+        assert int(kc[b].item()) == len(ref)
+        assert np.array_equal(keep[b, :len(ref)].cpu().numpy(), ref)
+
+
+def test_roi_align_matches_oracle(gpu_ctx):
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(11)
+    B, C = 2, 256
+    shapes = [(64, 80), (32, 40), (16, 20), (8, 10)]
+    feats = [torch.from_numpy(rng.normal(0, 1, (B, h, w, C)).astype(np.float32)) for h, w in shapes]
+    R = 120
+    ctr = rng.uniform(0, 1, (R, 2)) * np.array([320, 256])
+    size = np.exp(rng.uniform(np.log(4), np.log(500), (R, 2)))
+    rois = np.concatenate([ctr - size / 2, ctr + size / 2], 1).astype(np.float32)
+    rois = np.clip(rois, 0, [320, 256, 320, 256]).astype(np.float32)
+    rois[0] = [10, 10, 10, 30]            # zero width -> empty sampling grid -> zeros
+    rois[1] = [0, 0, 320, 256]            # whole image, highest level
+    bidx = rng.integers(0, B, R).astype(np.int32)
+    for P in (7, 14):
+        out, lvl = ops.roi_align(gpu_ctx, [f.to(DEV) for f in feats], torch.from_numpy(rois).to(DEV),
+                                 torch.from_numpy(bidx).to(DEV), P)
+        torch.cuda.synchronize()
+        out, lvl = out.cpu(), lvl.cpu().numpy()
+        ref_lvl = O.assign_levels(torch.from_numpy(rois)).numpy()
+        assert np.array_equal(lvl, ref_lvl)
+        for r in range(R):
+            f = feats[ref_lvl[r]][bidx[r]].permute(2, 0, 1)
+            ref = O.roi_align(f, torch.from_numpy(rois[r:r + 1]), P, 1.0 / (4 * 2 ** ref_lvl[r]))[0].permute(1, 2, 0)
+            assert torch.equal(out[r], ref), (P, r, float((out[r] - ref).abs().max()))
+
+
+def test_box_inference_chain(gpu_ctx):
+    """box_candidates -> sort_gather -> nms -> same detections as fast_rcnn_inference_single_image."""
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(5)
+    B, Rcap, K, H, W, D = 2, 400, 3, 300, 400, 50
+    cfg = O.Cfg(num_classes=K, detections_per_image=D)
+    pred = rng.normal(0, 1.5, (B * Rcap, 5 * K + 1)).astype(np.float32)
+    pred[:, K + 1:] *= 0.5
+    ctr = rng.uniform(0, 1, (B, Rcap, 2)) * np.array([W, H])
+    size = rng.uniform(8, 120, (B, Rcap, 2))
+    props = np.clip(np.concatenate([ctr - size / 2, ctr + size / 2], 2), 0, [W, H, W, H]).astype(np.float32)
+    counts = np.array([Rcap, Rcap - 37], np.int32)
+    dense, keys, cnt, ovf = ops.box_candidates(gpu_ctx, torch.from_numpy(pred).to(DEV), torch.from_numpy(props).to(DEV),
+                                               torch.from_numpy(counts).to(DEV), K, cfg.score_thresh, H, W)
+    sb, ss, sc, scount, _ = ops.sort_gather(gpu_ctx, keys, dense, box_stride=Rcap * K)
+    keep, kc = ops.nms(gpu_ctx, sb, sc, scount, cfg.nms_thresh, D)
+    torch.cuda.synchronize()
+    assert int(ovf.item()) == 0
+    for b in range(B):
+        n = counts[b]
+        rows = torch.from_numpy(pred[b * Rcap: b * Rcap + n])
+        rb, rs, rc = O.box_inference_single(rows[:, :K + 1], rows[:, K + 1:], torch.from_numpy(props[b, :n]), (H, W), cfg)
+        k = int(kc[b].item())
+        assert k == len(rb)
+        idx = keep[b, :k].long()
+        assert np.array_equal(sc[b][idx].cpu().numpy(), rc.numpy())
+        assert np.abs(ss[b][idx].cpu().numpy() - rs.numpy()).max() < 2e-6
+        assert np.abs(sb[b][idx].cpu().numpy() - rb.numpy()).max() < 2e-4
+
+
+def test_paste_rle_matches_oracle(gpu_ctx):
+    """paste + threshold + RLE on device == oracle paste_mask (F.grid_sample) + oracle RLE encode, run for run."""
+    from ampis_amd import ops
+    from oracle import maskrcnn as O, rle as orle
+    rng = np.random.default_rng(9)
+    H, W = 160, 208
+    N = 40
+    # smooth blobs + a few noisy ones (many runs), probabilities in [0,1]
+    yy, xx = np.mgrid[0:28, 0:28]
+    prob = np.zeros((N, 28, 28), np.float32)
+    for i in range(N):
+        cy, cx, r = rng.uniform(8, 20), rng.uniform(8, 20), rng.uniform(4, 12)
+        prob[i] = 1 / (1 + np.exp(((yy - cy) ** 2 + (xx - cx) ** 2 - r * r) / 8))
+        if i % 5 == 0:
+            prob[i] = rng.uniform(0, 1, (28, 28))
+    ctr = rng.uniform(0, 1, (N, 2)) * np.array([W, H])
+    size = np.exp(rng.uniform(np.log(3), np.log(150), (N, 2)))
+    boxes = np.concatenate([ctr - size / 2, ctr + size / 2], 1).astype(np.float32)
+    boxes[0] = [-20, -10, W + 30, H + 20]     # covers everything (wrap-around columns)
+    boxes[1] = [5.5, 0, 40.25, H]             # full-height columns
+    boxes[2] = [50, 60, 50, 90]               # empty after clip -> dropped
+    boxes[3] = [W - 10.3, 20.7, W + 5, 70.2]  # touches the right border
+    ob, valid, runs = ops.paste_rle(gpu_ctx, torch.from_numpy(prob).to(DEV), torch.from_numpy(boxes).to(DEV),
+                                    torch.zeros(N, dtype=torch.int32, device=DEV),
+                                    torch.tensor([H], dtype=torch.int32, device=DEV), torch.tensor([W], dtype=torch.int32, device=DEV),
+                                    H, W)
+    ob, valid = ob.cpu().numpy(), valid.cpu().numpy()
+    nflip = 0
+    for i in range(N):
+        b = O.clip_boxes(torch.from_numpy(boxes[i:i + 1]).clone(), H, W)[0]
+        nonempty = bool((b[2] - b[0] > 0) and (b[3] - b[1] > 0))
+        assert bool(valid[i]) == nonempty
+        if not nonempty:
+            assert len(runs[i]) == 0
+            continue
+        assert np.array_equal(ob[i], b.numpy())
+        ref = O.paste_mask(torch.from_numpy(prob[i]), b, H, W, 0.5).numpy()
+        assert int(runs[i].sum()) == H * W
+        got = orle.decode_counts(runs[i], H, W)
+        if not np.array_equal(runs[i], orle.encode_counts(ref)):
+            nflip += int((got != ref).sum())   # a pixel whose interpolated value is within 1 ulp of 0.5
+    assert nflip <= 2, f"{nflip} pixels differ from the oracle paste"
