@@ -1,0 +1,62 @@
+"""DefaultPredictor façade on the GPU: notebook cells 24-28 (cfg -> DefaultPredictor -> predictor(img) -> format_outputs)
+against the oracle run on the same resized input; includes the 800/1333 resize and the rescale to the original size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_predictor_matches_oracle_with_resize(tmp_path):
+    from ampis_amd import checkpoint, data_utils, model_zoo, params as P, rle, synth
+    from ampis_amd.config import get_cfg
+    from ampis_amd.engine import DefaultPredictor
+    from ampis_amd.engine.defaults import resize_shortest_edge
+    from oracle import maskrcnn as O
+
+    K, D = 1, 30
+    npp = P.init_params(K, seed=21, style="spread")
+    wpath = tmp_path / "model_final.pth"
+    checkpoint.save_checkpoint(wpath, npp)
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = K
+    cfg.TEST.DETECTIONS_PER_IMAGE = D
+    cfg.DATASETS.TEST = ("particle_Train",)
+    cfg.MODEL.WEIGHTS = str(wpath)
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 160, 256      # small net input, exercises the resize + rescale
+    img, _ = synth.micrograph(3, 240, 300)
+    predictor = DefaultPredictor(cfg)
+    outs = predictor(img)
+    inst = outs["instances"]
+    assert inst.image_size == (240, 300) and len(inst) > 0
+    assert inst.pred_boxes.tensor.dtype == torch.float32 and inst.pred_classes.dtype == torch.int64
+    assert torch.all(inst.scores[:-1] >= inst.scores[1:])
+
+    small = resize_shortest_edge(img, 160, 256)
+    assert small.shape[:2] == (160, 200)
+    ref = O.infer(small[None], O.to_torch_params(npp), O.Cfg(num_classes=K, detections_per_image=D), out_sizes=[(240, 300)])[0]
+    rb, rm = ref["boxes"].numpy(), ref["masks"].numpy()
+    assert abs(len(rb) - len(inst)) <= 1
+    res = data_utils.format_outputs("a.png", "particle_Train", outs)
+    p = res["pred"]["instances"]
+    good = 0
+    for i in range(len(rb)):
+        d = np.abs(p.pred_boxes - rb[i]).max(axis=1)
+        j = int(np.argmin(d))
+        if d[j] < 1e-3:
+            gm = rle.decode(p.pred_masks[j]).astype(bool)
+            u = (gm | rm[i]).sum()
+            good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
+    assert good >= 0.97 * len(rb), f"{good}/{len(rb)}"
+
+
+def test_predictor_refuses_cpu_device():
+    from ampis_amd import _lib
+    from ampis_amd.config import get_cfg
+    from ampis_amd.engine import DefaultPredictor
+    cfg = get_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
+    with pytest.raises(_lib.AmpError):
+        DefaultPredictor(cfg)
