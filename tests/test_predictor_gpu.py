@@ -40,15 +40,18 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
     assert abs(len(rb) - len(inst)) <= 1
     res = data_utils.format_outputs("a.png", "particle_Train", outs)
     p = res["pred"]["instances"]
+    # Gate (DESIGN.md "Parity"): every oracle instance has a HIP twin with box |d| < 1e-3 px whose mask differs by at most
+    # 2 pixels (an interpolated value within ~1e-5 of the 0.5 threshold may flip); >= 95 % reach IoU >= 0.999.
     good = 0
     for i in range(len(rb)):
         d = np.abs(p.pred_boxes - rb[i]).max(axis=1)
         j = int(np.argmin(d))
-        if d[j] < 1e-3:
-            gm = rle.decode(p.pred_masks[j]).astype(bool)
-            u = (gm | rm[i]).sum()
-            good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
-    assert good >= 0.97 * len(rb), f"{good}/{len(rb)}"
+        assert d[j] < 1e-3, (i, d[j])
+        gm = rle.decode(p.pred_masks[j]).astype(bool)
+        assert int((gm ^ rm[i]).sum()) <= 2, (i, int((gm ^ rm[i]).sum()))
+        u = (gm | rm[i]).sum()
+        good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
+    assert good >= 0.95 * len(rb), f"{good}/{len(rb)}"
 
 
 def test_predictor_refuses_cpu_device():
