@@ -169,48 +169,94 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue ----
-    const int C2 = a.Cout >> 2;  // deconv scatter only
+    // ---- epilogue: accumulators -> LDS (per-wave tile, [m][n]) -> row-wise float4 residual loads + stores ----
+    // The MFMA C layout puts one n per lane and 16 m in registers: stored directly that is 64 dword stores per lane and,
+    // with a residual, 64 dependent dword loads.  Transposed through LDS every lane owns 4 consecutive n of one row per
+    // step: 16-B coalesced residual loads (all issued before the first store) and 16-B stores.
+    constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
+    constexpr int F4R = WTN / 4;                       // float4 per row
+    constexpr int RPI = 64 / F4R;                      // rows per iteration (one wave)
+    constexpr int NIT = WTM / RPI;
+    static_assert(4 * WTM * SLD <= 2 * TILE_FLOATS, "staging tile must fit in the operand buffers");
+    float* stage = lds + wave * (WTM * SLD);
+    // (the loop's last __syncthreads() already ordered every wave's operand reads before these writes)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + l31;
-        const bool nv = n < a.Cout;
-        const float sc = (a.scale && nv) ? a.scale[n] : 1.f;
-        const float sh = (a.shift && nv) ? a.shift[n] : 0.f;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (!nv || m >= a.M) continue;
-                float v = __fadd_rn(__fmul_rn(acc[i][j][e], sc), sh);
-                size_t yoff;
-                if (a.res_mode == 0 && a.out_mode == 0) {
-                    yoff = (size_t)m * a.Cout + n;
+            for (int e = 0; e < 16; ++e)
+                stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + l31] = acc[i][j][e];
+
+    const int erow = lane / F4R;                       // row within an iteration
+    const int ec4 = lane % F4R;
+    const int n = n0 + wn * WTN + ec4 * 4;
+    const bool vec = (a.Cout & 3) == 0;                // rows of y / res are 16-B aligned
+    const bool nv = n < a.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (n + q < a.Cout) {
+            if (a.scale) sc[q] = a.scale[n + q];
+            if (a.shift) sh[q] = a.shift[n + q];
+        }
+    }
+    const int C2 = a.Cout >> 2;                        // deconv scatter only
+
+    size_t yoff[NIT];
+    f32x4 rres[NIT];
+    bool mv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int m = m0 + wm * WTM + it * RPI + erow;
+        mv[it] = nv && m < a.M;
+        yoff[it] = (size_t)m * a.Cout + n;
+        rres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!mv[it]) continue;
+        if (a.res_mode != 0 || a.out_mode != 0) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            size_t roff = yoff[it];
+            if (a.res_mode == 2)
+                roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+            if (a.res_mode != 0) {
+                if (vec) {
+                    rres[it] = *reinterpret_cast<const f32x4*>(a.res + roff);
                 } else {
-                    const int b = m / HoWo;
-                    const int rem = m - b * HoWo;
-                    const int oy = rem / a.Wo;
-                    const int ox = rem - oy * a.Wo;
-                    if (a.res_mode == 1) {
-                        v = __fadd_rn(v, a.res[(size_t)m * a.Cout + n]);
-                    } else if (a.res_mode == 2) {
-                        const size_t roff =
-                            ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
-                        v = __fadd_rn(v, a.res[roff]);
-                    }
-                    if (a.out_mode == 1) {
-                        const int kk = n / C2;
-                        const int co = n - kk * C2;
-                        const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
-                        yoff = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
-                    } else {
-                        yoff = (size_t)m * a.Cout + n;
-                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.Cout) rres[it][q] = a.res[roff + q];
                 }
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.y[yoff] = v;
             }
+            if (a.out_mode == 1) {
+                const int kk = n / C2;
+                const int co = n - kk * C2;
+                const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
+                yoff[it] = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                   // staging writes of this wave precede its reads (same-wave LDS order)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * RPI + erow) * SLD + ec4 * 4);
+        if (!mv[it]) continue;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = __fadd_rn(__fmul_rn(v[q], sc[q]), sh[q]);
+            if (a.res_mode != 0) t = __fadd_rn(t, rres[it][q]);
+            if (a.relu) t = fmaxf(t, 0.f);
+            o[q] = t;
+        }
+        if (vec) {
+            *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < a.Cout) a.y[yoff[it] + q] = o[q];
         }
     }
 }

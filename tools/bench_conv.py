@@ -6,6 +6,12 @@ from ampis_amd import ops
 
 SHAPES = [
     # name, B, H, W, Cin, Cout, k, stride, pad
+    ("res2.1x1c+res", 8, 256, 256, 64, 256, 1, 1, 0, "res"),
+    ("res3.1x1c+res", 8, 128, 128, 128, 512, 1, 1, 0, "res"),
+    ("res4.1x1c+res", 8, 64, 64, 256, 1024, 1, 1, 0, "res"),
+    ("fpn.lat.p2+up", 8, 256, 256, 256, 256, 1, 1, 0, "up"),
+    ("mask.deconv", 1600, 14, 14, 256, 1024, 1, 1, 0, "deconv"),
+    ("mask.pred(K=2)", 1600, 28, 28, 256, 2, 1, 1, 0),
     ("stem7x7(kw8,c4)", 8, 1024, 1024, 4, 64, (7, 8), 2, 3),
     ("res2.1x1a", 8, 256, 256, 64, 64, 1, 1, 0),
     ("res2.3x3", 8, 256, 256, 64, 64, 3, 1, 1),
@@ -28,20 +34,29 @@ def main():
     ctx = ops.torch_context(0)
     d = "cuda:0"
     out = []
-    for name, B, H, W, Cin, Cout, k, s, p in SHAPES:
+    for shp in SHAPES:
+        name, B, H, W, Cin, Cout, k, s, p = shp[:9]
+        mode = shp[9] if len(shp) > 9 else ""
         kh, kw = (k if isinstance(k, tuple) else (k, k))
         x = torch.randn(B, H, W, Cin, device=d)
         w = torch.randn(Cout, kh, kw, Cin, device=d) * 0.05
         sc = torch.ones(Cout, device=d); sh = torch.zeros(Cout, device=d)
         Ho = (H + 2 * p - kh) // s + 1; Wo = (W + 2 * p - kw) // s + 1
         flops = 2.0 * B * Ho * Wo * Cout * kh * kw * Cin
+        kw_args = dict(stride=s, pad=p, relu=True)
+        if mode == "res":
+            kw_args.update(res=torch.randn(B, Ho, Wo, Cout, device=d), res_mode=1)
+        elif mode == "up":
+            kw_args.update(res=torch.randn(B, Ho // 2, Wo // 2, Cout, device=d), res_mode=2)
+        elif mode == "deconv":
+            kw_args.update(deconv2x2=True)
         for _ in range(2):
-            ops.conv2d_nhwc(ctx, x, w, sc, sh, stride=s, pad=p, relu=True)
+            ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw_args)
         torch.cuda.synchronize()
         n = 5
         ctx.timer_start()
         for _ in range(n):
-            ops.conv2d_nhwc(ctx, x, w, sc, sh, stride=s, pad=p, relu=True)
+            ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw_args)
         ms = ctx.timer_stop() / n
         tf = flops / ms / 1e9
         out.append((name, ms, tf))
