@@ -71,6 +71,7 @@ struct amp_ctx {
     hipStream_t stream;
     bool own_stream;
     hipEvent_t ev0, ev1;
+    float* zero_page = nullptr;            // 256 zero bytes: source of out-of-image taps for the LDS-DMA conv
     // live kernel profile (amp_prof_begin/end): HIP-event pairs around every conv launch on this stream
     bool prof_on = false;
     std::vector<amp_prof_rec> prof_pool;   // pre-created events

@@ -45,6 +45,11 @@ int amp_init(int device, void* hip_stream, int flags, amp_ctx** out) {
         delete c;
         return AMP_ERR_HIP;
     }
+    if (hipMalloc(&c->zero_page, 256) != hipSuccess || hipMemset(c->zero_page, 0, 256) != hipSuccess) {
+        amp::set_error("amp_init: zero page allocation failed");
+        delete c;
+        return AMP_ERR_HIP;
+    }
     *out = c;
     return AMP_OK;
 }
@@ -101,6 +106,7 @@ void amp_destroy(amp_ctx* ctx) {
     for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    (void)hipFree(ctx->zero_page);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

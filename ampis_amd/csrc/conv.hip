@@ -40,7 +40,105 @@ struct ConvArgs {
     int nblk;
 };
 
-template <int BM, int BN>
+// Epilogue shared by both kernels: accumulators -> LDS (per-wave tile, [m][n]) -> row-wise float4 residual loads + stores.
+// The MFMA C layout puts one n per lane and 16 m in registers: stored directly that is 64 dword stores per lane and,
+// with a residual, 64 dependent dword loads.  Transposed through LDS every lane owns 4 consecutive n of one row per step:
+// 16-B coalesced residual loads (all issued before the first store) and 16-B stores.  Callers pass the wave's tile origin
+// (mw0, nw0) and must have synchronised the workgroup after the last operand reads.
+template <int WTM, int WTN, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* lds, int wave, int lane,
+                                              int mw0, int nw0, int HoWo) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
+    constexpr int F4R = WTN / 4;                       // float4 per row
+    constexpr int RPI = 64 / F4R;                      // rows per iteration (one wave)
+    constexpr int NIT = WTM / RPI;
+    float* stage = lds + wave * (WTM * SLD);
+    // (the loop's last __syncthreads() already ordered every wave's operand reads before these writes)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + l31] = acc[i][j][e];
+
+    const int erow = lane / F4R;                       // row within an iteration
+    const int ec4 = lane % F4R;
+    const int n = nw0 + ec4 * 4;
+    const bool vec = (a.Cout & 3) == 0;                // rows of y / res are 16-B aligned
+    const bool nv = n < a.Cout;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (n + q < a.Cout) {
+            if (a.scale) sc[q] = a.scale[n + q];
+            if (a.shift) sh[q] = a.shift[n + q];
+        }
+    }
+    const int C2 = a.Cout >> 2;                        // deconv scatter only
+
+    size_t yoff[NIT];
+    f32x4 rres[NIT];
+    bool mv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int m = mw0 + it * RPI + erow;
+        mv[it] = nv && m < a.M;
+        yoff[it] = (size_t)m * a.Cout + n;
+        rres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!mv[it]) continue;
+        if (a.res_mode != 0 || a.out_mode != 0) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            size_t roff = yoff[it];
+            if (a.res_mode == 2)
+                roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
+            if (a.res_mode != 0) {
+                if (vec) {
+                    rres[it] = *reinterpret_cast<const f32x4*>(a.res + roff);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.Cout) rres[it][q] = a.res[roff + q];
+                }
+            }
+            if (a.out_mode == 1) {
+                const int kk = n / C2;
+                const int co = n - kk * C2;
+                const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
+                yoff[it] = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                   // staging writes of this wave precede its reads (same-wave LDS order)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * RPI + erow) * SLD + ec4 * 4);
+        if (!mv[it]) continue;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float t = __fadd_rn(__fmul_rn(v[q], sc[q]), sh[q]);
+            if (a.res_mode != 0) t = __fadd_rn(t, rres[it][q]);
+            if (a.relu) t = fmaxf(t, 0.f);
+            o[q] = t;
+        }
+        if (vec) {
+            *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < a.Cout) a.y[yoff[it] + q] = o[q];
+        }
+    }
+}
+
+// ABL (ablation, tools/bench_conv_ablate.py only; results wrong for ABL != 0): 1 = no global loads in the K loop,
+// 2 = also no LDS writes / barriers, 3 = MFMA only (fragments read once).
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -143,19 +241,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     for (int step = 0; step < a.nsteps; ++step) {
         const int cur = step & 1;
         const bool more = step + 1 < a.nsteps;
-        if (more) load_tiles(step + 1);
+        if (more && ABL == 0) load_tiles(step + 1);
 
         const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * LDS_LD + 4 * lh;
         const float* Bs = lds + cur * TILE_FLOATS + BM * LDS_LD + (wn * WTN + l31) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[MT], bf[NT];
+            if (ABL < 3 || step == 0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * q);
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LDS_LD + 8 * q);
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * q);
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LDS_LD + 8 * q);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = f32x4{acc[i][0][0], 1.f, 2.f, 3.f};
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = f32x4{acc[0][j][1], 1.f, 2.f, 3.f};
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -165,103 +270,167 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
 
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
+        if (ABL < 2) {
+            if (more) store_tiles(cur ^ 1);
+            __syncthreads();
+        }
     }
+    if (ABL >= 2) __syncthreads();
 
-    // ---- epilogue: accumulators -> LDS (per-wave tile, [m][n]) -> row-wise float4 residual loads + stores ----
-    // The MFMA C layout puts one n per lane and 16 m in registers: stored directly that is 64 dword stores per lane and,
-    // with a residual, 64 dependent dword loads.  Transposed through LDS every lane owns 4 consecutive n of one row per
-    // step: 16-B coalesced residual loads (all issued before the first store) and 16-B stores.
-    constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
-    constexpr int F4R = WTN / 4;                       // float4 per row
-    constexpr int RPI = 64 / F4R;                      // rows per iteration (one wave)
-    constexpr int NIT = WTM / RPI;
-    static_assert(4 * WTM * SLD <= 2 * TILE_FLOATS, "staging tile must fit in the operand buffers");
-    float* stage = lds + wave * (WTM * SLD);
-    // (the loop's last __syncthreads() already ordered every wave's operand reads before these writes)
+    static_assert(4 * (BM / 2) * (BN / 2 + 4) <= 2 * TILE_FLOATS, "staging tile must fit in the operand buffers");
+    conv_epilogue<WTM, WTN, MT, NT>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv_glds_kernel: same tiling and epilogue, operand staging by LDS-DMA (global_load_lds_dwordx4), for Cin % 32 == 0
+// (every layer but the stem).  Measured on the register-staged kernel above (tools/bench_conv_ablate.py, 3x3 256->256
+// @256^2): MFMA-only floor 151.7 TF, + LDS reads 150.1, + register->LDS writes and barrier 137.6, + predicated global
+// loads and their per-step address VALU 120.4.  Here a K-step's tap (ky,kx,c0) is block-uniform scalar state, a lane's
+// source pointer per row is recomputed only when the tap changes, out-of-image taps read a zero page (no predication),
+// and the loads land in LDS without passing through VGPRs.  One wave-instruction writes 8 rows x 128 B linearly, so the
+// bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE chunk and again on the fragment reads
+// (chunk ^ ((row >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128).
+// ------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, const float* __restrict__ zero_page) {
+    constexpr int BM = 128;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int GA = 4;                 // glds per wave per step for A: 32 rows per wave, 8 rows per instruction
+    constexpr int GB = BN / 32;           // ... for B: BN/4 rows per wave
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int SLD = WTN + 4;
+    constexpr int STAGE_FLOATS = 4 * WTM * SLD;
+    constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = tile % a.ntn;
+    const int tile_m = tile / a.ntn;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int HoWo = a.Ho * a.Wo;
+
+    // ---- staging geometry: instruction g of this wave fills rows wave*R + 8g + (lane>>3), 16-B position lane&7 ----
+    const int srow = lane >> 3, spos = lane & 7;
+    int a_iy0[GA], a_ix0[GA], a_pb[GA];
+    int a_chunk[GA];                      // source chunk (floats) = 4 * (pos ^ swz(row))
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+        const int r = wave * 32 + 8 * g + srow;
+        a_chunk[g] = 4 * (spos ^ ((r >> 1) & 7));
+        const int m = m0 + r;
+        if (m < a.M) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oy = rem / a.Wo;
+            const int ox = rem - oy * a.Wo;
+            a_iy0[g] = oy * a.stride - a.pad;
+            a_ix0[g] = ox * a.stride - a.pad;
+            a_pb[g] = b * a.H * a.W;
+        } else {
+            a_iy0[g] = -(1 << 28);
+            a_ix0[g] = 0;
+            a_pb[g] = 0;
+        }
+    }
+    const float* b_ptr[GB];               // weight row pointer incl. the swizzled chunk; advances 32 floats per step
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * (BN / 4) + 8 * g + srow;
+        const int n = n0 + r;
+        b_ptr[g] = (n < a.Cout) ? a.w + (size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7)) : nullptr;
+    }
+    const float* a_ptr[GA];               // input pixel pointer of the current tap incl. the swizzled chunk (null = padding)
+
+    const int csteps = a.Cin / BK;        // K-steps per tap
+    int ky = 0, kx = 0, cs = 0;           // block-uniform tap state of the tile being STAGED
+
+    auto stage = [&](int buf) {
+        if (cs == 0) {                    // new tap: recompute the row pointers (uniform branch)
+#pragma unroll
+            for (int g = 0; g < GA; ++g) {
+                const int iy = a_iy0[g] + ky, ix = a_ix0[g] + kx;
+                const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                a_ptr[g] = v ? a.x + (size_t)(a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g] : nullptr;
+            }
+        }
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + BM * BK;
+        const int coff = cs * BK;
+#pragma unroll
+        for (int g = 0; g < GA; ++g) {
+            const float* src = a_ptr[g] ? a_ptr[g] + coff : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(As + (wave * 32 + 8 * g) * BK), 16, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+            const float* src = b_ptr[g] ? b_ptr[g] : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK), 16, 0, 0);
+            if (b_ptr[g]) b_ptr[g] += BK;
+        }
+        if (++cs == csteps) {
+            cs = 0;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + l31] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int erow = lane / F4R;                       // row within an iteration
-    const int ec4 = lane % F4R;
-    const int n = n0 + wn * WTN + ec4 * 4;
-    const bool vec = (a.Cout & 3) == 0;                // rows of y / res are 16-B aligned
-    const bool nv = n < a.Cout;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    // fragment read offsets (floats): row*32 + 4*((2q+lh) ^ swz(row)), swz(row) = (l31>>1)&7 for every 32-row fragment
+    const int fswz = (l31 >> 1) & 7;
+    int foff[BK / 8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (n + q < a.Cout) {
-            if (a.scale) sc[q] = a.scale[n + q];
-            if (a.shift) sh[q] = a.shift[n + q];
-        }
-    }
-    const int C2 = a.Cout >> 2;                        // deconv scatter only
+    for (int q = 0; q < BK / 8; ++q) foff[q] = 4 * ((2 * q + lh) ^ fswz);
 
-    size_t yoff[NIT];
-    f32x4 rres[NIT];
-    bool mv[NIT];
+    stage(0);
+    __syncthreads();
+
+    for (int step = 0; step < a.nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < a.nsteps) stage(cur ^ 1);
+
+        const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
+        const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int m = m0 + wm * WTM + it * RPI + erow;
-        mv[it] = nv && m < a.M;
-        yoff[it] = (size_t)m * a.Cout + n;
-        rres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!mv[it]) continue;
-        if (a.res_mode != 0 || a.out_mode != 0) {
-            const int b = m / HoWo;
-            const int rem = m - b * HoWo;
-            const int oy = rem / a.Wo;
-            const int ox = rem - oy * a.Wo;
-            size_t roff = yoff[it];
-            if (a.res_mode == 2)
-                roff = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout + n;
-            if (a.res_mode != 0) {
-                if (vec) {
-                    rres[it] = *reinterpret_cast<const f32x4*>(a.res + roff);
-                } else {
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 af[MT], bf[NT];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.Cout) rres[it][q] = a.res[roff + q];
-                }
-            }
-            if (a.out_mode == 1) {
-                const int kk = n / C2;
-                const int co = n - kk * C2;
-                const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
-                yoff[it] = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
-            }
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + foff[q]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + foff[q]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();   // emits vmcnt(0): the LDS-DMA of the next tile has landed; everyone is done with `cur`
     }
-    __builtin_amdgcn_wave_barrier();                   // staging writes of this wave precede its reads (same-wave LDS order)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * RPI + erow) * SLD + ec4 * 4);
-        if (!mv[it]) continue;
-        f32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float t = __fadd_rn(__fmul_rn(v[q], sc[q]), sh[q]);
-            if (a.res_mode != 0) t = __fadd_rn(t, rres[it][q]);
-            if (a.relu) t = fmaxf(t, 0.f);
-            o[q] = t;
-        }
-        if (vec) {
-            *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (n + q < a.Cout) a.y[yoff[it] + q] = o[q];
-        }
-    }
+
+    conv_epilogue<WTM, WTN, MT, NT>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
 }
 
 }  // namespace
+
+static int g_conv_ablate = 0;
+extern "C" void amp_debug_set_conv_ablate(int mode) { g_conv_ablate = mode; }
 
 extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                                const float* scale, const float* shift, const float* res, float* y) {
@@ -303,10 +472,26 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
             ctx->prof_truncated = true;
         }
     }
-    if (a.Cout > 64) {
+    const bool glds = (a.Cin % BK == 0) && g_conv_ablate == 0;   // every layer but the stem (Cin = 4)
+    if (glds) {
+        if (a.Cout > 64) {
+            a.ntn = amp::cdiv(a.Cout, 128);
+            a.nblk = ntm * a.ntn;
+            hipLaunchKernelGGL((conv_glds_kernel<128>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, ctx->zero_page);
+        } else {
+            a.ntn = 1;
+            a.nblk = ntm;
+            hipLaunchKernelGGL((conv_glds_kernel<64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, ctx->zero_page);
+        }
+    } else if (a.Cout > 64) {
         a.ntn = amp::cdiv(a.Cout, 128);
         a.nblk = ntm * a.ntn;
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, 128>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+        switch (g_conv_ablate) {
+            case 1: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 1>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            case 2: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 2>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            case 3: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 3>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 0>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+        }
     } else {
         a.ntn = 1;
         a.nblk = ntm;
