@@ -282,21 +282,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// conv_glds_kernel: same tiling and epilogue, operand staging by LDS-DMA (global_load_lds_dwordx4), for Cin % 32 == 0
-// (every layer but the stem).  Measured on the register-staged kernel above (tools/bench_conv_ablate.py, 3x3 256->256
-// @256^2): MFMA-only floor 151.7 TF, + LDS reads 150.1, + register->LDS writes and barrier 137.6, + predicated global
-// loads and their per-step address VALU 120.4.  Here a K-step's tap (ky,kx,c0) is block-uniform scalar state, a lane's
-// source pointer per row is recomputed only when the tap changes, out-of-image taps read a zero page (no predication),
-// and the loads land in LDS without passing through VGPRs.  One wave-instruction writes 8 rows x 128 B linearly, so the
-// bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE chunk and again on the fragment reads
-// (chunk ^ ((row >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128).
+// conv_glds_kernel: same tiling and epilogue, operand staging by LDS-DMA (buffer_load_dwordx4 ... lds), for Cin % 32 == 0
+// (every layer but the stem).  What the experiments on this kernel family showed (tools/bench_conv_ablate.py and the
+// timing variants recorded in DESIGN.md §4, 3x3 256->256 @256^2): MFMA-only floor 151.7 TF; LDS fragment reads and the
+// per-step barrier are free (148-150 TF); register-staged operands with predicated global loads 120 TF; LDS-DMA with
+// per-lane 64-bit pointers + zero-page selects 134 TF, of which ~3 % is the DMA instructions and ~9 % their address VALU
+// (each VALU instruction takes an issue slot the MFMA stream wants).  Hence: buffer addressing.  A row's byte offset
+// (voffset, 32-bit) is recomputed only when the tap (ky,kx) changes; the channel offset inside the tap and the K offset
+// of the weights are block-uniform and ride in the scalar soffset; out-of-image taps and rows beyond M / Cout get an
+// out-of-range voffset, for which the hardware bounds check writes zeros into LDS (probed on gfx950) -- no predication,
+// no zero page, no per-step VALU.  One wave-instruction writes 8 rows x 128 B linearly, so the bank-conflict fix is an
+// XOR swizzle applied to the per-lane SOURCE chunk and again on the fragment reads (chunk ^ ((row >> 1) & 7):
+// conflict-free for the 16-lane groups of ds_read_b128).
 // ------------------------------------------------------------------------------------------------------------------
+constexpr unsigned int OOB_VOFF = 0x80000000u;   // >= num_records of every buffer this kernel accepts (< 2 GiB)
+
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, const float* __restrict__ zero_page) {
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int GA = 4;                 // glds per wave per step for A: 32 rows per wave, 8 rows per instruction
+    constexpr int GA = 4;                 // DMA instructions per wave per step for A: 32 rows per wave, 8 rows each
     constexpr int GB = BN / 32;           // ... for B: BN/4 rows per wave
     constexpr int TILE_FLOATS = (BM + BN) * BK;
     constexpr int SLD = WTN + 4;
@@ -317,14 +323,16 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     const int n0 = tile_n * BN;
     const int HoWo = a.Ho * a.Wo;
 
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+
     // ---- staging geometry: instruction g of this wave fills rows wave*R + 8g + (lane>>3), 16-B position lane&7 ----
     const int srow = lane >> 3, spos = lane & 7;
-    int a_iy0[GA], a_ix0[GA], a_pb[GA];
-    int a_chunk[GA];                      // source chunk (floats) = 4 * (pos ^ swz(row))
+    int a_iy0[GA], a_ix0[GA], a_pb[GA], a_chunk[GA];
 #pragma unroll
     for (int g = 0; g < GA; ++g) {
         const int r = wave * 32 + 8 * g + srow;
-        a_chunk[g] = 4 * (spos ^ ((r >> 1) & 7));
+        a_chunk[g] = 4 * (spos ^ ((r >> 1) & 7));      // source chunk (floats) = 4 * (pos ^ swz(row))
         const int m = m0 + r;
         if (m < a.M) {
             const int b = m / HoWo;
@@ -340,43 +348,41 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
             a_pb[g] = 0;
         }
     }
-    const float* b_ptr[GB];               // weight row pointer incl. the swizzled chunk; advances 32 floats per step
+    unsigned int b_voff[GB];              // byte offset of the weight row (+ swizzled chunk); the K offset rides in soffset
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
         const int r = wave * (BN / 4) + 8 * g + srow;
         const int n = n0 + r;
-        b_ptr[g] = (n < a.Cout) ? a.w + (size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7)) : nullptr;
+        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
-    const float* a_ptr[GA];               // input pixel pointer of the current tap incl. the swizzled chunk (null = padding)
+    unsigned int a_voff[GA];              // byte offset of the input pixel of the current tap (+ swizzled chunk), or OOB
 
     const int csteps = a.Cin / BK;        // K-steps per tap
     int ky = 0, kx = 0, cs = 0;           // block-uniform tap state of the tile being STAGED
+    int kstep = 0;                        // index of the tile being staged
 
     auto stage = [&](int buf) {
-        if (cs == 0) {                    // new tap: recompute the row pointers (uniform branch)
+        if (cs == 0) {                    // new tap: recompute the row offsets (uniform branch, once per Cin/32 steps)
 #pragma unroll
             for (int g = 0; g < GA; ++g) {
                 const int iy = a_iy0[g] + ky, ix = a_ix0[g] + kx;
                 const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                a_ptr[g] = v ? a.x + (size_t)(a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g] : nullptr;
+                a_voff[g] = v ? (unsigned int)(((a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g]) * 4) : OOB_VOFF;
             }
         }
         float* As = lds + buf * TILE_FLOATS;
         float* Bs = As + BM * BK;
-        const int coff = cs * BK;
+        const int a_soff = cs * (BK * 4);         // bytes, block-uniform
+        const int b_soff = kstep * (BK * 4);
 #pragma unroll
-        for (int g = 0; g < GA; ++g) {
-            const float* src = a_ptr[g] ? a_ptr[g] + coff : zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(As + (wave * 32 + 8 * g) * BK), 16, 0, 0);
-        }
+        for (int g = 0; g < GA; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * 32 + 8 * g) * BK),
+                                                     16, (int)a_voff[g], a_soff, 0, 0);
 #pragma unroll
-        for (int g = 0; g < GB; ++g) {
-            const float* src = b_ptr[g] ? b_ptr[g] : zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK), 16, 0, 0);
-            if (b_ptr[g]) b_ptr[g] += BK;
-        }
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK),
+                                                     16, (int)b_voff[g], b_soff, 0, 0);
+        ++kstep;
         if (++cs == csteps) {
             cs = 0;
             if (++kx == a.KW) { kx = 0; ++ky; }
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
 
 }  // namespace
 
-static int g_conv_ablate = 0;
+static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
 extern "C" void amp_debug_set_conv_ablate(int mode) { g_conv_ablate = mode; }
 
 extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
@@ -466,22 +472,27 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
         if (ctx->prof_used < ctx->prof_pool.size()) {
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)d->Cin;
-            rec->variant = a.Cout > 64 ? 0 : 1;
+            rec->variant = (a.Cout > 64 && (a.Cin % BK != 0 || ntm * amp::cdiv(a.Cout, 128) >= 512)) ? 0 : 1;
             AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
         } else {
             ctx->prof_truncated = true;
         }
     }
-    const bool glds = (a.Cin % BK == 0) && g_conv_ablate == 0;   // every layer but the stem (Cin = 4)
+    const size_t x_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(float);
+    const size_t w_bytes = (size_t)a.Cout * a.K * sizeof(float);
+    // LDS-DMA kernel: every layer but the stem (Cin = 4); buffers must stay below the out-of-range marker (2 GiB)
+    const bool glds = (a.Cin % BK == 0) && g_conv_ablate == 0 && x_bytes < (size_t)OOB_VOFF && w_bytes < (size_t)OOB_VOFF;
     if (glds) {
-        if (a.Cout > 64) {
+        const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
+        // BN = 64 also for wide layers whose 128-wide grid would leave CUs idle (2 workgroups fit per CU)
+        if (a.Cout > 64 && nblk128 >= 512) {
             a.ntn = amp::cdiv(a.Cout, 128);
             a.nblk = ntm * a.ntn;
-            hipLaunchKernelGGL((conv_glds_kernel<128>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, ctx->zero_page);
+            hipLaunchKernelGGL((conv_glds_kernel<128>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else {
-            a.ntn = 1;
-            a.nblk = ntm;
-            hipLaunchKernelGGL((conv_glds_kernel<64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, ctx->zero_page);
+            a.ntn = amp::cdiv(a.Cout, 64);
+            a.nblk = ntm * a.ntn;
+            hipLaunchKernelGGL((conv_glds_kernel<64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes);
         }
     } else if (a.Cout > 64) {
         a.ntn = amp::cdiv(a.Cout, 128);

@@ -140,7 +140,7 @@ def main():
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<128,128> (fp32 MFMA implicit-GEMM conv)",
+            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                          "launches_per_step": prof["launches"][0] / args.steps,

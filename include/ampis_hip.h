@@ -56,7 +56,7 @@ int  amp_timer_stop(amp_ctx* ctx, float* ms_h);
 
 /* Live profile of the dominant kernel: between begin and end every amp_conv2d_nhwc launch on this context is bracketed
  * by a HIP-event pair on the context's stream; end waits for the stream and sums duration and algorithmic FLOPs
- * (2*M*Cout*KH*KW*Cin) per kernel variant: [0] = conv_mfma_kernel<128,128>, [1] = conv_mfma_kernel<128,64>. */
+ * (2*M*Cout*KH*KW*Cin) per tile variant: [0] = 128x128 tiles (conv_glds_kernel<128>), [1] = 128x64 tiles. */
 typedef struct amp_prof_summary {
     long long launches[2];
     double ms[2];
