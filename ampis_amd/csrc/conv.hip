@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr unsigned int OOB_VOFF = 0x80000000u;   // >= num_records of every buffer this kernel accepts (< 2 GiB)
 
-template <int BN>
+// STEM = true: the 7x7 stride-2 stem on the [B,H,W,4] input with weights [64][7][8][4]: a K-step is one kernel row ky, whose
+// 8 taps x 4 channels are 128 contiguous bytes; the 16-B chunk index IS the tap kx, so validity is per chunk.
+template <int BN, bool STEM = false>
 __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     }
     unsigned int a_voff[GA];              // byte offset of the input pixel of the current tap (+ swizzled chunk), or OOB
 
-    const int csteps = a.Cin / BK;        // K-steps per tap
+    const int csteps = STEM ? 1 : a.Cin / BK;   // K-steps per tap
+    const int kw_taps = STEM ? 1 : a.KW;        // STEM: the 8 taps of a row travel inside one K-step
     int ky = 0, kx = 0, cs = 0;           // block-uniform tap state of the tile being STAGED
     int kstep = 0;                        // index of the tile being staged
 
@@ -365,9 +368,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
         if (cs == 0) {                    // new tap: recompute the row offsets (uniform branch, once per Cin/32 steps)
 #pragma unroll
             for (int g = 0; g < GA; ++g) {
-                const int iy = a_iy0[g] + ky, ix = a_ix0[g] + kx;
+                const int iy = a_iy0[g] + ky;
+                const int ix = a_ix0[g] + (STEM ? (a_chunk[g] >> 2) : kx);
                 const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                a_voff[g] = v ? (unsigned int)(((a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g]) * 4) : OOB_VOFF;
+                const int off = STEM ? (a_pb[g] + iy * a.W + ix) * 4 : (a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g];
+                a_voff[g] = v ? (unsigned int)(off * 4) : OOB_VOFF;
             }
         }
         float* As = lds + buf * TILE_FLOATS;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
         ++kstep;
         if (++cs == csteps) {
             cs = 0;
-            if (++kx == a.KW) { kx = 0; ++ky; }
+            if (++kx == kw_taps) { kx = 0; ++ky; }
         }
     };
 
@@ -481,8 +486,14 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
     const size_t x_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(float);
     const size_t w_bytes = (size_t)a.Cout * a.K * sizeof(float);
     // LDS-DMA kernel: every layer but the stem (Cin = 4); buffers must stay below the out-of-range marker (2 GiB)
-    const bool glds = (a.Cin % BK == 0) && g_conv_ablate == 0 && x_bytes < (size_t)OOB_VOFF && w_bytes < (size_t)OOB_VOFF;
-    if (glds) {
+    const bool small = g_conv_ablate == 0 && x_bytes < (size_t)OOB_VOFF && w_bytes < (size_t)OOB_VOFF;
+    const bool glds = (a.Cin % BK == 0) && small;
+    const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
+    if (stem) {
+        a.ntn = 1;
+        a.nblk = ntm;
+        hipLaunchKernelGGL((conv_glds_kernel<64, true>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes);
+    } else if (glds) {
         const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
         // BN = 64 also for wide layers whose 128-wide grid would leave CUs idle (2 workgroups fit per CU)
         if (a.Cout > 64 && nblk128 >= 512) {

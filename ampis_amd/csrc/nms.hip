@@ -77,13 +77,19 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
     unsigned long long rem0 = 0ull, rem1 = 0ull;   // removed-bit words `lane` and `lane + 64`
     int nkept = 0;
     int* out = keep_idx + (size_t)b * max_keep;
+    // the diagonal word of the NEXT chunk does not depend on this chunk's decisions: keep its load in flight
+    unsigned long long diag_next = (lane < n) ? M[(size_t)lane * a.W] : 0ull;
     for (int c = 0; c < Wn && nkept < max_keep; ++c) {
         const unsigned long long rsel = (c < 64) ? rem0 : rem1;
         const unsigned int rlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel & 0xffffffffu), c & 63);
         const unsigned int rhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel >> 32), c & 63);
         const unsigned long long removed = ((unsigned long long)rhi << 32) | rlo;
         const int row = c * 64 + lane;
-        const unsigned long long diag = (row < n) ? M[(size_t)row * a.W + c] : 0ull;
+        const unsigned long long diag = diag_next;
+        {
+            const int nrow = row + 64;
+            diag_next = (c + 1 < Wn && nrow < n) ? M[(size_t)nrow * a.W + c + 1] : 0ull;
+        }
         const unsigned int dlo = (unsigned int)(diag & 0xffffffffu), dhi = (unsigned int)(diag >> 32);
         const int nb = min(64, n - c * 64);
         const unsigned long long valid = (nb == 64) ? ~0ull : ((1ull << nb) - 1ull);
@@ -110,12 +116,24 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         // OR the kept rows into the removed words of later chunks (lane owns words lane, lane + 64)
         unsigned long long kk = keep;
         const bool has0 = lane < Wn, has1 = lane + 64 < Wn;
-        while (kk != 0ull) {
-            const int bit = __builtin_ctzll(kk);
-            kk &= kk - 1ull;
-            const unsigned long long* r = M + (size_t)(c * 64 + bit) * a.W;
-            if (has0) rem0 |= r[lane];
-            if (has1) rem1 |= r[lane + 64];
+        while (kk != 0ull) {   // 4 independent row loads in flight per trip (the ORs are associative)
+            int bits[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bits[u] = kk ? __builtin_ctzll(kk) : -1;
+                if (kk) kk &= kk - 1ull;
+            }
+            unsigned long long v0[4] = {0ull, 0ull, 0ull, 0ull}, v1[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (bits[u] >= 0) {
+                    const unsigned long long* r = M + (size_t)(c * 64 + bits[u]) * a.W;
+                    if (has0) v0[u] = r[lane];
+                    if (has1) v1[u] = r[lane + 64];
+                }
+            }
+            rem0 |= (v0[0] | v0[1]) | (v0[2] | v0[3]);
+            rem1 |= (v1[0] | v1[1]) | (v1[2] | v1[3]);
         }
     }
     if (lane == 0) keep_count[b] = min(nkept, max_keep);
