@@ -126,6 +126,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
+            traffic = pmc["kernels"]["conv_glds_kernel<128>"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         ms_per_step = elapsed / args.steps * 1e3
         value = world * BATCH * args.steps / elapsed
         ach = prof["flops"][0] / (prof["ms"][0] * 1e-3) / 1e12 if prof["ms"][0] > 0 else 0.0
@@ -142,7 +148,8 @@ def main():
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
