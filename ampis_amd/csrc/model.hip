@@ -484,7 +484,7 @@ int amp_model_cfg_default(amp_model_cfg* c) {
 int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     AMP_REQUIRE(ctx && cfg && out, "amp_model_create: null argument");
     AMP_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 255, "amp_model_create: num_classes out of range");
-    AMP_REQUIRE(cfg->pre_nms_topk >= 1 && cfg->pre_nms_topk <= 1638, "amp_model_create: pre_nms_topk must be in [1,1638] (5 levels <= 8192 candidates)");
+    AMP_REQUIRE(cfg->pre_nms_topk >= 1 && cfg->pre_nms_topk <= 2048, "amp_model_create: pre_nms_topk must be in [1,2048]");
     AMP_REQUIRE(cfg->post_nms_topk >= 1 && cfg->detections_per_image >= 1, "amp_model_create: bad topk");
     AMP_REQUIRE(cfg->max_batch >= 1 && cfg->max_h >= 32 && cfg->max_w >= 32, "amp_model_create: bad capacity");
     amp_model* m = new amp_model();

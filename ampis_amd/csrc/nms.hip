@@ -5,8 +5,8 @@
 //   nms_mask_kernel : 64x64 tiles of the upper-triangular suppression matrix; lane i of a wave owns box i of the row tile
 //                     and builds one 64-bit word (bit j = "i suppresses j", j > i) against the 64 boxes of the column tile
 //                     staged in LDS.  IoU arithmetic in torchvision's op order, fp32, no contraction -> bit-exact vs the oracle.
-//   nms_scan_kernel : ONE wavefront per image walks the rows in score order.  The `removed` bitmask (<= 128 words) lives in
-//                     two registers per lane; per 64-box chunk the wave resolves intra-chunk suppression with a scalar loop
+//   nms_scan_kernel : ONE wavefront per image walks the rows in score order.  The `removed` bitmask (<= 256 words) lives in
+//                     up to four registers per lane; per 64-box chunk the wave resolves intra-chunk suppression with a scalar loop
 //                     over set bits (v_readlane of the diagonal words), then every lane ORs the kept rows' words of its own
 //                     column(s).  Exits as soon as max_keep boxes are kept (later rows cannot change earlier decisions).
 #include "common.h"
@@ -72,15 +72,15 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const int n = min(a.counts[b], a.cap);
-    const int Wn = (n + 63) >> 6;   // words in use (<= a.W <= 128)
+    const int Wn = (n + 63) >> 6;   // words in use (<= a.W <= 256)
     const unsigned long long* M = a.mask + (size_t)b * a.cap * a.W;
-    unsigned long long rem0 = 0ull, rem1 = 0ull;   // removed-bit words `lane` and `lane + 64`
+    unsigned long long rem[4] = {0ull, 0ull, 0ull, 0ull};   // removed-bit words lane, lane+64, lane+128, lane+192
     int nkept = 0;
     int* out = keep_idx + (size_t)b * max_keep;
     // the diagonal word of the NEXT chunk does not depend on this chunk's decisions: keep its load in flight
     unsigned long long diag_next = (lane < n) ? M[(size_t)lane * a.W] : 0ull;
     for (int c = 0; c < Wn && nkept < max_keep; ++c) {
-        const unsigned long long rsel = (c < 64) ? rem0 : rem1;
+        const unsigned long long rsel = (c < 64) ? rem[0] : (c < 128) ? rem[1] : (c < 192) ? rem[2] : rem[3];
         const unsigned int rlo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel & 0xffffffffu), c & 63);
         const unsigned int rhi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(rsel >> 32), c & 63);
         const unsigned long long removed = ((unsigned long long)rhi << 32) | rlo;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         if (nkept >= max_keep) break;
         // OR the kept rows into the removed words of later chunks (lane owns words lane, lane + 64)
         unsigned long long kk = keep;
-        const bool has0 = lane < Wn, has1 = lane + 64 < Wn;
+        const int nw = (Wn + 63) >> 6;   // 64-word groups in use (wave-uniform)
         while (kk != 0ull) {   // 4 independent row loads in flight per trip (the ORs are associative)
             int bits[4];
 #pragma unroll
@@ -123,17 +123,16 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
                 bits[u] = kk ? __builtin_ctzll(kk) : -1;
                 if (kk) kk &= kk - 1ull;
             }
-            unsigned long long v0[4] = {0ull, 0ull, 0ull, 0ull}, v1[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (bits[u] >= 0) {
-                    const unsigned long long* r = M + (size_t)(c * 64 + bits[u]) * a.W;
-                    if (has0) v0[u] = r[lane];
-                    if (has1) v1[u] = r[lane + 64];
-                }
+            for (int wgrp = 0; wgrp < 4; ++wgrp) {
+                if (wgrp >= nw) break;
+                const int word = lane + 64 * wgrp;
+                unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (bits[u] >= 0 && word < Wn) v[u] = M[(size_t)(c * 64 + bits[u]) * a.W + word];
+                rem[wgrp] |= (v[0] | v[1]) | (v[2] | v[3]);
             }
-            rem0 |= (v0[0] | v0[1]) | (v0[2] | v0[3]);
-            rem1 |= (v1[0] | v1[1]) | (v1[2] | v1[3]);
         }
     }
     if (lane == 0) keep_count[b] = min(nkept, max_keep);
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
 extern "C" int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const int* cats, const int* counts, float thresh,
                        int max_keep, unsigned long long* mask_scratch, int* keep_idx, int* keep_count) {
     AMP_REQUIRE(ctx && boxes && cats && counts && mask_scratch && keep_idx && keep_count, "amp_nms: null argument");
-    AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 8192 && max_keep >= 1, "amp_nms: cap=%d must be in [1,8192]", cap);
+    AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 16384 && max_keep >= 1, "amp_nms: cap=%d must be in [1,16384]", cap);
     NmsArgs a;
     a.boxes = boxes; a.cats = cats; a.counts = counts; a.mask = mask_scratch;
     a.cap = cap; a.W = amp::cdiv(cap, 64); a.thresh = thresh;

@@ -8,7 +8,7 @@
 //
 // Kernel 1 is a radix select (4 x 8-bit digits on the order-preserving uint32 image of the logit) done by one 1024-thread
 // workgroup per segment with LDS histograms, then a wave-ballot compaction in index order and an LDS bitonic sort of the
-// <= 2048 survivors.  Kernel 3 is an LDS bitonic sort of 64-bit (key, ~position) words, <= 8192 per image.
+// <= 2048 survivors.  Kernel 3 is an LDS bitonic sort of 64-bit (key, ~position) words, <= 16384 per image.
 #include "common.h"
 
 namespace {
@@ -314,7 +314,7 @@ int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const i
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
                     float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out) {
     AMP_REQUIRE(ctx && sortkey && boxes_in && boxes_out && score_out && cat_out && count_out, "amp_sort_gather: null argument");
-    AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 8192, "amp_sort_gather: cap=%d out of range [1,8192]", cap);
+    AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 16384, "amp_sort_gather: cap=%d out of range [1,16384]", cap);
     int N = 64;
     while (N < cap) N <<= 1;
     const size_t smem = (size_t)N * 8 + 16;

@@ -108,12 +108,12 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
 /* decode + clip the selected anchors; sortkey = 0 for non-finite / empty boxes. boxes [B,cap,4], sortkey [B,cap]. */
 int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
                    const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey);
-/* per image: order `cap` (<= 8192) 64-bit sort words descending; gather boxes_in[b][pos] (box_stride entries per image);
+/* per image: order `cap` (<= 16384) 64-bit sort words descending; gather boxes_in[b][pos] (box_stride entries per image);
  * outputs sorted boxes/scores/categories [B,cap], the number of valid entries [B], optionally the source positions. */
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
                     float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out);
 
-/* Stages a12 / a15: batched greedy NMS on score-sorted boxes (cap <= 8192 per image) ---------- */
+/* Stages a12 / a15: batched greedy NMS on score-sorted boxes (cap <= 16384 per image) ---------- */
 /* mask_scratch: [B*cap*ceil(cap/64)] u64. keep_idx [B,max_keep] (positions, ascending), keep_count [B]. */
 int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const int* cats, const int* counts, float thresh,
             int max_keep, unsigned long long* mask_scratch, int* keep_idx, int* keep_count);

@@ -72,17 +72,17 @@ def test_rpn_decode_and_sort(gpu_ctx):
         assert np.abs(sb[b, :n].cpu().numpy() - rb).max() < 1e-4     # expf: <= a few ulp of the box size
 
 
-@pytest.mark.parametrize("n,ncat,thresh", [(700, 3, 0.5), (3000, 5, 0.7), (64, 1, 0.3), (1, 1, 0.5), (0, 1, 0.5)])
+@pytest.mark.parametrize("n,ncat,thresh", [(700, 3, 0.5), (3000, 5, 0.7), (64, 1, 0.3), (1, 1, 0.5), (0, 1, 0.5), (10000, 5, 0.6)])
 def test_nms_exact(gpu_ctx, n, ncat, thresh):
     from ampis_amd import ops
     from oracle import maskrcnn as O
     rng = np.random.default_rng(n + 7)
-    B, cap = 2, 3072
+    B, cap = 2, (3072 if n <= 3072 else 10240)
     boxes = np.zeros((B, cap, 4), np.float32)
     cats = np.full((B, cap), -1, np.int32)
     ns = [n, max(n - 5, 0)]
     for b in range(B):
-        c = rng.uniform(0, 300, (ns[b], 2))
+        c = rng.uniform(0, 300 if n <= 3072 else 1000, (ns[b], 2))
         s = rng.uniform(4, 80, (ns[b], 2))
         boxes[b, :ns[b]] = np.concatenate([c - s / 2, c + s / 2], 1)
         cats[b, :ns[b]] = rng.integers(0, ncat, ns[b])
