@@ -34,7 +34,16 @@ class ModelCfg(C.Structure):
                 ("score_thresh", C.c_float), ("nms_thresh", C.c_float), ("detections_per_image", C.c_int),
                 ("bbox_reg_weights", C.c_float * 4), ("mask_threshold", C.c_float),
                 ("max_batch", C.c_int), ("max_h", C.c_int), ("max_w", C.c_int), ("max_out_hw", C.c_int),
-                ("rle_pool_counts", C.c_size_t)]
+                ("rle_pool_counts", C.c_size_t),
+                ("train_enable", C.c_int), ("pre_nms_topk_train", C.c_int), ("post_nms_topk_train", C.c_int),
+                ("rpn_batch", C.c_int), ("rpn_pos_frac", C.c_float), ("rpn_iou_lo", C.c_float), ("rpn_iou_hi", C.c_float),
+                ("roi_batch", C.c_int), ("roi_fg_frac", C.c_float), ("roi_iou", C.c_float),
+                ("max_gt", C.c_int), ("max_poly_doubles", C.c_int)]
+
+
+class Gt(C.Structure):
+    _fields_ = [("B", C.c_int), ("gt_off", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
+                ("classes", C.POINTER(C.c_int)), ("poly_off", C.POINTER(C.c_int)), ("poly_xy", C.POINTER(C.c_double))]
 
 
 class ProfSummary(C.Structure):
@@ -89,12 +98,12 @@ def _declare(L):
         "amp_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),
         "amp_subsample2": ([vp, vp, i, i, i, i, vp], i),
         "amp_rpn_topk": ([vp, C.POINTER(RpnLevels), i, i, vp, i, vp, vp, vp], i),
-        "amp_rpn_decode": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, i, vp, vp], i),
-        "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_rpn_decode": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, i, vp, vp, vp], i),
+        "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_nms": ([vp, i, i, vp, vp, vp, f, i, vp, vp, vp], i),
         "amp_roi_align": ([vp, C.POINTER(FpnFeats), vp, vp, vp, i, i, vp, vp], i),
         "amp_box_candidates": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, i, vp, vp], i),
-        "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_mask_prob": ([vp, vp, vp, i, i, vp], i),
         "amp_paste_rle": ([vp, vp, vp, vp, i, vp, vp, i, i, i, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp], i),
         "amp_rle_to_string": ([vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)], i),
@@ -113,6 +122,12 @@ def _declare(L):
         "amp_model_load_tensor": ([vp, C.c_char_p, vp, C.POINTER(C.c_longlong), i], i),
         "amp_model_finalize": ([vp], i),
         "amp_model_infer": ([vp, vp, i, i, i, i, vp, vp, C.POINTER(Dets)], i),
+        "amp_model_forward_losses": ([vp, vp, i, i, i, i, C.POINTER(Gt), C.c_uint, C.POINTER(f)], i),
+        "amp_anchor_labels": ([vp, C.POINTER(RpnLevels), i, vp, vp, i, f, f, vp, vp, vp, vp], i),
+        "amp_rpn_sample_loss": ([vp, C.POINTER(RpnLevels), vp, i, vp, vp, vp, vp, vp, i, f, C.c_uint, vp, vp, vp], i),
+        "amp_roi_sample": ([vp, i, vp, vp, i, vp, vp, vp, i, i, f, f, C.c_uint, vp, vp, vp, i, vp, vp, vp, vp, vp, i], i),
+        "amp_box_loss": ([vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, C.POINTER(f), i, vp], i),
+        "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_model_get_tap": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_longlong)], i),
     }
     for name, (args, res) in sig.items():

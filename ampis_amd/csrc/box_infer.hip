@@ -62,23 +62,25 @@ __global__ void box_candidates_kernel(const CandArgs a) {
 
 __global__ void gather_dets_kernel(int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
                                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores,
-                                   int* det_classes) {
+                                   int* det_classes, const int* payload_in, int* payload_out) {
     const int total = B * D;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int b = t / D, i = t - b * D;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s = 0.f;
-        int c = -1;
+        int c = -1, pl = -1;
         if (i < keep_count[b]) {
             const int src = keep_idx[(size_t)b * D + i];
             const float* p = sboxes + ((size_t)b * cap + src) * 4;
             x1 = p[0]; y1 = p[1]; x2 = p[2]; y2 = p[3];
             s = sscores[(size_t)b * cap + src];
             c = scats[(size_t)b * cap + src];
+            if (payload_in) pl = payload_in[(size_t)b * cap + src];
         }
         float* o = det_boxes + (size_t)t * 4;
         o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
         det_scores[t] = s;
         det_classes[t] = c;
+        if (payload_out) payload_out[t] = pl;
     }
 }
 
@@ -108,11 +110,12 @@ int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* pro
 }
 
 int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
-                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes) {
+                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes,
+                    const int* payload_in, int* payload_out) {
     AMP_REQUIRE(ctx && sboxes && sscores && scats && keep_idx && keep_count && det_boxes && det_scores && det_classes,
                 "amp_gather_dets: null argument");
     hipLaunchKernelGGL(gather_dets_kernel, dim3(amp::cdiv(B * D, 256)), dim3(256), 0, ctx->stream, B, cap, D, sboxes,
-                       sscores, scats, keep_idx, keep_count, det_boxes, det_scores, det_classes);
+                       sscores, scats, keep_idx, keep_count, det_boxes, det_scores, det_classes, payload_in, payload_out);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -162,15 +162,22 @@ void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_li
     if (!var) { amp::set_error("amp_model: workspace exhausted allocating %s (%zu bytes, cap %zu)", #var, \
                                (size_t)(n) * sizeof(T), ws.cap); return AMP_ERR_NOMEM; }
 
-// The whole forward. With ws.dry == true nothing is launched: only the workspace peak is measured.
-int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out_h, const int* out_w) {
+struct Trunk {
+    float* feat[5];
+    int fh[5], fw[5];
+    amp_rpn_levels lv;
+    amp_fpn_feats ff;
+    int max_n;
+};
+
+// Shared by inference and training: preprocess -> ResNet-50 -> FPN -> RPN head. With ws.dry nothing is launched.
+int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T) {
     Bump& ws = m->ws;
     const bool dry = ws.dry;
     const amp_model_cfg& c = m->cfg;
     amp_ctx* ctx = m->ctx;
     ws.off = 0;
     if (!dry) m->taps.clear();
-    const int K = c.num_classes;
     const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
     auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
 
@@ -272,10 +279,32 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         }
     }
 
-    // ---------------- proposals ----------------
-    const int k = c.pre_nms_topk;
+    for (int l = 0; l < 5; ++l) { T.feat[l] = feat[l]; T.fh[l] = fh[l]; T.fw[l] = fw[l]; }
+    T.lv = lv;
+    T.max_n = max_n;
+    memset(&T.ff, 0, sizeof(T.ff));
+    T.ff.C = 256;
+    for (int l = 0; l < 4; ++l) { T.ff.feat[l] = feat[l]; T.ff.h[l] = fh[l]; T.ff.w[l] = fw[l]; T.ff.stride[l] = fstride[l]; }
+    return AMP_OK;
+}
+
+struct Proposals {
+    float* boxes;    // [B][Rcap][4]
+    float* logits;   // [B][Rcap]
+    int* count;      // [B]
+    int* anchor;     // [B][Rcap] global anchor index each proposal was decoded from
+    int Rcap;
+};
+
+// find_top_rpn_proposals: per-level top-k, decode, sort, NMS, first post_nms_topk.
+int run_proposals(amp_model* m, const Trunk& T, int B, int H, int W, int k, int Rcap, Proposals& P) {
+    Bump& ws = m->ws;
+    const bool dry = ws.dry;
+    const amp_model_cfg& c = m->cfg;
+    amp_ctx* ctx = m->ctx;
+    const amp_rpn_levels& lv = T.lv;
+    const int max_n = T.max_n;
     const int cap = 5 * k;                 // candidates per image
-    const int Rcap = c.post_nms_topk;
     AMP_ALLOC(keys_scratch, uint32_t, (size_t)B * 5 * max_n);
     AMP_ALLOC(sel_idx, int, (size_t)B * 5 * k);
     AMP_ALLOC(sel_logit, float, (size_t)B * 5 * k);
@@ -292,12 +321,15 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(prop_boxes, float, (size_t)B * Rcap * 4);
     AMP_ALLOC(prop_logits, float, (size_t)B * Rcap);
     AMP_ALLOC(prop_lvl, int, (size_t)B * Rcap);
+    AMP_ALLOC(cand_anchor, int, (size_t)B * cap);
+    AMP_ALLOC(s_anchor, int, (size_t)B * cap);
+    AMP_ALLOC(prop_anchor, int, (size_t)B * Rcap);
     if (!dry) {
         AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
-        AMP_TRY(amp_rpn_decode(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, cap, cand_boxes, cand_keys));
-        AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr));
+        AMP_TRY(amp_rpn_decode(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, cap, cand_boxes, cand_keys, cand_anchor));
+        AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr, cand_anchor, s_anchor));
         AMP_TRY(amp_nms(ctx, B, cap, s_boxes, s_cats, s_count, c.rpn_nms_thresh, Rcap, nms_mask, keep_idx, prop_count));
-        AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl));
+        AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl, s_anchor, prop_anchor));
         tap(m, "rpn_sel_idx", sel_idx, 1, {B, 5, k});
         tap(m, "rpn_sel_logit", sel_logit, 0, {B, 5, k});
         tap(m, "rpn_cand_sorted_boxes", s_boxes, 0, {B, cap, 4});
@@ -308,12 +340,28 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         tap(m, "prop_logits", prop_logits, 0, {B, Rcap});
         tap(m, "prop_count", prop_count, 1, {B});
     }
+    P.boxes = prop_boxes; P.logits = prop_logits; P.count = prop_count; P.anchor = prop_anchor; P.Rcap = Rcap;
+    return AMP_OK;
+}
+
+// The whole inference forward. With ws.dry == true nothing is launched: only the workspace peak is measured.
+int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out_h, const int* out_w) {
+    Bump& ws = m->ws;
+    const bool dry = ws.dry;
+    const amp_model_cfg& c = m->cfg;
+    amp_ctx* ctx = m->ctx;
+    const int K = c.num_classes;
+    auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
+    Trunk T;
+    AMP_TRY(run_trunk(m, imgs_d, B, H, W, T));
+    Proposals PR;
+    AMP_TRY(run_proposals(m, T, B, H, W, c.pre_nms_topk, c.post_nms_topk, PR));
+    float* prop_boxes = PR.boxes;
+    int* prop_count = PR.count;
+    const int Rcap = PR.Rcap;
+    const amp_fpn_feats& ff = T.ff;
 
     // ---------------- box head ----------------
-    amp_fpn_feats ff;
-    memset(&ff, 0, sizeof(ff));
-    ff.C = 256;
-    for (int l = 0; l < 4; ++l) { ff.feat[l] = feat[l]; ff.h[l] = fh[l]; ff.w[l] = fw[l]; ff.stride[l] = fstride[l]; }
     const int R = B * Rcap;
     const int ld_box = 5 * K + 1;
     AMP_ALLOC(pooled, float, (size_t)R * 49 * 256);
@@ -342,9 +390,9 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
         AMP_TRY(amp_box_candidates(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
                                    H, W, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
-        AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr));
+        AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
         AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
-        AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes));
+        AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr));
         tap(m, "box_pooled", pooled, 0, {R, 7, 7, 256});
         tap(m, "box_pred", box_pred, 0, {R, ld_box});
         tap(m, "det_boxes", det_boxes, 0, {B, D, 4});
@@ -462,6 +510,161 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     return AMP_OK;
 }
 
+// Training-mode forward + losses. With ws.dry nothing is launched (workspace sizing only).
+int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const amp_gt* gt, unsigned int seed, float losses[5]) {
+    Bump& ws = m->ws;
+    const bool dry = ws.dry;
+    const amp_model_cfg& c = m->cfg;
+    amp_ctx* ctx = m->ctx;
+    const int K = c.num_classes;
+    auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
+    Trunk T;
+    AMP_TRY(run_trunk(m, imgs_d, B, H, W, T));
+    const int total_gt = dry ? c.max_gt : gt->gt_off[B];
+    const int npoly = dry ? c.max_poly_doubles : gt->poly_off[total_gt];
+    AMP_REQUIRE(total_gt <= c.max_gt && npoly <= c.max_poly_doubles, "amp_model_forward_losses: %d instances / %d polygon doubles exceed cfg.max_gt / max_poly_doubles", total_gt, npoly);
+    int A = 0;
+    for (int l = 0; l < 5; ++l) A += T.fh[l] * T.fw[l] * 3;
+
+    AMP_ALLOC(d_gt_boxes, float, (size_t)std::max(total_gt, 1) * 4);
+    AMP_ALLOC(d_gt_cls, int, (size_t)std::max(total_gt, 1));
+    AMP_ALLOC(d_gt_off, int, (size_t)B + 1);
+    AMP_ALLOC(d_poly_off, int, (size_t)total_gt + 1);
+    AMP_ALLOC(d_poly_xy, double, (size_t)std::max(npoly, 1));
+    AMP_ALLOC(match_val, float, (size_t)B * A);
+    AMP_ALLOC(match_idx, int, (size_t)B * A);
+    AMP_ALLOC(gt_best, unsigned int, (size_t)std::max(total_gt, 1));
+    AMP_ALLOC(label, signed char, (size_t)B * A);
+    AMP_ALLOC(keys, uint32_t, (size_t)B * A);
+    AMP_ALLOC(rpn_sampled, int, (size_t)B * c.rpn_batch);
+    AMP_ALLOC(rpn_counts, int, (size_t)B * 2);
+    AMP_ALLOC(rpn_partial, float, (size_t)B * 2);
+    if (!dry) {
+        AMP_HIP_CHECK(hipMemcpyAsync(d_gt_off, gt->gt_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(d_poly_off, gt->poly_off, (size_t)(total_gt + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (total_gt) {
+            AMP_HIP_CHECK(hipMemcpyAsync(d_gt_boxes, gt->boxes, (size_t)total_gt * 16, hipMemcpyHostToDevice, ctx->stream));
+            AMP_HIP_CHECK(hipMemcpyAsync(d_gt_cls, gt->classes, (size_t)total_gt * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (npoly) AMP_HIP_CHECK(hipMemcpyAsync(d_poly_xy, gt->poly_xy, (size_t)npoly * 8, hipMemcpyHostToDevice, ctx->stream));
+        AMP_TRY(amp_anchor_labels(ctx, &T.lv, B, d_gt_boxes, d_gt_off, total_gt, c.rpn_iou_lo, c.rpn_iou_hi, match_val, match_idx, gt_best, label));
+        AMP_TRY(amp_rpn_sample_loss(ctx, &T.lv, nullptr, B, d_gt_boxes, d_gt_off, label, match_idx, keys, c.rpn_batch, c.rpn_pos_frac, seed,
+                                    rpn_sampled, rpn_counts, rpn_partial));
+        tap(m, "rpn_label", label, 3, {B, A});
+        tap(m, "rpn_match_idx", match_idx, 1, {B, A});
+        tap(m, "rpn_sampled", rpn_sampled, 1, {B, c.rpn_batch});
+        tap(m, "rpn_counts", rpn_counts, 1, {B, 2});
+    }
+    // proposals (training top-k), GT appended, matched and sampled
+    Proposals PR;
+    AMP_TRY(run_proposals(m, T, B, H, W, c.pre_nms_topk_train, c.post_nms_topk_train, PR));
+    const int RB = c.roi_batch;
+    const int ncap = c.post_nms_topk_train + c.max_gt;
+    AMP_ALLOC(rkeys, uint32_t, (size_t)B * ncap);
+    AMP_ALLOC(rcls_s, int, (size_t)B * ncap);
+    AMP_ALLOC(rgti_s, int, (size_t)B * ncap);
+    AMP_ALLOC(rois, float, (size_t)B * RB * 4);
+    AMP_ALLOC(roi_cls, int, (size_t)B * RB);
+    AMP_ALLOC(roi_gti, int, (size_t)B * RB);
+    AMP_ALLOC(roi_counts, int, (size_t)B * 2);
+    const int R = B * RB;
+    const int ld_box = 5 * K + 1;
+    AMP_ALLOC(roi_batch_idx, int, (size_t)R);
+    AMP_ALLOC(pooled, float, (size_t)R * 49 * 256);
+    AMP_ALLOC(fc1, float, (size_t)R * 1024);
+    AMP_ALLOC(fc2, float, (size_t)R * 1024);
+    AMP_ALLOC(box_pred, float, (size_t)R * ld_box);
+    AMP_ALLOC(box_partial, float, (size_t)B * 2);
+    std::vector<int> h_counts(2 * B, 0), h_cls, h_gti;
+    if (!dry) {
+        AMP_TRY(amp_roi_sample(ctx, B, PR.boxes, PR.count, PR.Rcap, d_gt_boxes, d_gt_cls, d_gt_off, K, RB, c.roi_fg_frac, c.roi_iou, seed, rkeys,
+                               rcls_s, rgti_s, ncap, rois, roi_cls, roi_gti, roi_counts, PR.anchor, A));
+        std::vector<int> iota(R);
+        for (int i = 0; i < R; ++i) iota[i] = i / RB;
+        AMP_HIP_CHECK(hipMemcpyAsync(roi_batch_idx, iota.data(), (size_t)R * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // iota is a temporary
+        AMP_TRY(amp_roi_align(ctx, &T.ff, rois, roi_batch_idx, nullptr, R, 7, pooled, nullptr));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
+        // counts decide the normalisers and the mask-branch sizes
+        h_cls.resize(R); h_gti.resize(R);
+        AMP_HIP_CHECK(hipMemcpyAsync(h_counts.data(), roi_counts, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(h_cls.data(), roi_cls, (size_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(h_gti.data(), roi_gti, (size_t)R * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        tap(m, "train_rois", rois, 0, {B, RB, 4});
+        tap(m, "train_roi_cls", roi_cls, 1, {B, RB});
+        tap(m, "train_roi_gti", roi_gti, 1, {B, RB});
+        tap(m, "train_roi_counts", roi_counts, 1, {B, 2});
+        tap(m, "train_box_pred", box_pred, 0, {R, ld_box});
+    }
+    int total_rois = 0, N = dry ? B * (int)(RB * c.roi_fg_frac) : 0;
+    std::vector<int> fg_off(B + 1, 0);
+    if (!dry) {
+        for (int b = 0; b < B; ++b) { total_rois += h_counts[2 * b] + h_counts[2 * b + 1]; fg_off[b + 1] = fg_off[b] + h_counts[2 * b]; }
+        N = fg_off[B];
+        AMP_TRY(amp_box_loss(ctx, B, RB, K, box_pred, ld_box, nullptr, rois, roi_cls, roi_gti, d_gt_boxes, d_gt_off, c.bbox_reg_weights, total_rois,
+                             box_partial));
+    }
+    // mask branch on the foreground RoIs (the first nfg of every image's sample)
+    const int Nc = std::max(N, 1);
+    AMP_ALLOC(m_rois, float, (size_t)Nc * 4);
+    AMP_ALLOC(m_batch, int, (size_t)Nc);
+    AMP_ALLOC(m_cls, int, (size_t)Nc);
+    AMP_ALLOC(m_poly, int, (size_t)Nc);
+    AMP_ALLOC(mpooled, float, (size_t)Nc * 196 * 256);
+    AMP_ALLOC(mt_a, float, (size_t)Nc * 196 * 256);
+    AMP_ALLOC(mt_b, float, (size_t)Nc * 784 * 256);
+    AMP_ALLOC(mlogits, float, (size_t)Nc * 784 * K);
+    AMP_ALLOC(m_partial, float, (size_t)Nc);
+    AMP_ALLOC(m_targets, unsigned char, (size_t)Nc * 784);
+    if (dry) return AMP_OK;
+    std::vector<float> h_mpart(N);
+    if (N > 0) {
+        std::vector<int> hb(N), hc(N), hp(N);
+        for (int b = 0; b < B; ++b) {
+            const int nb = fg_off[b + 1] - fg_off[b];
+            if (!nb) continue;
+            AMP_HIP_CHECK(hipMemcpyAsync(m_rois + (size_t)fg_off[b] * 4, rois + (size_t)b * RB * 4, (size_t)nb * 16, hipMemcpyDeviceToDevice, ctx->stream));
+            for (int i = 0; i < nb; ++i) {
+                hb[fg_off[b] + i] = b;
+                hc[fg_off[b] + i] = h_cls[b * RB + i];
+                hp[fg_off[b] + i] = gt->gt_off[b] + h_gti[b * RB + i];
+            }
+        }
+        AMP_HIP_CHECK(hipMemcpyAsync(m_batch, hb.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(m_cls, hc.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(m_poly, hp.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // hb/hc/hp are temporaries
+        AMP_TRY(amp_roi_align(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
+        AMP_TRY(amp_mask_target_loss(ctx, N, K, mlogits, nullptr, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
+        AMP_HIP_CHECK(hipMemcpyAsync(h_mpart.data(), m_partial, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        tap(m, "train_mask_targets", m_targets, 4, {N, 28, 28});
+        tap(m, "train_mask_logits", mlogits, 0, {N, 28, 28, K});
+    }
+    std::vector<float> h_rpn(2 * B), h_box(2 * B);
+    AMP_HIP_CHECK(hipMemcpyAsync(h_rpn.data(), rpn_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AMP_HIP_CHECK(hipMemcpyAsync(h_box.data(), box_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    float s_bce = 0.f, s_loc = 0.f, s_ce = 0.f, s_l1 = 0.f, s_mask = 0.f;
+    for (int b = 0; b < B; ++b) { s_bce += h_rpn[2 * b]; s_loc += h_rpn[2 * b + 1]; s_ce += h_box[2 * b]; s_l1 += h_box[2 * b + 1]; }
+    for (int i = 0; i < N; ++i) s_mask += h_mpart[i];
+    const float rpn_norm = (float)(c.rpn_batch * B);
+    losses[0] = total_rois ? s_ce / (float)total_rois : 0.f;
+    losses[1] = s_l1 / (float)std::max(total_rois, 1);
+    losses[2] = N ? s_mask / ((float)N * 784.f) : 0.f;
+    losses[3] = s_bce / rpn_norm;
+    losses[4] = s_loc / rpn_norm;
+    return AMP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -478,6 +681,11 @@ int amp_model_cfg_default(amp_model_cfg* c) {
     c->mask_threshold = 0.5f;
     c->max_batch = 1; c->max_h = 1344; c->max_w = 1344; c->max_out_hw = 4096;
     c->rle_pool_counts = 0;
+    c->train_enable = 0;
+    c->pre_nms_topk_train = 2000; c->post_nms_topk_train = 1000;
+    c->rpn_batch = 256; c->rpn_pos_frac = 0.5f; c->rpn_iou_lo = 0.3f; c->rpn_iou_hi = 0.7f;
+    c->roi_batch = 512; c->roi_fg_frac = 0.25f; c->roi_iou = 0.5f;
+    c->max_gt = 16384; c->max_poly_doubles = 16384 * 80;
     return AMP_OK;
 }
 
@@ -505,6 +713,10 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     m->ws.dry = true;
     std::vector<int> oh(cfg->max_batch, cfg->max_out_hw), ow(cfg->max_batch, cfg->max_out_hw);
     int st = run(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, oh.data(), ow.data());
+    if (st == AMP_OK && cfg->train_enable) {
+        float dummy[5];
+        st = run_train(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, nullptr, 0, dummy);
+    }
     if (st != AMP_OK) { (void)hipFree(m->parena); delete m; return st; }
     m->ws.dry = false;
     m->ws.cap = m->ws.peak + (1 << 20);
@@ -722,6 +934,27 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
     out->out_h = m->r_out_h.data();
     out->out_w = m->r_out_w.data();
     return AMP_OK;
+}
+
+int amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                             unsigned int seed, float losses_h[5]) {
+    AMP_REQUIRE(m && imgs_bgr && gt && losses_h, "amp_model_forward_losses: null argument");
+    AMP_REQUIRE(m->finalized, "amp_model_forward_losses: call amp_model_finalize after loading every tensor");
+    AMP_REQUIRE(m->cfg.train_enable, "amp_model_forward_losses: the model was created with cfg.train_enable = 0");
+    AMP_REQUIRE(gt->B == B && gt->gt_off && gt->boxes && gt->classes && gt->poly_off && gt->poly_xy, "amp_model_forward_losses: incomplete ground truth");
+    const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+    AMP_REQUIRE(B >= 1 && B <= m->cfg.max_batch && Hp <= m->cfg.max_h && Wp <= m->cfg.max_w, "amp_model_forward_losses: batch exceeds the model capacity");
+    AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
+    const uint8_t* imgs_d = imgs_bgr;
+    uint8_t* staged = nullptr;
+    if (imgs_on_host) {
+        AMP_HIP_CHECK(hipMalloc(&staged, (size_t)B * H * W * 3));
+        AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
+        imgs_d = staged;
+    }
+    const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h);
+    if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
+    return st;
 }
 
 int amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]) {

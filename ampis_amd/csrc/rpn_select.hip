@@ -14,7 +14,6 @@
 namespace {
 
 constexpr int TOPK_THREADS = 1024;
-constexpr int MAX_K = 2048;
 constexpr int MAX_LEVELS = 5;
 
 using amp::f2ord;
@@ -31,128 +30,30 @@ struct TopkArgs {
     int* sel_count;                  // [B][nlevels]
 };
 
-// In-LDS bitonic sort, descending, of N (power of two) 64-bit words by all threads of the block.
-template <int NT>
-__device__ void bitonic_desc(unsigned long long* s, int N) {
-    for (int size = 2; size <= N; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = threadIdx.x; t < (N >> 1); t += NT) {
-                const int lo = (t / stride) * (stride << 1) + (t % stride);
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = s[lo], b = s[hi];
-                if ((a < b) == desc) { s[lo] = b; s[hi] = a; }
-            }
-        }
-    }
-    __syncthreads();
-}
+}  // namespace
+#include "select.h"
+namespace {
 
 __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int s_prefix, s_remaining;
-    __shared__ unsigned int wave_gt[16], wave_eq[16];
-    __shared__ unsigned long long sorted[MAX_K];
-
+    __shared__ amp::SelectSmem sm;
     const int seg = blockIdx.x;
     const int b = seg / a.nlevels, lvl = seg % a.nlevels;
     const int n = a.hw[lvl] * a.A;
-    const int k = min(a.k, n);
     const float* pred = a.pred[lvl] + (size_t)b * a.hw[lvl] * a.ld;
     uint32_t* keys = a.keys_scratch + (size_t)seg * a.max_n;
-    const int tid = threadIdx.x;
-
-    // pass 0: strided gather of the logits -> compact ordered keys, histogram of the top digit
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += TOPK_THREADS) {
-        const int pix = i / a.A, an = i - pix * a.A;
-        const uint32_t key = f2ord(pred[(size_t)pix * a.ld + an]);
-        keys[i] = key;
-        atomicAdd(&hist[key >> 24], 1u);
-    }
-    if (tid == 0) { s_prefix = 0; s_remaining = (unsigned)k; }
-    __syncthreads();
-
-    // 4 digit rounds: find the k-th largest key T
-    for (int round = 0; round < 4; ++round) {
-        const int shift = 24 - 8 * round;
-        if (round > 0) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const uint32_t prefix = s_prefix;
-            const uint32_t himask = 0xffffffffu << (shift + 8);
-            for (int i = tid; i < n; i += TOPK_THREADS) {
-                const uint32_t key = keys[i];
-                if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            unsigned int rem = s_remaining;
-            int d = 255;
-            for (; d > 0; --d) {
-                const unsigned int c = hist[d];
-                if (c >= rem) break;
-                rem -= c;
-            }
-            s_prefix |= ((uint32_t)d << shift);
-            s_remaining = rem;   // how many are still needed from keys sharing the chosen prefix
-        }
-        __syncthreads();
-    }
-    const uint32_t T = s_prefix;
-    const unsigned int need_eq = s_remaining;   // number of keys == T to take (smallest indices first)
-
-    // compaction in index order: wave w owns the contiguous range [w*chunk, (w+1)*chunk)
-    const int wave = tid >> 6, lane = tid & 63;
-    const int chunk = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
-    const int beg = wave * chunk, end = min(n, beg + chunk);
-    unsigned int cgt = 0, ceq = 0;
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t key = (i < end) ? keys[i] : 0u;
-        const bool gt = (i < end) && key > T, eq = (i < end) && key == T;
-        cgt += __popcll(__ballot(gt));
-        ceq += __popcll(__ballot(eq));
-    }
-    if (lane == 0) { wave_gt[wave] = cgt; wave_eq[wave] = ceq; }
-    __syncthreads();
-    unsigned int gt_before = 0, eq_before = 0, gt_total = 0;
-    for (int w = 0; w < 16; ++w) {
-        if (w < wave) { gt_before += wave_gt[w]; eq_before += wave_eq[w]; }
-        gt_total += wave_gt[w];
-    }
-    // slot layout: [0, gt_total) = keys > T in index order, [gt_total, k) = first need_eq keys == T in index order
-    for (int i = tid; i < MAX_K; i += TOPK_THREADS) sorted[i] = 0ull;
-    __syncthreads();
-    unsigned int rgt = gt_before, req = eq_before;
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t key = (i < end) ? keys[i] : 0u;
-        const bool gt = (i < end) && key > T, eq = (i < end) && key == T;
-        const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
-        if (gt) sorted[rgt + __popcll(mgt & below)] = word;
-        if (eq) {
-            const unsigned int r = req + __popcll(meq & below);
-            if (r < need_eq) sorted[gt_total + r] = word;
-        }
-        rgt += __popcll(mgt);
-        req += __popcll(meq);
-    }
-    __syncthreads();
-    int N = 64;
-    while (N < k) N <<= 1;
-    bitonic_desc<TOPK_THREADS>(sorted, N);
-    for (int i = tid; i < k; i += TOPK_THREADS) {
-        const unsigned long long wv = sorted[i];
+    const int A = a.A, ld = a.ld;
+    // key = order-preserving image of the logit; (logit desc, index asc) == (key desc, index asc)
+    const int k = amp::select_topk(sm, n, a.k, keys, [&](int i) {
+        const int pix = i / A, an = i - pix * A;
+        uint32_t key = f2ord(pred[(size_t)pix * ld + an]);
+        return key ? key : 1u;   // 0 is the "not a candidate" marker of select_topk (only a negative NaN maps there)
+    });
+    for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
+        const unsigned long long wv = sm.sorted[i];
         a.sel_idx[(size_t)seg * a.k + i] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
         a.sel_logit[(size_t)seg * a.k + i] = ord2f((uint32_t)(wv >> 32));
     }
-    if (tid == 0) a.sel_count[seg] = k;
+    if (threadIdx.x == 0) a.sel_count[seg] = k;
 }
 
 struct DecodeArgs {
@@ -168,6 +69,8 @@ struct DecodeArgs {
     int cap;                         // capacity per image of the outputs (>= nlevels*k)
     float* boxes;                    // [B][cap][4] clipped boxes
     unsigned long long* sortkey;     // [B][cap]: (ord(logit) << 32) | ~pos, 0 when invalid / unused
+    int* anchor_id;                  // [B][cap] global anchor index (level offset + index), -1 for unused slots; may be null
+    int lvl_off[MAX_LEVELS];
 };
 
 __global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
@@ -176,6 +79,7 @@ __global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int b = t / a.cap, pos = t - b * a.cap;
         unsigned long long key = 0ull;
+        int aid = -1;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
         // position in the level-major concatenation: level lvl contributes sel_count[b][lvl] entries
         if (pos < per_img) {
@@ -185,6 +89,7 @@ __global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
                 const int seg = b * a.nlevels + lvl;
                 const int idx = a.sel_idx[(size_t)seg * a.k + off];
                 const float logit = a.sel_logit[(size_t)seg * a.k + off];
+                aid = a.lvl_off[lvl] + idx;
                 const int pix = idx / a.A, an = idx - pix * a.A;
                 const int py = pix / a.fw[lvl], px = pix - py * a.fw[lvl];
                 const float sx = (float)(px * a.stride[lvl]), sy = (float)(py * a.stride[lvl]);
@@ -213,6 +118,7 @@ __global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
         float* o = a.boxes + (size_t)t * 4;
         o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
         a.sortkey[t] = key;
+        if (a.anchor_id) a.anchor_id[t] = aid;
     }
 }
 
@@ -221,12 +127,12 @@ constexpr int SORT_THREADS = 1024;
 __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(const unsigned long long* sortkey, const float* boxes_in,
                                                                   int cap, int box_stride, int N, float* boxes_out,
                                                                   float* score_out, int* cat_out, int* count_out,
-                                                                  int* pos_out) {
+                                                                  int* pos_out, const int* payload_in, int* payload_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < N; i += SORT_THREADS) skeys[i] = (i < cap) ? sortkey[(size_t)b * cap + i] : 0ull;
     __syncthreads();
-    bitonic_desc<SORT_THREADS>(skeys, N);
+    amp::bitonic_desc<SORT_THREADS>(skeys, N);
     int cnt = 0;
     for (int i = threadIdx.x; i < cap; i += SORT_THREADS) {
         const unsigned long long kv = skeys[i];
@@ -245,6 +151,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(const unsigne
         score_out[(size_t)b * cap + i] = sc;
         cat_out[(size_t)b * cap + i] = cat;
         if (pos_out) pos_out[(size_t)b * cap + i] = pos;
+        if (payload_out) payload_out[(size_t)b * cap + i] = (pos >= 0 && payload_in) ? payload_in[(size_t)b * box_stride + pos] : -1;
     }
     // block reduce of the valid count (counter lives behind the keys: keep all LDS in the one dynamic region)
     int* s_cnt = reinterpret_cast<int*>(skeys + N);
@@ -264,7 +171,7 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
                  float* sel_logit, int* sel_count) {
     AMP_REQUIRE(ctx && lv && keys_scratch && sel_idx && sel_logit && sel_count, "amp_rpn_topk: null argument");
     AMP_REQUIRE(lv->nlevels >= 1 && lv->nlevels <= MAX_LEVELS && lv->A == 3, "amp_rpn_topk: need 1..5 levels, A == 3");
-    AMP_REQUIRE(k >= 1 && k <= MAX_K, "amp_rpn_topk: k=%d out of range [1,%d]", k, MAX_K);
+    AMP_REQUIRE(k >= 1 && k <= amp::SELECT_MAX_K, "amp_rpn_topk: k=%d out of range [1,%d]", k, amp::SELECT_MAX_K);
     TopkArgs a;
     for (int l = 0; l < lv->nlevels; ++l) {
         AMP_REQUIRE(lv->pred[l] && lv->h[l] > 0 && lv->w[l] > 0, "amp_rpn_topk: missing level %d", l);
@@ -281,7 +188,7 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
 }
 
 int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
-                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey) {
+                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey, int* anchor_id) {
     AMP_REQUIRE(ctx && lv && sel_idx && sel_logit && sel_count && boxes && sortkey, "amp_rpn_decode: null argument");
     AMP_REQUIRE(lv->nlevels >= 1 && lv->nlevels <= MAX_LEVELS && lv->A == 3, "amp_rpn_decode: need 1..5 levels, A == 3");
     AMP_REQUIRE(cap >= lv->nlevels * k, "amp_rpn_decode: cap=%d < nlevels*k", cap);
@@ -304,7 +211,9 @@ int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const i
     a.sel_idx = sel_idx; a.sel_logit = sel_logit; a.sel_count = sel_count;
     a.img_h = (float)img_h; a.img_w = (float)img_w;
     a.scale_clamp = (float)log(1000.0 / 16.0);
-    a.cap = cap; a.boxes = boxes; a.sortkey = sortkey;
+    a.cap = cap; a.boxes = boxes; a.sortkey = sortkey; a.anchor_id = anchor_id;
+    a.lvl_off[0] = 0;
+    for (int l = 1; l < MAX_LEVELS; ++l) a.lvl_off[l] = (l <= lv->nlevels) ? a.lvl_off[l - 1] + lv->h[l - 1] * lv->w[l - 1] * lv->A : 0;
     const int total = B * cap;
     hipLaunchKernelGGL(rpn_decode_kernel, dim3(amp::cdiv(total, 256)), dim3(256), 0, ctx->stream, a, B);
     AMP_HIP_CHECK(hipGetLastError());
@@ -312,7 +221,8 @@ int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const i
 }
 
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
-                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out) {
+                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out, const int* payload_in,
+                    int* payload_out) {
     AMP_REQUIRE(ctx && sortkey && boxes_in && boxes_out && score_out && cat_out && count_out, "amp_sort_gather: null argument");
     AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 16384, "amp_sort_gather: cap=%d out of range [1,16384]", cap);
     int N = 64;
@@ -321,7 +231,7 @@ int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned
     AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_gather_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(sort_gather_kernel, dim3(B), dim3(SORT_THREADS), smem, ctx->stream, sortkey, boxes_in, cap, box_stride, N,
-                       boxes_out, score_out, cat_out, count_out, pos_out);
+                       boxes_out, score_out, cat_out, count_out, pos_out, payload_in, payload_out);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -1,0 +1,127 @@
+// Exact top-k selection inside one 1024-thread workgroup (shared by the RPN top-k and the seeded anchor / RoI sampling).
+//   select_topk(sm, n, k, keys_scratch, key_fn): key_fn(i) -> uint32 for i in [0,n); 0 means "not a candidate".
+//   Selects the min(k, #candidates) largest keys, ties by ascending index, and leaves them sorted by (key desc, index asc)
+//   in sm.sorted[] as 64-bit words (key << 32) | (0xffffffff - index).  Returns the number selected.
+// Method: 4 x 8-bit radix-select rounds with LDS histograms find the k-th largest key T; a wave-ballot compaction in index
+// order places the keys > T and the first (k - #greater) keys == T; an LDS bitonic sort orders the <= 2048 survivors.
+#pragma once
+#include "common.h"
+
+namespace amp {
+
+constexpr int SELECT_THREADS = 1024;
+constexpr int SELECT_MAX_K = 2048;
+
+struct SelectSmem {
+    unsigned int hist[256];
+    unsigned int prefix, remaining, ncand;
+    unsigned int wave_gt[16], wave_eq[16];
+    unsigned long long sorted[SELECT_MAX_K];
+};
+
+// In-LDS bitonic sort, descending, of N (power of two) 64-bit words by all NT threads of the block.
+template <int NT>
+__device__ inline void bitonic_desc(unsigned long long* s, int N) {
+    for (int size = 2; size <= N; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (N >> 1); t += NT) {
+                const int lo = (t / stride) * (stride << 1) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = s[lo], b = s[hi];
+                if ((a < b) == desc) { s[lo] = b; s[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <class KeyFn>
+__device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* keys, KeyFn key_fn) {
+    const int tid = threadIdx.x;
+    __syncthreads();   // previous users of sm are done
+    if (tid < 256) sm.hist[tid] = 0;
+    if (tid == 0) sm.ncand = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (int i = tid; i < n; i += SELECT_THREADS) {
+        const uint32_t key = key_fn(i);
+        keys[i] = key;
+        if (key) { atomicAdd(&sm.hist[key >> 24], 1u); ++mine; }
+    }
+    if (mine) atomicAdd(&sm.ncand, mine);
+    __syncthreads();
+    const int k = min(kmax, (int)sm.ncand);
+    if (k <= 0) return 0;   // uniform
+    if (tid == 0) { sm.prefix = 0; sm.remaining = (unsigned)k; }
+    __syncthreads();
+    for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        if (round > 0) {
+            if (tid < 256) sm.hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sm.prefix;
+            const uint32_t himask = 0xffffffffu << (shift + 8);
+            for (int i = tid; i < n; i += SELECT_THREADS) {
+                const uint32_t key = keys[i];
+                if (key && (key & himask) == prefix) atomicAdd(&sm.hist[(key >> shift) & 0xff], 1u);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            unsigned int rem = sm.remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                const unsigned int c = sm.hist[d];
+                if (c >= rem) break;
+                rem -= c;
+            }
+            sm.prefix |= ((uint32_t)d << shift);
+            sm.remaining = rem;
+        }
+        __syncthreads();
+    }
+    const uint32_t T = sm.prefix;                 // k-th largest key (> 0 because only candidates were counted)
+    const unsigned int need_eq = sm.remaining;    // keys == T to take, smallest indices first
+    const int wave = tid >> 6, lane = tid & 63;
+    const int chunk = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
+    const int beg = wave * chunk, end = min(n, beg + chunk);
+    unsigned int cgt = 0, ceq = 0;
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = (i < end) ? keys[i] : 0u;
+        cgt += __popcll(__ballot(key > T));
+        ceq += __popcll(__ballot(key == T));
+    }
+    if (lane == 0) { sm.wave_gt[wave] = cgt; sm.wave_eq[wave] = ceq; }
+    for (int i = tid; i < SELECT_MAX_K; i += SELECT_THREADS) sm.sorted[i] = 0ull;
+    __syncthreads();
+    unsigned int rgt = 0, req = 0, gt_total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { rgt += sm.wave_gt[w]; req += sm.wave_eq[w]; }
+        gt_total += sm.wave_gt[w];
+    }
+    for (int i0 = beg; i0 < end; i0 += 64) {
+        const int i = i0 + lane;
+        const uint32_t key = (i < end) ? keys[i] : 0u;
+        const bool gt = key > T, eq = key == T;
+        const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+        if (gt) sm.sorted[rgt + __popcll(mgt & below)] = word;
+        if (eq) {
+            const unsigned int r = req + __popcll(meq & below);
+            if (r < need_eq) sm.sorted[gt_total + r] = word;
+        }
+        rgt += __popcll(mgt);
+        req += __popcll(meq);
+    }
+    __syncthreads();
+    int N = 64;
+    while (N < k) N <<= 1;
+    bitonic_desc<SELECT_THREADS>(sm.sorted, N);
+    return k;
+}
+
+}  // namespace amp

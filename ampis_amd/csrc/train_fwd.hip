@@ -1,0 +1,558 @@
+// Training-mode forward: label assignment, seeded sub-sampling and the five Mask R-CNN losses (SURVEY.md §8a rows a2, a18;
+// detectron2 rpn.py label_and_sample_anchors / losses, matcher.py, sampling.py, roi_heads.py label_and_sample_proposals,
+// fast_rcnn.py losses, mask_head.py mask_rcnn_loss, masks.py rasterize_polygons_within_box + pycocotools rleFrPoly) --
+// what `self._model(data)` returns to AMPIS's LossEvalHook (ampis/data_utils.py:111-122).
+//
+// Every loss kernel also writes the gradient of its loss w.r.t. the network outputs it reads (sparse for the RPN), so the
+// backward pass starts from these buffers.  Sub-sampling is a counter-based hash (oracle/train.py hash32): take the k
+// candidates with the largest key = max(0xffffffff - hash32(seed, image, stream, index), 1), ties by index.
+// Reductions are fixed-order trees inside one workgroup per image / RoI; the host adds the per-image partials in order.
+#include "common.h"
+#include "select.h"
+
+namespace {
+
+constexpr int NL = 5;
+constexpr int MAXG_TILE = 256;
+
+__device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t image, uint32_t stream, uint32_t idx) {
+    uint32_t x = seed * 0x9E3779B1u + image * 0x85EBCA77u + stream * 0xC2B2AE3Du + idx * 0x27D4EB2Fu;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t sample_key(uint32_t seed, uint32_t image, uint32_t stream, uint32_t idx) {
+    const uint32_t k = 0xffffffffu - hash32(seed, image, stream, idx);
+    return k ? k : 1u;
+}
+
+struct AnchorGeom {
+    int hw[NL], fw[NL], stride[NL], off[NL + 1];   // off: first anchor index of each level (x3 anchors per location)
+    float cell[NL][3][4];
+    int total;
+};
+
+__device__ __forceinline__ void anchor_box(const AnchorGeom& g, int a, float& x1, float& y1, float& x2, float& y2, int& lvl, int& local) {
+    lvl = 0;
+    while (lvl + 1 < NL && a >= g.off[lvl + 1]) ++lvl;
+    local = a - g.off[lvl];
+    const int pix = local / 3, an = local - pix * 3;
+    const int py = pix / g.fw[lvl], px = pix - py * g.fw[lvl];
+    const float sx = (float)(px * g.stride[lvl]), sy = (float)(py * g.stride[lvl]);
+    x1 = __fadd_rn(sx, g.cell[lvl][an][0]); y1 = __fadd_rn(sy, g.cell[lvl][an][1]);
+    x2 = __fadd_rn(sx, g.cell[lvl][an][2]); y2 = __fadd_rn(sy, g.cell[lvl][an][3]);
+}
+
+// detectron2 pairwise_iou(gt, box): 0 where the intersection is empty
+__device__ __forceinline__ float iou_gt_box(float gx1, float gy1, float gx2, float gy2, float garea, float x1, float y1, float x2,
+                                            float y2, float area) {
+    const float w = fmaxf(__fsub_rn(fminf(gx2, x2), fmaxf(gx1, x1)), 0.f);
+    const float h = fmaxf(__fsub_rn(fminf(gy2, y2), fmaxf(gy1, y1)), 0.f);
+    const float inter = __fmul_rn(w, h);
+    return inter > 0.f ? __fdiv_rn(inter, __fsub_rn(__fadd_rn(garea, area), inter)) : 0.f;
+}
+
+// ---- anchors <-> GT: best GT per anchor and best IoU per GT (Matcher inputs) -------------------------------------------------
+__global__ __launch_bounds__(256) void anchor_match_kernel(const AnchorGeom g, const float* __restrict__ gt_boxes,
+                                                           const int* __restrict__ gt_off, float* match_val, int* match_idx,
+                                                           unsigned int* gt_best /* [sum G] float bits, zeroed */) {
+    __shared__ float sg[MAXG_TILE][5];
+    __shared__ float wmax[4];
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    int lvl, local;
+    const bool av = a < g.total;
+    if (av) anchor_box(g, a, x1, y1, x2, y2, lvl, local);
+    const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    float best = -1.f;
+    int besti = 0;
+    for (int t0 = 0; t0 < G; t0 += MAXG_TILE) {
+        const int tn = min(MAXG_TILE, G - t0);
+        __syncthreads();
+        if ((int)threadIdx.x < tn) {
+            const float* p = gt_boxes + (size_t)(g0 + t0 + threadIdx.x) * 4;
+            sg[threadIdx.x][0] = p[0]; sg[threadIdx.x][1] = p[1]; sg[threadIdx.x][2] = p[2]; sg[threadIdx.x][3] = p[3];
+            sg[threadIdx.x][4] = __fmul_rn(__fsub_rn(p[2], p[0]), __fsub_rn(p[3], p[1]));
+        }
+        __syncthreads();
+        for (int j = 0; j < tn; ++j) {
+            const float v = av ? iou_gt_box(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area) : 0.f;
+            if (v > best) { best = v; besti = t0 + j; }        // first maximum, like torch.max(dim=0)
+            // workgroup max of this GT's IoU over the 256 anchors -> one atomicMax per (workgroup, GT)
+            float m = v;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const float mm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+                if (mm > 0.f) atomicMax(&gt_best[g0 + t0 + j], __float_as_uint(mm));   // IoU >= 0: uint order == float order
+            }
+            __syncthreads();
+        }
+    }
+    if (av) {
+        match_val[(size_t)b * g.total + a] = (G > 0) ? best : 0.f;
+        match_idx[(size_t)b * g.total + a] = besti;
+    }
+}
+
+// Matcher labels (thresholds lo/hi -> 0 / -1 / 1) + set_low_quality_matches_ (IoU == that GT's best over all anchors)
+__global__ __launch_bounds__(256) void anchor_label_kernel(const AnchorGeom g, const float* __restrict__ gt_boxes,
+                                                           const int* __restrict__ gt_off, const float* match_val,
+                                                           const unsigned int* gt_best, float lo, float hi, signed char* label) {
+    __shared__ float sg[MAXG_TILE][6];
+    const int b = blockIdx.y;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    int lvl, local;
+    const bool av = a < g.total;
+    if (av) anchor_box(g, a, x1, y1, x2, y2, lvl, local);
+    const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    bool lowq = false;
+    for (int t0 = 0; t0 < G; t0 += MAXG_TILE) {
+        const int tn = min(MAXG_TILE, G - t0);
+        __syncthreads();
+        if ((int)threadIdx.x < tn) {
+            const float* p = gt_boxes + (size_t)(g0 + t0 + threadIdx.x) * 4;
+            sg[threadIdx.x][0] = p[0]; sg[threadIdx.x][1] = p[1]; sg[threadIdx.x][2] = p[2]; sg[threadIdx.x][3] = p[3];
+            sg[threadIdx.x][4] = __fmul_rn(__fsub_rn(p[2], p[0]), __fsub_rn(p[3], p[1]));
+            sg[threadIdx.x][5] = __uint_as_float(gt_best[g0 + t0 + threadIdx.x]);
+        }
+        __syncthreads();
+        if (av)
+            for (int j = 0; j < tn; ++j) {
+                const float v = iou_gt_box(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area);
+                lowq = lowq || (v == sg[j][5]);
+            }
+    }
+    if (av) {
+        signed char l = 0;
+        if (G > 0) {
+            const float v = match_val[(size_t)b * g.total + a];
+            l = (v >= hi) ? 1 : (v >= lo ? -1 : 0);
+            if (lowq) l = 1;
+        }
+        label[(size_t)b * g.total + a] = l;
+    }
+}
+
+// ---- RPN: sample 256 anchors / image, BCE + L1 losses and their gradients -----------------------------------------------------
+struct RpnLossArgs {
+    AnchorGeom g;
+    const float* pred[NL];        // [B, hw, 15]
+    float* dpred[NL];             // same shape, zero-filled by the caller; receives d(loss)/d(pred) (may be null)
+    const float* gt_boxes;
+    const int* gt_off;
+    const signed char* label;
+    const int* match_idx;
+    uint32_t* keys_scratch;       // [B][total]
+    int batch, num_pos_max;       // 256, 128
+    uint32_t seed;
+    float inv_norm;               // 1 / (batch * B)
+    int* sampled;                 // [B][batch] anchor indices: positives then negatives, ascending hash
+    int* counts;                  // [B][2] npos, nneg
+    float* partial;               // [B][2] sum BCE, sum L1 (unnormalised)
+};
+
+__global__ __launch_bounds__(1024) void rpn_sample_loss_kernel(const RpnLossArgs a) {
+    __shared__ amp::SelectSmem sm;
+    __shared__ int s_idx[512];
+    __shared__ float s_red[2][1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.g.total;
+    const signed char* lab = a.label + (size_t)b * n;
+    uint32_t* keys = a.keys_scratch + (size_t)b * n;
+    const uint32_t seed = a.seed;
+    const int npos = amp::select_topk(sm, n, a.num_pos_max, keys, [&](int i) { return lab[i] == 1 ? sample_key(seed, b, 0, i) : 0u; });
+    for (int i = tid; i < npos; i += 1024) s_idx[i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+    __syncthreads();
+    const int nneg = amp::select_topk(sm, n, a.batch - npos, keys, [&](int i) { return lab[i] == 0 ? sample_key(seed, b, 1, i) : 0u; });
+    for (int i = tid; i < nneg; i += 1024) s_idx[npos + i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+    __syncthreads();
+    float bce = 0.f, l1 = 0.f;
+    if (tid < npos + nneg) {
+        const int an = s_idx[tid];
+        a.sampled[(size_t)b * a.batch + tid] = an;
+        float x1, y1, x2, y2;
+        int lvl, local;
+        anchor_box(a.g, an, x1, y1, x2, y2, lvl, local);
+        const int pix = local / 3, k = local - pix * 3;
+        const size_t row = ((size_t)b * a.g.hw[lvl] + pix) * 15;
+        const float* p = a.pred[lvl] + row;
+        float* dp = a.dpred[lvl] ? a.dpred[lvl] + row : nullptr;
+        const float x = p[k];
+        const float y = tid < npos ? 1.f : 0.f;
+        // binary_cross_entropy_with_logits: max(x,0) - x*y + log1p(exp(-|x|)); d/dx = sigmoid(x) - y
+        bce = __fadd_rn(__fsub_rn(fmaxf(x, 0.f), __fmul_rn(x, y)), log1pf(expf(-fabsf(x))));
+        if (dp) dp[k] = __fmul_rn(__fsub_rn(__fdiv_rn(1.f, __fadd_rn(1.f, expf(-x))), y), a.inv_norm);
+        if (tid < npos) {
+            const float* gb = a.gt_boxes + (size_t)(a.gt_off[b] + a.match_idx[(size_t)b * n + an]) * 4;
+            const float sw = __fsub_rn(x2, x1), sh = __fsub_rn(y2, y1);
+            const float sx = __fadd_rn(x1, __fmul_rn(0.5f, sw)), sy = __fadd_rn(y1, __fmul_rn(0.5f, sh));
+            const float tw = __fsub_rn(gb[2], gb[0]), th = __fsub_rn(gb[3], gb[1]);
+            const float tx = __fadd_rn(gb[0], __fmul_rn(0.5f, tw)), ty = __fadd_rn(gb[1], __fmul_rn(0.5f, th));
+            const float t[4] = {__fdiv_rn(__fsub_rn(tx, sx), sw), __fdiv_rn(__fsub_rn(ty, sy), sh), logf(__fdiv_rn(tw, sw)),
+                                logf(__fdiv_rn(th, sh))};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = __fsub_rn(p[3 + 4 * k + q], t[q]);
+                l1 = __fadd_rn(l1, fabsf(d));
+                if (dp) dp[3 + 4 * k + q] = (d > 0.f ? a.inv_norm : (d < 0.f ? -a.inv_norm : 0.f));
+            }
+        }
+    }
+    s_red[0][tid] = bce; s_red[1][tid] = l1;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { s_red[0][tid] = __fadd_rn(s_red[0][tid], s_red[0][tid + o]); s_red[1][tid] = __fadd_rn(s_red[1][tid], s_red[1][tid + o]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.counts[2 * b] = npos; a.counts[2 * b + 1] = nneg;
+        a.partial[2 * b] = s_red[0][0]; a.partial[2 * b + 1] = s_red[1][0];
+    }
+}
+
+// ---- RoI heads: append GT, match (IoU >= 0.5), sample 512 / image with <= 25 % foreground -----------------------------------------
+struct RoiSampleArgs {
+    const float* prop_boxes;      // [B][Pcap][4]
+    const int* prop_count;        // [B]
+    const float* gt_boxes;
+    const int* gt_classes;
+    const int* gt_off;
+    int Pcap, K, batch, num_fg_max;
+    float iou_thresh;
+    uint32_t seed;
+    uint32_t* keys_scratch;       // [B][ncap]
+    int* cls_scratch;             // [B][ncap]
+    int* gti_scratch;             // [B][ncap]
+    int ncap;
+    float* rois;                  // [B][batch][4]
+    int* roi_cls;                 // [B][batch]  (K = background, -1 = unused slot)
+    int* roi_gti;                 // [B][batch]  matched GT (index within the image)
+    int* counts;                  // [B][2] nfg, nbg
+    const int* prop_anchor;       // [B][Pcap] originating anchor of each proposal: the hash identity (order-independent)
+    int num_anchors;              // GT box j hashes as num_anchors + j
+};
+
+__global__ __launch_bounds__(1024) void roi_sample_kernel(const RoiSampleArgs a) {
+    __shared__ amp::SelectSmem sm;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int P = min(a.prop_count[b], a.Pcap);
+    const int g0 = a.gt_off[b], G = a.gt_off[b + 1] - g0;
+    const int n = P + G;
+    int* cls = a.cls_scratch + (size_t)b * a.ncap;
+    int* gti = a.gti_scratch + (size_t)b * a.ncap;
+    uint32_t* keys = a.keys_scratch + (size_t)b * a.ncap;
+    auto box_of = [&](int i) -> const float* { return i < P ? a.prop_boxes + ((size_t)b * a.Pcap + i) * 4 : a.gt_boxes + (size_t)(g0 + i - P) * 4; };
+    for (int i = tid; i < n; i += 1024) {
+        const float* p = box_of(i);
+        const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+        const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+        float best = -1.f;
+        int bi = 0;
+        for (int j = 0; j < G; ++j) {
+            const float* q = a.gt_boxes + (size_t)(g0 + j) * 4;
+            const float ga = __fmul_rn(__fsub_rn(q[2], q[0]), __fsub_rn(q[3], q[1]));
+            const float v = iou_gt_box(q[0], q[1], q[2], q[3], ga, x1, y1, x2, y2, area);
+            if (v > best) { best = v; bi = j; }
+        }
+        const bool fg = G > 0 && best >= a.iou_thresh;
+        cls[i] = fg ? a.gt_classes[g0 + bi] : a.K;
+        gti[i] = bi;
+    }
+    __syncthreads();
+    const uint32_t seed = a.seed;
+    const int K = a.K;
+    auto ident = [&](int i) -> uint32_t { return (uint32_t)(i < P ? a.prop_anchor[(size_t)b * a.Pcap + i] : a.num_anchors + (i - P)); };
+    const int nfg = amp::select_topk(sm, n, a.num_fg_max, keys, [&](int i) { return cls[i] != K ? sample_key(seed, b, 2, ident(i)) : 0u; });
+    for (int i = tid; i < a.batch; i += 1024) a.roi_cls[(size_t)b * a.batch + i] = -1;
+    __syncthreads();
+    for (int i = tid; i < nfg; i += 1024) {
+        const int src = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+        const float* p = box_of(src);
+        float* o = a.rois + ((size_t)b * a.batch + i) * 4;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+        a.roi_cls[(size_t)b * a.batch + i] = cls[src];
+        a.roi_gti[(size_t)b * a.batch + i] = gti[src];
+    }
+    const int nbg = amp::select_topk(sm, n, a.batch - nfg, keys, [&](int i) { return cls[i] == K ? sample_key(seed, b, 3, ident(i)) : 0u; });
+    for (int i = tid; i < nbg; i += 1024) {
+        const int src = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+        const float* p = box_of(src);
+        float* o = a.rois + ((size_t)b * a.batch + nfg + i) * 4;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+        a.roi_cls[(size_t)b * a.batch + nfg + i] = K;
+        a.roi_gti[(size_t)b * a.batch + nfg + i] = gti[src];
+    }
+    for (int i = tid + nfg + nbg; i < a.batch; i += 1024) {
+        float* o = a.rois + ((size_t)b * a.batch + i) * 4;
+        o[0] = o[1] = o[2] = o[3] = 0.f;
+    }
+    if (tid == 0) { a.counts[2 * b] = nfg; a.counts[2 * b + 1] = nbg; }
+}
+
+// ---- box head losses: softmax CE (mean over all sampled RoIs) + L1 on the GT-class deltas of the foreground RoIs ---------------------
+struct BoxLossArgs {
+    const float* pred;            // [B*batch][ld]: K+1 logits then 4K deltas
+    float* dpred;                 // same shape (may be null)
+    const float* rois;
+    const int* roi_cls;
+    const int* roi_gti;
+    const float* gt_boxes;
+    const int* gt_off;
+    int batch, K, ld;
+    float wx, wy, ww, wh;
+    float inv_total;              // 1 / (number of sampled RoIs in the batch)
+    float* partial;               // [B][2] sum CE, sum L1
+};
+
+__global__ __launch_bounds__(512) void box_loss_kernel(const BoxLossArgs a) {
+    __shared__ float s_red[2][512];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float ce = 0.f, l1 = 0.f;
+    for (int r = tid; r < a.batch; r += 512) {
+        const size_t row = (size_t)b * a.batch + r;
+        const int c = a.roi_cls[row];
+        float* dp = a.dpred ? a.dpred + row * a.ld : nullptr;
+        if (c < 0) {
+            if (dp) for (int k = 0; k < a.ld; ++k) dp[k] = 0.f;
+            continue;
+        }
+        const float* p = a.pred + row * a.ld;
+        float mx = p[0];
+        for (int k = 1; k <= a.K; ++k) mx = fmaxf(mx, p[k]);
+        float sum = 0.f;
+        for (int k = 0; k <= a.K; ++k) sum = __fadd_rn(sum, expf(__fsub_rn(p[k], mx)));
+        const float lse = __fadd_rn(mx, logf(sum));
+        ce = __fadd_rn(ce, __fsub_rn(lse, p[c]));
+        if (dp) {
+            for (int k = 0; k <= a.K; ++k)
+                dp[k] = __fmul_rn(__fsub_rn(__fdiv_rn(expf(__fsub_rn(p[k], mx)), sum), k == c ? 1.f : 0.f), a.inv_total);
+            for (int k = a.K + 1; k < a.ld; ++k) dp[k] = 0.f;
+        }
+        if (c < a.K) {
+            const float* s = a.rois + row * 4;
+            const float* g = a.gt_boxes + (size_t)(a.gt_off[b] + a.roi_gti[row]) * 4;
+            const float sw = __fsub_rn(s[2], s[0]), sh = __fsub_rn(s[3], s[1]);
+            const float sx = __fadd_rn(s[0], __fmul_rn(0.5f, sw)), sy = __fadd_rn(s[1], __fmul_rn(0.5f, sh));
+            const float tw = __fsub_rn(g[2], g[0]), th = __fsub_rn(g[3], g[1]);
+            const float tx = __fadd_rn(g[0], __fmul_rn(0.5f, tw)), ty = __fadd_rn(g[1], __fmul_rn(0.5f, th));
+            const float t[4] = {__fdiv_rn(__fmul_rn(a.wx, __fsub_rn(tx, sx)), sw), __fdiv_rn(__fmul_rn(a.wy, __fsub_rn(ty, sy)), sh),
+                                __fmul_rn(a.ww, logf(__fdiv_rn(tw, sw))), __fmul_rn(a.wh, logf(__fdiv_rn(th, sh)))};
+            for (int q = 0; q < 4; ++q) {
+                const int col = a.K + 1 + 4 * c + q;
+                const float d = __fsub_rn(p[col], t[q]);
+                l1 = __fadd_rn(l1, fabsf(d));
+                if (dp) dp[col] = (d > 0.f ? a.inv_total : (d < 0.f ? -a.inv_total : 0.f));
+            }
+        }
+    }
+    s_red[0][tid] = ce; s_red[1][tid] = l1;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) {
+        if (tid < o) { s_red[0][tid] = __fadd_rn(s_red[0][tid], s_red[0][tid + o]); s_red[1][tid] = __fadd_rn(s_red[1][tid], s_red[1][tid + o]); }
+        __syncthreads();
+    }
+    if (tid == 0) { a.partial[2 * b] = s_red[0][0]; a.partial[2 * b + 1] = s_red[1][0]; }
+}
+
+// ---- mask targets: rasterize_polygons_within_box (28x28) by pycocotools' rleFrPoly; mask BCE loss + gradient ---------------------------
+struct MaskLossArgs {
+    const float* logits;          // [N][28][28][K]
+    float* dlogits;               // same shape (may be null)
+    const float* rois;            // [N][4]
+    const int* cls;               // [N]
+    const int* poly_id;           // [N] global instance index (polygon of the matched GT)
+    const double* poly_xy;        // flat vertex list
+    const int* poly_off;          // [instances+1] offsets into poly_xy (in doubles)
+    int N, K;
+    float inv_count;              // 1 / (N * 784)
+    float* partial;               // [N] per-RoI BCE sums
+    unsigned char* target_out;    // [N][784] (may be null): the rasterised targets, row-major, for the parity tests
+};
+
+constexpr int MS = 28;
+constexpr int NBITS = MS * MS + 1;          // positions 0..784 (a = x*h + y with y <= h)
+constexpr int NWORDS = (NBITS + 31) / 32;   // 25
+
+__global__ __launch_bounds__(64) void mask_target_loss_kernel(const MaskLossArgs a) {
+    __shared__ unsigned int tog[NWORDS];
+    __shared__ unsigned char bits[MS * MS];   // column-major: bits[x*28 + y]
+    __shared__ float s_red[64];
+    const int n = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < NWORDS; i += 64) tog[i] = 0u;
+    __syncthreads();
+    const float* r = a.rois + (size_t)n * 4;
+    // detectron2 rasterize_polygons_within_box: box arithmetic in fp32, polygon in fp64
+    const float w32 = __fsub_rn(r[2], r[0]), h32 = __fsub_rn(r[3], r[1]);
+    const double rw = (double)__fdiv_rn((float)MS, fmaxf(w32, 0.1f)), rh = (double)__fdiv_rn((float)MS, fmaxf(h32, 0.1f));
+    const double bx = (double)r[0], by = (double)r[1];
+    const int pid = a.poly_id[n];
+    const double* xy = a.poly_xy + a.poly_off[pid];
+    const int k = (a.poly_off[pid + 1] - a.poly_off[pid]) / 2;
+    const double scale = 5.0;
+    for (int j = lane; j < k; j += 64) {
+        const int j2 = (j + 1 == k) ? 0 : j + 1;
+        int xs = (int)(scale * ((xy[2 * j] - bx) * rw) + 0.5), ys = (int)(scale * ((xy[2 * j + 1] - by) * rh) + 0.5);
+        int xe = (int)(scale * ((xy[2 * j2] - bx) * rw) + 0.5), ye = (int)(scale * ((xy[2 * j2 + 1] - by) * rh) + 0.5);
+        const int dx = abs(xe - xs), dy = abs(ys - ye);
+        const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+        if (flip) { int t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+        const int len = dx >= dy ? dx : dy;
+        const double s = dx >= dy ? (dx ? (double)(ye - ys) / dx : 0.0) : (double)(xe - xs) / dy;
+        int pu = 0, pv = 0;
+        for (int d = 0; d <= len; ++d) {
+            const int t = flip ? len - d : d;
+            int u, v;
+            if (dx >= dy) { u = t + xs; v = (int)(ys + s * t + 0.5); } else { v = t + ys; u = (int)(xs + s * t + 0.5); }
+            if (d > 0 && u != pu) {
+                double xd = (double)(u < pu ? u : u - 1);
+                xd = (xd + 0.5) / scale - 0.5;
+                if (floor(xd) == xd && xd >= 0 && xd <= MS - 1) {
+                    double yd = (double)(v < pv ? v : pv);
+                    yd = (yd + 0.5) / scale - 0.5;
+                    if (yd < 0) yd = 0; else if (yd > MS) yd = MS;
+                    yd = ceil(yd);
+                    const int pos = (int)xd * MS + (int)yd;      // run boundary; runs alternate -> parity toggles
+                    atomicXor(&tog[pos >> 5], 1u << (pos & 31));
+                }
+            }
+            pu = u; pv = v;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {   // prefix parity over the 785 positions (column-major); 25 words
+        unsigned int carry = 0;
+        for (int wv = 0; wv < NWORDS; ++wv) {
+            unsigned int x = tog[wv];
+            x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;
+            if (carry) x = ~x;
+            carry = x >> 31;
+            tog[wv] = x;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < MS * MS; i += 64) bits[i] = (tog[i >> 5] >> (i & 31)) & 1u;
+    __syncthreads();
+    const int c = a.cls[n];
+    float acc = 0.f;
+    for (int i = lane; i < MS * MS; i += 64) {
+        const int y = i / MS, x = i - y * MS;           // row-major pixel of the logits
+        const float t = (float)bits[x * MS + y];
+        const size_t off = ((size_t)n * MS * MS + i) * a.K;
+        const float z = a.logits[off + c];
+        acc = __fadd_rn(acc, __fadd_rn(__fsub_rn(fmaxf(z, 0.f), __fmul_rn(z, t)), log1pf(expf(-fabsf(z)))));
+        if (a.dlogits) {
+            for (int q = 0; q < a.K; ++q) a.dlogits[off + q] = 0.f;
+            a.dlogits[off + c] = __fmul_rn(__fsub_rn(__fdiv_rn(1.f, __fadd_rn(1.f, expf(-z))), t), a.inv_count);
+        }
+        if (a.target_out) a.target_out[(size_t)n * MS * MS + i] = (unsigned char)t;
+    }
+    s_red[lane] = acc;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        if (lane < o) s_red[lane] = __fadd_rn(s_red[lane], s_red[lane + o]);
+        __syncthreads();
+    }
+    if (lane == 0) a.partial[n] = s_red[0];
+}
+
+void fill_geom(AnchorGeom& g, const amp_rpn_levels* lv) {
+    g.off[0] = 0;
+    for (int l = 0; l < NL; ++l) {
+        g.hw[l] = lv->h[l] * lv->w[l];
+        g.fw[l] = lv->w[l];
+        g.stride[l] = lv->stride[l];
+        g.off[l + 1] = g.off[l] + g.hw[l] * 3;
+        for (int r = 0; r < 3; ++r) {
+            const double ratio = (r == 0) ? 0.5 : (r == 1 ? 1.0 : 2.0);
+            const double area = (double)lv->anchor_size[l] * (double)lv->anchor_size[l];
+            const double w = sqrt(area / ratio), h = ratio * w;
+            g.cell[l][r][0] = (float)(-w / 2.0); g.cell[l][r][1] = (float)(-h / 2.0);
+            g.cell[l][r][2] = (float)(w / 2.0);  g.cell[l][r][3] = (float)(h / 2.0);
+        }
+    }
+    g.total = g.off[NL];
+}
+
+}  // namespace
+
+extern "C" {
+
+int amp_anchor_labels(amp_ctx* ctx, const amp_rpn_levels* lv, int B, const float* gt_boxes, const int* gt_off, int total_gt,
+                      float iou_lo, float iou_hi, float* match_val, int* match_idx, unsigned int* gt_best, signed char* label) {
+    AMP_REQUIRE(ctx && lv && gt_boxes && gt_off && match_val && match_idx && gt_best && label, "amp_anchor_labels: null argument");
+    AMP_REQUIRE(lv->nlevels == NL && lv->A == 3, "amp_anchor_labels: need 5 levels, 3 anchors");
+    AnchorGeom g;
+    fill_geom(g, lv);
+    AMP_HIP_CHECK(hipMemsetAsync(gt_best, 0, (size_t)(total_gt > 0 ? total_gt : 1) * sizeof(unsigned int), ctx->stream));
+    const dim3 grid(amp::cdiv(g.total, 256), B);
+    hipLaunchKernelGGL(anchor_match_kernel, grid, dim3(256), 0, ctx->stream, g, gt_boxes, gt_off, match_val, match_idx, gt_best);
+    hipLaunchKernelGGL(anchor_label_kernel, grid, dim3(256), 0, ctx->stream, g, gt_boxes, gt_off, match_val, gt_best, iou_lo, iou_hi, label);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_rpn_sample_loss(amp_ctx* ctx, const amp_rpn_levels* lv, float* const dpred[5], int B, const float* gt_boxes,
+                        const int* gt_off, const signed char* label, const int* match_idx, uint32_t* keys_scratch, int batch,
+                        float pos_frac, unsigned int seed, int* sampled, int* counts, float* partial) {
+    AMP_REQUIRE(ctx && lv && gt_boxes && gt_off && label && match_idx && keys_scratch && sampled && counts && partial, "amp_rpn_sample_loss: null argument");
+    AMP_REQUIRE(batch >= 1 && batch <= 512, "amp_rpn_sample_loss: batch must be in [1,512]");
+    RpnLossArgs a;
+    fill_geom(a.g, lv);
+    for (int l = 0; l < NL; ++l) { a.pred[l] = lv->pred[l]; a.dpred[l] = dpred ? dpred[l] : nullptr; }
+    a.gt_boxes = gt_boxes; a.gt_off = gt_off; a.label = label; a.match_idx = match_idx; a.keys_scratch = keys_scratch;
+    a.batch = batch; a.num_pos_max = (int)(batch * pos_frac); a.seed = seed; a.inv_norm = 1.0f / (float)(batch * B);
+    a.sampled = sampled; a.counts = counts; a.partial = partial;
+    hipLaunchKernelGGL(rpn_sample_loss_kernel, dim3(B), dim3(1024), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_roi_sample(amp_ctx* ctx, int B, const float* prop_boxes, const int* prop_count, int Pcap, const float* gt_boxes,
+                   const int* gt_classes, const int* gt_off, int K, int batch, float fg_frac, float iou_thresh, unsigned int seed,
+                   uint32_t* keys_scratch, int* cls_scratch, int* gti_scratch, int ncap, float* rois, int* roi_cls, int* roi_gti,
+                   int* counts, const int* prop_anchor, int num_anchors) {
+    AMP_REQUIRE(ctx && prop_boxes && prop_count && gt_boxes && gt_classes && gt_off && keys_scratch && cls_scratch && gti_scratch && rois &&
+                roi_cls && roi_gti && counts && prop_anchor, "amp_roi_sample: null argument");
+    AMP_REQUIRE(batch >= 1 && batch <= amp::SELECT_MAX_K, "amp_roi_sample: batch out of range");
+    RoiSampleArgs a;
+    a.prop_boxes = prop_boxes; a.prop_count = prop_count; a.gt_boxes = gt_boxes; a.gt_classes = gt_classes; a.gt_off = gt_off;
+    a.Pcap = Pcap; a.K = K; a.batch = batch; a.num_fg_max = (int)(batch * fg_frac); a.iou_thresh = iou_thresh; a.seed = seed;
+    a.keys_scratch = keys_scratch; a.cls_scratch = cls_scratch; a.gti_scratch = gti_scratch; a.ncap = ncap;
+    a.rois = rois; a.roi_cls = roi_cls; a.roi_gti = roi_gti; a.counts = counts; a.prop_anchor = prop_anchor; a.num_anchors = num_anchors;
+    hipLaunchKernelGGL(roi_sample_kernel, dim3(B), dim3(1024), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int ld, float* dpred, const float* rois, const int* roi_cls,
+                 const int* roi_gti, const float* gt_boxes, const int* gt_off, const float reg_weights[4], int total_rois, float* partial) {
+    AMP_REQUIRE(ctx && pred && rois && roi_cls && roi_gti && gt_boxes && gt_off && reg_weights && partial, "amp_box_loss: null argument");
+    BoxLossArgs a;
+    a.pred = pred; a.dpred = dpred; a.rois = rois; a.roi_cls = roi_cls; a.roi_gti = roi_gti; a.gt_boxes = gt_boxes; a.gt_off = gt_off;
+    a.batch = batch; a.K = K; a.ld = ld; a.wx = reg_weights[0]; a.wy = reg_weights[1]; a.ww = reg_weights[2]; a.wh = reg_weights[3];
+    a.inv_total = 1.0f / (float)(total_rois > 0 ? total_rois : 1);
+    a.partial = partial;
+    hipLaunchKernelGGL(box_loss_kernel, dim3(B), dim3(512), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
+                         const int* poly_id, const double* poly_xy, const int* poly_off, float* partial, unsigned char* target_out) {
+    AMP_REQUIRE(ctx && logits && rois && cls && poly_id && poly_xy && poly_off && partial, "amp_mask_target_loss: null argument");
+    if (N == 0) return AMP_OK;
+    MaskLossArgs a;
+    a.logits = logits; a.dlogits = dlogits; a.rois = rois; a.cls = cls; a.poly_id = poly_id; a.poly_xy = poly_xy; a.poly_off = poly_off;
+    a.N = N; a.K = K; a.inv_count = 1.0f / ((float)N * MS * MS); a.partial = partial; a.target_out = target_out;
+    hipLaunchKernelGGL(mask_target_loss_kernel, dim3(N), dim3(64), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+}  // extern "C"

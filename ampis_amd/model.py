@@ -8,17 +8,18 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Dets, ModelCfg, check, lib
+from ._lib import Dets, Gt, ModelCfg, check, lib
 from . import rle as _rle
 
-_TAP_DTYPES = {0: np.float32, 1: np.int32, 2: np.uint64}
+_TAP_DTYPES = {0: np.float32, 1: np.int32, 2: np.uint64, 3: np.int8, 4: np.uint8}
 
 
 class MaskRCNN:
     def __init__(self, ctx, num_classes, max_batch=1, max_h=1344, max_w=1344, max_out_hw=4096,
                  detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
                  score_thresh=0.05, nms_thresh=0.5, mask_threshold=0.5, pixel_mean=(103.530, 116.280, 123.675),
-                 pixel_std=(1.0, 1.0, 1.0), rle_pool_counts=0):
+                 pixel_std=(1.0, 1.0, 1.0), rle_pool_counts=0, train=False, max_gt=16384, max_poly_doubles=16384 * 80,
+                 pre_nms_topk_train=2000, post_nms_topk_train=1000, rpn_batch=256, roi_batch=512):
         self.ctx = ctx
         cfg = ModelCfg()
         check(lib().amp_model_cfg_default(C.byref(cfg)), "amp_model_cfg_default")
@@ -33,6 +34,10 @@ class MaskRCNN:
         pad = lambda v: (int(v) + 31) // 32 * 32
         cfg.max_batch, cfg.max_h, cfg.max_w, cfg.max_out_hw = int(max_batch), pad(max_h), pad(max_w), int(max_out_hw)
         cfg.rle_pool_counts = int(rle_pool_counts)
+        cfg.train_enable = int(bool(train))
+        cfg.max_gt, cfg.max_poly_doubles = int(max_gt), int(max_poly_doubles)
+        cfg.pre_nms_topk_train, cfg.post_nms_topk_train = int(pre_nms_topk_train), int(post_nms_topk_train)
+        cfg.rpn_batch, cfg.roi_batch = int(rpn_batch), int(roi_batch)
         self.cfg = cfg
         self.num_classes = int(num_classes)
         self._h = C.c_void_p()
@@ -108,6 +113,34 @@ class MaskRCNN:
             out.append(dict(boxes=boxes[b, :k].copy(), scores=scores[b, :k].copy(),
                             classes=classes[b, :k].astype(np.int64), masks=masks, image_size=(h, w)))
         return out
+
+    LOSS_NAMES = ("loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc")
+
+    def forward_losses(self, images, gt, seed=0):
+        """Training-mode forward: the loss dict `model(data)` returns to LossEvalHook (ampis/data_utils.py:111-122).
+        images uint8 [B,H,W,3]; gt: per image dict(boxes [G,4], classes [G], polygons list of flat xy arrays)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8)
+        B, H, W, _ = images.shape
+        assert len(gt) == B
+        off = np.zeros(B + 1, dtype=np.int32)
+        for b, g in enumerate(gt):
+            off[b + 1] = off[b] + len(g["boxes"])
+        total = int(off[B])
+        boxes = np.ascontiguousarray(np.concatenate([np.asarray(g["boxes"], np.float32).reshape(-1, 4) for g in gt]) if total else np.zeros((0, 4), np.float32))
+        classes = np.ascontiguousarray(np.concatenate([np.asarray(g["classes"], np.int32).reshape(-1) for g in gt]) if total else np.zeros(0, np.int32), dtype=np.int32)
+        polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
+        assert len(polys) == total, "one polygon per instance"
+        poff = np.zeros(total + 1, dtype=np.int32)
+        if total:
+            poff[1:] = np.cumsum([len(p) for p in polys])
+        pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
+        g = Gt(B, off.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(C.POINTER(C.c_float)),
+               classes.ctypes.data_as(C.POINTER(C.c_int)), poff.ctypes.data_as(C.POINTER(C.c_int)),
+               pxy.ctypes.data_as(C.POINTER(C.c_double)))
+        out = (C.c_float * 5)()
+        check(lib().amp_model_forward_losses(self._h, images.ctypes.data_as(C.c_void_p), 1, B, H, W, C.byref(g), int(seed) & 0xFFFFFFFF, out),
+              "amp_model_forward_losses")
+        return {n: float(out[i]) for i, n in enumerate(self.LOSS_NAMES)}
 
     def tap(self, name):
         """Copy an intermediate device buffer of the last infer call to the host (parity tests)."""

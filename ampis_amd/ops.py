@@ -85,7 +85,7 @@ def rpn_decode(ctx, preds, shapes, B, k, sel_idx, sel_logit, sel_count, img_h, i
     dev = preds[0].device
     boxes, keys = torch.empty((B, cap, 4), device=dev), _u64(B, cap, device=dev)
     check(lib().amp_rpn_decode(ctx.handle, C.byref(lv), B, k, ptr(sel_idx), ptr(sel_logit), ptr(sel_count), img_h, img_w, cap,
-                               ptr(boxes), ptr(keys)), "amp_rpn_decode")
+                               ptr(boxes), ptr(keys), None), "amp_rpn_decode")
     return boxes, keys
 
 
@@ -95,7 +95,7 @@ def sort_gather(ctx, keys, boxes_in, box_stride=None):
     sb, ss, sc, cnt, pos = torch.empty((B, cap, 4), device=dev), torch.empty((B, cap), device=dev), _i32(B, cap, device=dev), \
         _i32(B, device=dev), _i32(B, cap, device=dev)
     check(lib().amp_sort_gather(ctx.handle, B, cap, box_stride or boxes_in.shape[1], ptr(keys), ptr(boxes_in), ptr(sb), ptr(ss),
-                                ptr(sc), ptr(cnt), ptr(pos)), "amp_sort_gather")
+                                ptr(sc), ptr(cnt), ptr(pos), None, None), "amp_sort_gather")
     return sb, ss, sc, cnt, pos
 
 

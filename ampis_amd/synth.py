@@ -15,7 +15,8 @@ def micrograph(index, h=1024, w=1024, seed=1234, mean_particles=200):
     scale = (h * w) / (1024.0 * 1536.0)
     area = np.exp(rng.normal(np.log(3952.0 * scale), 1.45, 4 * n))
     area = np.clip(area, 60.0, 29360.0 * scale)
-    boxes, classes, radii = [], [], []
+    boxes, classes, radii, polygons = [], [], [], []
+    ang32 = np.linspace(0.0, 2.0 * np.pi, 33)[:-1]
     placed = []
     for a in area:
         if len(placed) >= n:
@@ -44,9 +45,11 @@ def micrograph(index, h=1024, w=1024, seed=1234, mean_particles=200):
                 continue
             val = rng.normal(190.0, 15.0) - 45.0 * d2 / (r * r)   # radial shading
             img[y0:y1, x0:x1] = np.where(inside, val, img[y0:y1, x0:x1])
-            boxes.append([max(cx - r, 0), max(cy - r, 0), min(cx + r, w), min(cy + r, h)])
-            classes.append(cls)
+            poly = np.stack([np.clip(cx + r * np.cos(ang32), 0, w), np.clip(cy + r * np.sin(ang32), 0, h)], axis=1)   # 32-gon
+            boxes.append([poly[:, 0].min(), poly[:, 1].min(), poly[:, 0].max(), poly[:, 1].max()])   # bbox of the polygon,
+            classes.append(cls)                                                                   # as get_ddicts does (data_utils.py:471)
             radii.append(r)
+            polygons.append(poly.reshape(-1).astype(np.float64))
     # separable 5-tap Gaussian blur (sigma 1) + sensor noise
     k = np.exp(-0.5 * (np.arange(-2, 3) ** 2)).astype(np.float32)
     k /= k.sum()
@@ -57,7 +60,7 @@ def micrograph(index, h=1024, w=1024, seed=1234, mean_particles=200):
     u8 = np.clip(np.rint(img), 0, 255).astype(np.uint8)
     bgr = np.repeat(u8[:, :, None], 3, axis=2)
     gt = dict(boxes=np.asarray(boxes, np.float32).reshape(-1, 4), classes=np.asarray(classes, np.int64),
-              radii=np.asarray(radii, np.float32))
+              radii=np.asarray(radii, np.float32), polygons=polygons)
     return bgr, gt
 
 

@@ -107,11 +107,13 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
                  float* sel_logit, int* sel_count);
 /* decode + clip the selected anchors; sortkey = 0 for non-finite / empty boxes. boxes [B,cap,4], sortkey [B,cap]. */
 int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
-                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey);
+                   const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey,
+                   int* anchor_id /* [B,cap] global anchor index of each candidate, or NULL */);
 /* per image: order `cap` (<= 16384) 64-bit sort words descending; gather boxes_in[b][pos] (box_stride entries per image);
  * outputs sorted boxes/scores/categories [B,cap], the number of valid entries [B], optionally the source positions. */
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
-                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out);
+                    float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out,
+                    const int* payload_in /* [B,box_stride] or NULL */, int* payload_out /* [B,cap] or NULL */);
 
 /* Stages a12 / a15: batched greedy NMS on score-sorted boxes (cap <= 16384 per image) ---------- */
 /* mask_scratch: [B*cap*ceil(cap/64)] u64. keep_idx [B,max_keep] (positions, ascending), keep_count [B]. */
@@ -133,7 +135,8 @@ int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* pro
                        int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,
                        float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
 int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
-                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes);
+                    const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes,
+                    const int* payload_in /* [B,cap] or NULL */, int* payload_out /* [B,D] or NULL */);
 
 /* Stages a16 / a17 / a3: mask probability, paste + threshold + RLE counts ----------------------- */
 int amp_mask_prob(amp_ctx* ctx, const float* logits, const int* classes, int N, int K, float* prob);
@@ -141,6 +144,21 @@ int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const
                   const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
                   int* rle_len, int* overflow);
+
+/* Stage a18: training-mode label assignment, seeded sampling and losses (+ their gradients w.r.t. the network outputs) ---- */
+int amp_anchor_labels(amp_ctx* ctx, const amp_rpn_levels* lv, int B, const float* gt_boxes, const int* gt_off, int total_gt,
+                      float iou_lo, float iou_hi, float* match_val, int* match_idx, unsigned int* gt_best, signed char* label);
+int amp_rpn_sample_loss(amp_ctx* ctx, const amp_rpn_levels* lv, float* const dpred[5], int B, const float* gt_boxes,
+                        const int* gt_off, const signed char* label, const int* match_idx, uint32_t* keys_scratch, int batch,
+                        float pos_frac, unsigned int seed, int* sampled, int* counts, float* partial);
+int amp_roi_sample(amp_ctx* ctx, int B, const float* prop_boxes, const int* prop_count, int Pcap, const float* gt_boxes,
+                   const int* gt_classes, const int* gt_off, int K, int batch, float fg_frac, float iou_thresh, unsigned int seed,
+                   uint32_t* keys_scratch, int* cls_scratch, int* gti_scratch, int ncap, float* rois, int* roi_cls, int* roi_gti,
+                   int* counts, const int* prop_anchor /* [B,Pcap] stable ids for the sampling hash */, int num_anchors);
+int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int ld, float* dpred, const float* rois, const int* roi_cls,
+                 const int* roi_gti, const float* gt_boxes, const int* gt_off, const float reg_weights[4], int total_rois, float* partial);
+int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
+                         const int* poly_id, const double* poly_xy, const int* poly_off, float* partial, unsigned char* target_out);
 
 /* Host-side COCO RLE codec (all pointers HOST) --------------------------------------------------- */
 int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t* len);
@@ -165,7 +183,28 @@ typedef struct amp_model_cfg {
     int max_batch, max_h, max_w;     /* capacity: largest (padded) network input */
     int max_out_hw;                  /* capacity: largest side of an output (original) image */
     size_t rle_pool_counts;          /* capacity of the RLE run pool in uint32 (0 = default) */
+    /* training-mode forward (amp_model_forward_losses); train_enable = 0 skips its workspace */
+    int train_enable;
+    int pre_nms_topk_train, post_nms_topk_train;   /* MODEL.RPN.{PRE,POST}_NMS_TOPK_TRAIN (2000 / 1000) */
+    int rpn_batch;                   /* MODEL.RPN.BATCH_SIZE_PER_IMAGE (256) */
+    float rpn_pos_frac;              /* MODEL.RPN.POSITIVE_FRACTION (0.5) */
+    float rpn_iou_lo, rpn_iou_hi;    /* MODEL.RPN.IOU_THRESHOLDS (0.3, 0.7) */
+    int roi_batch;                   /* MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE (512) */
+    float roi_fg_frac;               /* MODEL.ROI_HEADS.POSITIVE_FRACTION (0.25) */
+    float roi_iou;                   /* MODEL.ROI_HEADS.IOU_THRESHOLDS (0.5) */
+    int max_gt;                      /* capacity: ground-truth instances per batch */
+    int max_poly_doubles;            /* capacity: polygon coordinates (doubles) per batch */
 } amp_model_cfg;
+/* Ground truth of one batch (all pointers HOST): instances of image b are [gt_off[b], gt_off[b+1]); one polygon per instance
+ * (flat x0,y0,x1,y1,... in input-image pixels), polygon of instance i = poly_xy[poly_off[i] .. poly_off[i+1]). */
+typedef struct amp_gt {
+    int B;
+    const int* gt_off;
+    const float* boxes;              /* [total,4] XYXY */
+    const int* classes;              /* [total] in [0, num_classes) */
+    const int* poly_off;             /* [total+1], in doubles */
+    const double* poly_xy;
+} amp_gt;
 /* Host view of the detections of the last amp_model_infer call; pointers stay valid until the next call. */
 typedef struct amp_dets {
     int B, D;                        /* images, capacity per image (detections_per_image) */
@@ -191,6 +230,10 @@ int  amp_model_finalize(amp_model* m);
  * image sizes the boxes/masks are rescaled to (NULL = network input size). */
 int  amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const int* out_h_h,
                      const int* out_w_h, amp_dets* out);
+/* Training-mode forward (what `model(data)` returns to LossEvalHook, ampis/data_utils.py:111-122):
+ * losses_h[5] = loss_cls, loss_box_reg, loss_mask, loss_rpn_cls, loss_rpn_loc. Sub-sampling is seeded (oracle/train.py). */
+int  amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                              unsigned int seed, float losses_h[5]);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
 int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
 

@@ -1,0 +1,109 @@
+"""Training-mode forward (amp_model_forward_losses, through the C ABI) against oracle/train.py on identical inputs, weights
+and sampling seed: anchor labels, sampled anchor / RoI sets, polygon mask targets, and the five losses."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_ctx):
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    K, B, H, W = 2, 2, 256, 320
+    imgs, gts = synth.batch(B, H, W, seed=5)
+    gts = [dict(boxes=g["boxes"][:60], classes=g["classes"][:60], polygons=g["polygons"][:60]) for g in gts]
+    npp = P.init_params(K, seed=1, style="spread")
+    cfg = T.TrainCfg(num_classes=K, seed=7)
+    st = {}
+    ref = T.forward_losses(imgs, gts, M.to_torch_params(npp), cfg, stages=st)
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=4096, max_poly_doubles=4096 * 64)
+    model.load_params(npp)
+    got = model.forward_losses(imgs, gts, seed=7)
+    return dict(model=model, got=got, ref={k: float(v) for k, v in ref.items()}, st=st, gts=gts, B=B, K=K)
+
+
+def test_anchor_labels_and_rpn_samples(setup):
+    from oracle import train as T
+    m, st, B = setup["model"], setup["st"], setup["B"]
+    label, sampled, counts = m.tap("rpn_label"), m.tap("rpn_sampled"), m.tap("rpn_counts")
+    anchors = st["anchors"]
+    for b in range(B):
+        gtb = torch.as_tensor(setup["gts"][b]["boxes"], dtype=torch.float32)
+        _, ml = T.matcher(T.pairwise_iou(gtb, anchors), (0.3, 0.7), (0, -1, 1), True)
+        assert np.array_equal(label[b], ml.numpy())                       # exact labels for all 60k+ anchors
+        pos, neg, _ = st["rpn_samples"][b]
+        assert counts[b, 0] == len(pos) and counts[b, 1] == len(neg)
+        assert np.array_equal(sampled[b, :len(pos)], pos.numpy())          # same seeded subset, same order
+        assert np.array_equal(sampled[b, len(pos):len(pos) + len(neg)], neg.numpy())
+
+
+def test_roi_samples_and_mask_targets(setup):
+    m, st, B, K = setup["model"], setup["st"], setup["B"], setup["K"]
+    rois, cls, gti, counts = m.tap("train_rois"), m.tap("train_roi_cls"), m.tap("train_roi_gti"), m.tap("train_roi_counts")
+    exact = 0
+    for b in range(B):
+        rc = st["roi_cls"][b].numpy()
+        n = len(rc)
+        assert counts[b, 0] + counts[b, 1] == n
+        assert counts[b, 0] == int((rc != K).sum())
+        assert np.array_equal(cls[b, :n], rc)
+        d = np.abs(rois[b, :n] - st["rois"][b].numpy()).max()
+        assert d < 5e-3                                                    # proposals differ by fp32 noise only
+        exact += int(np.array_equal(gti[b, :n][rc != K], st["roi_gtidx"][b].numpy()[rc != K]))
+    assert exact == B
+    tg = m.tap("train_mask_targets")
+    ref = st["mask_targets"].numpy().astype(np.uint8)
+    assert tg.shape == ref.shape
+    # targets are rasterised from the sampled RoI boxes: a box differing by 1e-4 px may move a polygon vertex across a
+    # rounding boundary of rleFrPoly's 5x grid; allow a handful of pixels over the whole batch
+    assert int((tg != ref).sum()) <= 0.002 * ref.size
+
+
+def test_losses_match_oracle(setup):
+    got, ref = setup["got"], setup["ref"]
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
+        assert got[k] == pytest.approx(ref[k], rel=2e-4, abs=1e-6), (k, got[k], ref[k])
+
+
+def test_polygon_rasteriser_exact_on_identical_boxes(gpu_ctx):
+    """amp_mask_target_loss on boxes given bit-identically to the oracle's rasterize_polygon_within_box: exact targets."""
+    import ctypes as C
+    from ampis_amd._lib import check, lib, ptr
+    from oracle import train as T
+    rng = np.random.default_rng(3)
+    N, K = 64, 1
+    th = np.linspace(0, 2 * np.pi, 33)[:-1]
+    polys, boxes = [], []
+    for i in range(N):
+        cx, cy, r = rng.uniform(30, 200), rng.uniform(30, 200), rng.uniform(3, 60)
+        p = np.stack([cx + r * np.cos(th) * rng.uniform(0.6, 1.0), cy + r * np.sin(th)], 1).reshape(-1)
+        if i % 7 == 0:
+            p = np.array([cx - r, cy - r, cx + r, cy - r, cx + r, cy + r, cx - r, cy + r], float)   # axis-aligned square
+        polys.append(p)
+        j = rng.uniform(-0.3, 0.3, 4) * r
+        boxes.append([cx - r + j[0], cy - r + j[1], cx + r + j[2], cy + r + j[3]])
+    boxes = np.asarray(boxes, np.float32)
+    poff = np.zeros(N + 1, np.int32); poff[1:] = np.cumsum([len(p) for p in polys])
+    d = "cuda:0"
+    t_boxes = torch.from_numpy(boxes).to(d)
+    t_cls = torch.zeros(N, dtype=torch.int32, device=d)
+    t_pid = torch.arange(N, dtype=torch.int32, device=d)
+    t_pxy = torch.from_numpy(np.concatenate(polys)).to(d)
+    t_poff = torch.from_numpy(poff).to(d)
+    logits = torch.randn(N, 28, 28, K, device=d)
+    part = torch.zeros(N, device=d)
+    tgt = torch.zeros(N, 784, dtype=torch.uint8, device=d)
+    check(lib().amp_mask_target_loss(gpu_ctx.handle, N, K, ptr(logits), None, ptr(t_boxes), ptr(t_cls), ptr(t_pid), ptr(t_pxy), ptr(t_poff),
+                                     ptr(part), ptr(tgt)))
+    torch.cuda.synchronize()
+    got = tgt.cpu().numpy().reshape(N, 28, 28)
+    for i in range(N):
+        ref = T.rasterize_polygon_within_box(polys[i], boxes[i], 28)
+        assert np.array_equal(got[i].astype(bool), ref), i
+    # per-RoI BCE sums
+    lg = logits.cpu()[..., 0]
+    ref_l = torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.from_numpy(got.astype(np.float32)), reduction="none").flatten(1).sum(1)
+    assert torch.allclose(part.cpu(), ref_l, rtol=1e-5, atol=1e-4)
