@@ -94,6 +94,11 @@ def _declare(L):
         "amp_memcpy_d2h": ([vp, vp, vp, C.c_size_t], i),
         "amp_memset": ([vp, vp, i, C.c_size_t], i),
         "amp_conv2d_nhwc": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp], i),
+        "amp_conv2d_nhwc_ex": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_conv_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
+        "amp_conv2d_wgrad": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i], i),
+        "amp_colsum": ([vp, vp, i, i, vp, vp, i], i),
+        "amp_dgrad_weights": ([vp, vp, vp, i, i, i, i, vp], i),
         "amp_preprocess": ([vp, vp, i, i, i, i, i, C.POINTER(f), C.POINTER(f), vp], i),
         "amp_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),
         "amp_subsample2": ([vp, vp, i, i, i, i, vp], i),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <algorithm>
 #include <string>
 
 #include "../../include/ampis_hip.h"

@@ -30,6 +30,7 @@ struct ConvArgs {
     const float* scale;
     const float* shift;
     const float* res;
+    const float* mask;   // optional, indexed like y: y = mask > 0 ? y : 0 (ReLU backward of the tensor the gradient belongs to)
     float* y;
     int B, H, W, Cin;
     int Ho, Wo, Cout;
@@ -110,6 +111,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
                 const int co = n - kk * C2;
                 const int oy2 = 2 * oy + (kk >> 1), ox2 = 2 * ox + (kk & 1);
                 yoff[it] = ((size_t)(b * 2 * a.Ho + oy2) * (2 * a.Wo) + ox2) * C2 + co;
+            } else if (a.out_mode == 2) {   // stride-2 scatter into a [B,2Ho,2Wo,Cout] tensor (data gradient of a strided 1x1 conv)
+                yoff[it] = ((size_t)(b * 2 * a.Ho + 2 * oy) * (2 * a.Wo) + 2 * ox) * a.Cout + n;
             }
         }
     }
@@ -125,6 +128,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
             if (a.res_mode != 0) t = __fadd_rn(t, rres[it][q]);
             if (a.relu) t = fmaxf(t, 0.f);
             o[q] = t;
+        }
+        if (a.mask) {
+            if (vec) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + yoff[it]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = mk[q] > 0.f ? o[q] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < a.Cout) o[q] = a.mask[yoff[it] + q] > 0.f ? o[q] : 0.f;
+            }
         }
         if (vec) {
             *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
@@ -443,17 +457,25 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
 static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
 extern "C" void amp_debug_set_conv_ablate(int mode) { g_conv_ablate = mode; }
 
+extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
+                                  const float* shift, const float* res, const float* mask, float* y);
+
 extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                                const float* scale, const float* shift, const float* res, float* y) {
+    return amp_conv2d_nhwc_ex(ctx, d, x, w, scale, shift, res, nullptr, y);
+}
+
+extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
+                                  const float* shift, const float* res, const float* mask, float* y) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
     AMP_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "amp_conv2d_nhwc: bad window");
-    AMP_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && d->out_mode >= 0 && d->out_mode <= 1,
+    AMP_REQUIRE(d->res_mode >= 0 && d->res_mode <= 2 && d->out_mode >= 0 && d->out_mode <= 2,
                 "amp_conv2d_nhwc: bad res_mode/out_mode");
     AMP_REQUIRE(d->res_mode == 0 || res != nullptr, "amp_conv2d_nhwc: res_mode=%d needs res", d->res_mode);
     ConvArgs a;
-    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.mask = mask; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;

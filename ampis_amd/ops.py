@@ -25,7 +25,7 @@ def _f32c(t):
 
 
 def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, res_mode=None,
-                deconv2x2=False):
+                deconv2x2=False, mask=None, scatter2=False, out=None):
     """x [B,H,W,Cin], w [Cout,KH,KW,Cin] -> y [B,Ho,Wo,Cout] (or [B,2Ho,2Wo,Cout/4] when deconv2x2)."""
     _f32c(x), _f32c(w), _f32c(scale), _f32c(shift), _f32c(res)
     B, H, W, Cin = x.shape
@@ -35,14 +35,48 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
     Wo = (W + 2 * pad - KW) // stride + 1
     if res_mode is None:
         res_mode = 0 if res is None else 1
-    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), int(res_mode), int(deconv2x2))
-    if deconv2x2:
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), int(res_mode), 2 if scatter2 else int(deconv2x2))
+    if out is not None:
+        y = out
+    elif deconv2x2:
         y = torch.empty((B, 2 * Ho, 2 * Wo, Cout // 4), device=x.device, dtype=torch.float32)
+    elif scatter2:
+        y = torch.zeros((B, 2 * Ho, 2 * Wo, Cout), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    check(lib().amp_conv2d_nhwc(ctx.handle, C.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y)),
-          "amp_conv2d_nhwc")
+    check(lib().amp_conv2d_nhwc_ex(ctx.handle, C.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(_f32c(mask)), ptr(y)),
+          "amp_conv2d_nhwc_ex")
     return y
+
+
+def conv2d_wgrad(ctx, x, dy, w_shape, stride=1, pad=0, scale=None, grad=None):
+    """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dW [Cout,KH,KW,Cin] (accumulated into `grad` when given)."""
+    _f32c(x), _f32c(dy)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w_shape
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0, 0)
+    n = lib().amp_conv_wgrad_scratch_floats(C.byref(d))
+    scratch = torch.empty(n, device=x.device)
+    acc = grad is not None
+    if grad is None:
+        grad = torch.empty(w_shape, device=x.device)
+    check(lib().amp_conv2d_wgrad(ctx.handle, C.byref(d), ptr(x), ptr(dy), ptr(scale), ptr(scratch), ptr(grad), int(acc)), "amp_conv2d_wgrad")
+    return grad
+
+
+def dgrad_weights(ctx, w, scale=None):
+    Cout, KH, KW, Cin = w.shape
+    wt = torch.empty((Cin, KH, KW, Cout), device=w.device)
+    check(lib().amp_dgrad_weights(ctx.handle, ptr(_f32c(w)), ptr(scale), Cout, KH, KW, Cin, ptr(wt)), "amp_dgrad_weights")
+    return wt
+
+
+def colsum(ctx, dy):
+    M, N = dy.shape
+    scratch = torch.empty(((M + 4095) // 4096 + 1) * N, device=dy.device)
+    out = torch.empty(N, device=dy.device)
+    check(lib().amp_colsum(ctx.handle, ptr(_f32c(dy)), M, N, ptr(scratch), ptr(out), 0), "amp_colsum")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------

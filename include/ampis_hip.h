@@ -80,11 +80,26 @@ typedef struct amp_conv_desc {
     int KH, KW, stride, pad;
     int relu;                 /* 1: y = max(y, 0) after the affine and the residual */
     int res_mode;             /* 0 none; 1 res[B,Ho,Wo,Cout] added; 2 res[B,Ho/2,Wo/2,Cout] nearest-upsampled x2 then added (FPN top-down) */
-    int out_mode;             /* 0 NHWC [B,Ho,Wo,Cout]; 1 ConvTranspose 2x2 s2 scatter: Cout = 4*C2 ordered (ky,kx,co) -> y[B,2Ho,2Wo,C2] */
+    int out_mode;             /* 0 NHWC [B,Ho,Wo,Cout]; 1 ConvTranspose 2x2 s2 scatter: Cout = 4*C2 ordered (ky,kx,co) -> y[B,2Ho,2Wo,C2];
+                                 2 stride-2 scatter: row (b,oy,ox) -> y[B,2Ho,2Wo,Cout] at (2oy,2ox), y pre-zeroed (dgrad of a strided 1x1) */
 } amp_conv_desc;
 /* y = act( conv(x, w) * scale[c] + shift[c] (+ res) ); scale may be NULL (= 1), shift may be NULL (= 0). */
 int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                     const float* scale, const float* shift, const float* res, float* y);
+/* same, with an optional mask tensor indexed like y: y = mask > 0 ? y : 0 (applied last; the ReLU backward of a data gradient) */
+int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
+                       const float* res, const float* mask, float* y);
+
+/* Stage a19: backward building blocks -------------------------------------------------------------------------------- */
+/* dW[Cout][KH][KW][Cin] (= or +=) scale[n] * conv-wgrad(dy [B*Ho*Wo, Cout], x [B,H,W,Cin]); `d` describes the FORWARD conv.
+ * Cin % 128 == 0, Cout % 4 == 0. scratch: amp_conv_wgrad_scratch_floats(d) floats. Deterministic (split-K slabs, fixed-order sum). */
+size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d);
+int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
+                     float* grad, int accumulate);
+/* out[n] (= or +=) sum_m dy[m][n]; scratch >= ceil(M/4096)*N floats */
+int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
+/* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
+int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
 
 
 /* Stage a8 / a9 / a10: memory-bound NHWC helpers --------------------------------------------- */
