@@ -254,7 +254,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     }
 
     // ---------------- RPN head ----------------
-    const int ld_rpn = 15;
+    const int ld_rpn = 16;   // 3 logits + 12 deltas + 1 zero pad column
     amp_rpn_levels lv;
     memset(&lv, 0, sizeof(lv));
     lv.nlevels = 5; lv.A = 3; lv.ld = ld_rpn;
@@ -363,7 +363,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
 
     // ---------------- box head ----------------
     const int R = B * Rcap;
-    const int ld_box = 5 * K + 1;
+    const int ld_box = (5 * K + 1 + 3) / 4 * 4;
     AMP_ALLOC(pooled, float, (size_t)R * 49 * 256);
     AMP_ALLOC(fc1, float, (size_t)R * 1024);
     AMP_ALLOC(fc2, float, (size_t)R * 1024);
@@ -422,7 +422,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(mpooled, float, (size_t)std::max(N, 1) * 196 * 256);
     AMP_ALLOC(mt_a, float, (size_t)std::max(N, 1) * 196 * 256);
     AMP_ALLOC(mt_b, float, (size_t)std::max(N, 1) * 784 * 256);
-    AMP_ALLOC(mlogits, float, (size_t)std::max(N, 1) * 784 * K);
+    const int Kp = (K + 3) / 4 * 4;
+    AMP_ALLOC(mlogits, float, (size_t)std::max(N, 1) * 784 * Kp);
     AMP_ALLOC(mprob, float, (size_t)std::max(N, 1) * 784);
     AMP_ALLOC(o_boxes, float, (size_t)std::max(N, 1) * 4);
     AMP_ALLOC(o_valid, int, (size_t)std::max(N, 1));
@@ -458,7 +459,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
-        AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, K, mprob));
+        AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
         AMP_TRY(amp_paste_rle(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, c.mask_threshold, o_boxes,
                               o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1));
         tap(m, "mask_prob", mprob, 0, {N, 28, 28});
@@ -568,7 +569,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(roi_gti, int, (size_t)B * RB);
     AMP_ALLOC(roi_counts, int, (size_t)B * 2);
     const int R = B * RB;
-    const int ld_box = 5 * K + 1;
+    const int ld_box = (5 * K + 1 + 3) / 4 * 4;
     AMP_ALLOC(roi_batch_idx, int, (size_t)R);
     AMP_ALLOC(pooled, float, (size_t)R * 49 * 256);
     AMP_ALLOC(fc1, float, (size_t)R * 1024);
@@ -616,7 +617,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(mpooled, float, (size_t)Nc * 196 * 256);
     AMP_ALLOC(mt_a, float, (size_t)Nc * 196 * 256);
     AMP_ALLOC(mt_b, float, (size_t)Nc * 784 * 256);
-    AMP_ALLOC(mlogits, float, (size_t)Nc * 784 * K);
+    const int Kp = (K + 3) / 4 * 4;
+    AMP_ALLOC(mlogits, float, (size_t)Nc * 784 * Kp);
     AMP_ALLOC(m_partial, float, (size_t)Nc);
     AMP_ALLOC(m_targets, unsigned char, (size_t)Nc * 784);
     if (dry) return AMP_OK;
@@ -644,10 +646,10 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
-        AMP_TRY(amp_mask_target_loss(ctx, N, K, mlogits, nullptr, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
+        AMP_TRY(amp_mask_target_loss(ctx, N, Kp, mlogits, nullptr, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
         AMP_HIP_CHECK(hipMemcpyAsync(h_mpart.data(), m_partial, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
         tap(m, "train_mask_targets", m_targets, 4, {N, 28, 28});
-        tap(m, "train_mask_logits", mlogits, 0, {N, 28, 28, K});
+        tap(m, "train_mask_logits", mlogits, 0, {N, 28, 28, Kp});
     }
     std::vector<float> h_rpn(2 * B), h_box(2 * B);
     AMP_HIP_CHECK(hipMemcpyAsync(h_rpn.data(), rpn_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -835,6 +837,19 @@ int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, c
             for (int q = 0; q < 4; ++q) for (int co = 0; co < 256; ++co) v[q * 256 + co] = data[co];
             AMP_TRY(put_shift(prefix, v));
         }
+    } else if (prefix == "roi_heads.mask_head.predictor") {
+        const int Kp = (K + 3) / 4 * 4;
+        if (is_w) {
+            AMP_REQUIRE(numel == (size_t)K * 256, "%s: expected [%d,256,1,1]", name_c, K);
+            std::vector<float> v((size_t)Kp * 256, 0.f);
+            memcpy(v.data(), data, numel * 4);
+            AMP_TRY(put_conv(prefix, std::move(v), Kp, 256, 1, 1));
+        } else {
+            AMP_REQUIRE(numel == (size_t)K, "%s: expected [%d]", name_c, K);
+            std::vector<float> v(Kp, 0.f);
+            memcpy(v.data(), data, numel * 4);
+            AMP_TRY(put_shift(prefix, v));
+        }
     } else if (is_w) {
         AMP_REQUIRE(ndim == 4, "%s: expected a 4-d conv weight", name_c);
         const int O = (int)shape[0], I = (int)shape[1], KH = (int)shape[2], KW = (int)shape[3];
@@ -876,7 +891,8 @@ int amp_model_finalize(amp_model* m) {
         AMP_TRY(upload(m, cw.shift, sh));
     }
     auto fuse = [&](const char* key, const char* a, const char* b, int ra, int rb, int cols) -> int {
-        std::vector<float> w((size_t)(ra + rb) * cols), bias(ra + rb);
+        const int rp = (ra + rb + 3) / 4 * 4;   // rows padded to a multiple of 4 (zero rows): 16-byte output rows
+        std::vector<float> w((size_t)rp * cols, 0.f), bias(rp, 0.f);
         const auto& wa = m->host_raw.at(std::string(a) + ".weight");
         const auto& wb = m->host_raw.at(std::string(b) + ".weight");
         const auto& ba = m->host_raw.at(std::string(a) + ".bias");
@@ -888,7 +904,7 @@ int amp_model_finalize(amp_model* m) {
         ConvW& cw = m->conv[key];
         if (!cw.w) { cw.w = palloc(m, w.size()); cw.shift = palloc(m, bias.size()); }
         AMP_REQUIRE(cw.w && cw.shift, "amp_model_finalize: parameter arena exhausted");
-        cw.cout = ra + rb; cw.cin = cols; cw.kh = cw.kw = 1;
+        cw.cout = rp; cw.cin = cols; cw.kh = cw.kw = 1;
         AMP_TRY(upload(m, cw.w, w));
         return upload(m, cw.shift, bias);
     };

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void anchor_label_kernel(const AnchorGeom g, c
 // ---- RPN: sample 256 anchors / image, BCE + L1 losses and their gradients -----------------------------------------------------
 struct RpnLossArgs {
     AnchorGeom g;
-    const float* pred[NL];        // [B, hw, 15]
+    const float* pred[NL];        // [B, hw, ld]: 3 logits, 12 deltas (+ padding)
+    int ld;
     float* dpred[NL];             // same shape, zero-filled by the caller; receives d(loss)/d(pred) (may be null)
     const float* gt_boxes;
     const int* gt_off;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(1024) void rpn_sample_loss_kernel(const RpnLossArgs
         int lvl, local;
         anchor_box(a.g, an, x1, y1, x2, y2, lvl, local);
         const int pix = local / 3, k = local - pix * 3;
-        const size_t row = ((size_t)b * a.g.hw[lvl] + pix) * 15;
+        const size_t row = ((size_t)b * a.g.hw[lvl] + pix) * a.ld;
         const float* p = a.pred[lvl] + row;
         float* dp = a.dpred[lvl] ? a.dpred[lvl] + row : nullptr;
         const float x = p[k];
@@ -505,6 +506,7 @@ int amp_rpn_sample_loss(amp_ctx* ctx, const amp_rpn_levels* lv, float* const dpr
     RpnLossArgs a;
     fill_geom(a.g, lv);
     for (int l = 0; l < NL; ++l) { a.pred[l] = lv->pred[l]; a.dpred[l] = dpred ? dpred[l] : nullptr; }
+    a.ld = lv->ld;
     a.gt_boxes = gt_boxes; a.gt_off = gt_off; a.label = label; a.match_idx = match_idx; a.keys_scratch = keys_scratch;
     a.batch = batch; a.num_pos_max = (int)(batch * pos_frac); a.seed = seed; a.inv_norm = 1.0f / (float)(batch * B);
     a.sampled = sampled; a.counts = counts; a.partial = partial;

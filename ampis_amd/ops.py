@@ -92,7 +92,7 @@ def _u64(*shape, device="cuda:0"):
 
 def make_rpn_levels(preds, shapes, strides=(4, 8, 16, 32, 64), sizes=(32, 64, 128, 256, 512)):
     lv = _lib.RpnLevels()
-    lv.nlevels, lv.A, lv.ld = len(preds), 3, 15
+    lv.nlevels, lv.A, lv.ld = len(preds), 3, preds[0].shape[-1]
     for i, (p, (h, w)) in enumerate(zip(preds, shapes)):
         _f32c(p)
         lv.pred[i] = p.data_ptr()

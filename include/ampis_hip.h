@@ -100,6 +100,16 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
+/* dfeat[level] += RoIAlign-backward(dout [R,P,P,C]) (float atomics: reproducible to fp32 rounding, not bitwise) */
+int amp_roi_align_bwd(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
+                      const int* batch_idx, int R, int P, const float* dout);
+int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C);   /* dcoarse += 2x2 sums */
+int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, int W, int C);           /* dx[::2, ::2] += dy */
+int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n);                                  /* g *= (act > 0) */
+int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx, size_t npix);
+int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate);
+/* torch.optim.SGD: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
+int amp_sgd_update(amp_ctx* ctx, float* p, const float* g, float* v, size_t n, float lr, float momentum, float weight_decay, float grad_scale);
 
 
 /* Stage a8 / a9 / a10: memory-bound NHWC helpers --------------------------------------------- */

@@ -15,10 +15,11 @@ DEV = "cuda:0"
 def _levels(B, rng, shapes, ties=False):
     preds = []
     for (h, w) in shapes:
-        p = rng.normal(0, 2, (B, h * w, 15)).astype(np.float32)
+        p = rng.normal(0, 2, (B, h * w, 16)).astype(np.float32)
         if ties:   # heavy exact ties: quantise logits so the index tie-break is exercised everywhere
             p[:, :, :3] = np.round(p[:, :, :3] * 2) / 2
         p[:, :, 3:] *= 0.3
+        p[:, :, 15] = 0
         preds.append(torch.from_numpy(p))
     return preds
 
@@ -57,7 +58,7 @@ def test_rpn_decode_and_sort(gpu_ctx):
     sb, ss, scat, cnt, pos = ops.sort_gather(gpu_ctx, keys, boxes)
     torch.cuda.synchronize()
     cfg = O.Cfg(num_classes=2, pre_nms_topk=k)
-    outs = [(p[:, :, :3].reshape(B, -1), p[:, :, 3:].reshape(B, -1, 4)) for p in preds]
+    outs = [(p[:, :, :3].reshape(B, -1), p[:, :, 3:15].reshape(B, -1, 4)) for p in preds]
     cands = O.rpn_select_candidates(outs, shapes, cfg)
     for b in range(B):
         cb, cl, clv = cands[b][0], cands[b][1], cands[b][2]

@@ -26,7 +26,7 @@ for i, n in enumerate(["res2", "res3", "res4", "res5"]):
 for i, n in enumerate(["p2", "p3", "p4", "p5", "p6"]):
     print(n, _relerr(m.tap(n), _nhwc(st["feats"][i])))
 for i, n in enumerate(["rpn_pred2", "rpn_pred3", "rpn_pred4", "rpn_pred5", "rpn_pred6"]):
-    lg, dl = st["rpn_outs"][i]; got = m.tap(n); Bq, HW, _ = got.shape
+    lg, dl = st["rpn_outs"][i]; got = m.tap(n)[:, :, :15]; Bq, HW, _ = got.shape
     r = np.concatenate([lg.numpy().reshape(Bq, HW, 3), dl.numpy().reshape(Bq, HW, 12)], 2)
     print(n, _relerr(got, r))
 si, sl = m.tap("rpn_sel_idx"), m.tap("rpn_sel_logit")
