@@ -133,6 +133,17 @@ def _declare(L):
         "amp_roi_sample": ([vp, i, vp, vp, i, vp, vp, vp, i, i, f, f, C.c_uint, vp, vp, vp, i, vp, vp, vp, vp, vp, i], i),
         "amp_box_loss": ([vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, C.POINTER(f), i, vp], i),
         "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_model_forward_backward": ([vp, vp, i, i, i, i, C.POINTER(Gt), C.c_uint, C.POINTER(f)], i),
+        "amp_model_grad_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
+        "amp_model_sgd_step": ([vp, f, f, f, f], i),
+        "amp_model_get_tensor": ([vp, C.c_char_p, i, vp, C.c_size_t], i),
+        "amp_roi_align_bwd": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp], i),
+        "amp_upsample2_bwd": ([vp, vp, vp, i, i, i, i], i),
+        "amp_subsample2_bwd": ([vp, vp, vp, i, i, i, i], i),
+        "amp_relu_mask": ([vp, vp, vp, C.c_size_t], i),
+        "amp_small_k_dgrad": ([vp, vp, i, i, vp, i, vp, vp, C.c_size_t], i),
+        "amp_deconv_grad_transpose": ([vp, vp, vp, i, i, i, i], i),
+        "amp_sgd_update": ([vp, vp, vp, vp, C.c_size_t, f, f, f, f], i),
         "amp_model_get_tap": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_longlong)], i),
     }
     for name, (args, res) in sig.items():

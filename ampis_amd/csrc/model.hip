@@ -81,6 +81,17 @@ struct amp_model {
     std::vector<uint32_t> r_pool;
     std::vector<int> r_out_h, r_out_w;
     float last_stage_ms[8];
+    // ---- training ----
+    float* garena = nullptr;            // gradients, same offsets as parena
+    float* varena = nullptr;            // SGD momentum buffers, same offsets
+    bool saving = false;                // run_trunk keeps every activation the backward pass needs
+    struct BlockAct { std::string key; float *x_in, *t1, *t2, *sc, *out; int in_h, in_w, oh, ow, cin, mid, cout, stride, stage; bool has_sc; };
+    std::vector<BlockAct> blocks;
+    float* lat[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* rpn_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    struct Trainable { float* p; size_t n; };
+    std::vector<Trainable> trainable;
+    bool grads_valid = false;
 };
 
 namespace {
@@ -178,6 +189,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     amp_ctx* ctx = m->ctx;
     ws.off = 0;
     if (!dry) m->taps.clear();
+    m->blocks.clear();
     const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
     auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
 
@@ -219,7 +231,15 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
                 AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out));
             }
             (void)mark;
-            ws.off = keep;   // release sc/t1/t2 (stream order makes reuse safe)
+            if (m->saving) {
+                amp_model::BlockAct ba;
+                ba.key = p; ba.x_in = cur; ba.t1 = t1; ba.t2 = t2; ba.sc = (b == 0) ? const_cast<float*>(shortcut) : nullptr; ba.out = out;
+                ba.in_h = ch; ba.in_w = cw_; ba.oh = oh; ba.ow = ow; ba.cin = (b == 0) ? (s == 0 ? 64 : kOut[s - 1]) : kOut[s];
+                ba.mid = kMid[s]; ba.cout = kOut[s]; ba.stride = st; ba.stage = s; ba.has_sc = (b == 0);
+                if (!dry) m->blocks.push_back(ba);
+            } else {
+                ws.off = keep;   // release sc/t1/t2 (stream order makes reuse safe)
+            }
             cur = out;
             ch = oh; cw_ = ow;
         }
@@ -242,6 +262,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp));
         }
         prev_lat = lat;
+        m->lat[s] = lat;
         feat[s] = outp; fh[s] = res_h[s]; fw[s] = res_w[s];
     }
     fh[4] = (fh[3] - 1) / 2 + 1; fw[4] = (fw[3] - 1) / 2 + 1;
@@ -270,7 +291,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.pred"), t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred));
         }
         (void)mark;
-        ws.off = keep;
+        if (m->saving) m->rpn_t[l] = t; else ws.off = keep;
         lv.pred[l] = pred; lv.h[l] = fh[l]; lv.w[l] = fw[l]; lv.stride[l] = fstride[l]; lv.anchor_size[l] = asz[l];
         max_n = std::max(max_n, fh[l] * fw[l] * 3);
         if (!dry) {
@@ -512,7 +533,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
 }
 
 // Training-mode forward + losses. With ws.dry nothing is launched (workspace sizing only).
-int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const amp_gt* gt, unsigned int seed, float losses[5]) {
+int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const amp_gt* gt, unsigned int seed, float losses[5], bool backward) {
     Bump& ws = m->ws;
     const bool dry = ws.dry;
     const amp_model_cfg& c = m->cfg;
@@ -520,7 +541,10 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const int K = c.num_classes;
     auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
     Trunk T;
-    AMP_TRY(run_trunk(m, imgs_d, B, H, W, T));
+    m->saving = backward;
+    const int trunk_status = run_trunk(m, imgs_d, B, H, W, T);
+    m->saving = false;
+    AMP_TRY(trunk_status);
     const int total_gt = dry ? c.max_gt : gt->gt_off[B];
     const int npoly = dry ? c.max_poly_doubles : gt->poly_off[total_gt];
     AMP_REQUIRE(total_gt <= c.max_gt && npoly <= c.max_poly_doubles, "amp_model_forward_losses: %d instances / %d polygon doubles exceed cfg.max_gt / max_poly_doubles", total_gt, npoly);
@@ -540,6 +564,14 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(rpn_sampled, int, (size_t)B * c.rpn_batch);
     AMP_ALLOC(rpn_counts, int, (size_t)B * 2);
     AMP_ALLOC(rpn_partial, float, (size_t)B * 2);
+    float* d_rpn_pred[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (backward) {
+        for (int l = 0; l < 5; ++l) {
+            AMP_ALLOC(dp, float, (size_t)B * T.fh[l] * T.fw[l] * T.lv.ld);
+            d_rpn_pred[l] = dp;
+            if (!dry) AMP_HIP_CHECK(hipMemsetAsync(dp, 0, (size_t)B * T.fh[l] * T.fw[l] * T.lv.ld * 4, ctx->stream));
+        }
+    }
     if (!dry) {
         AMP_HIP_CHECK(hipMemcpyAsync(d_gt_off, gt->gt_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(d_poly_off, gt->poly_off, (size_t)(total_gt + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -549,7 +581,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         if (npoly) AMP_HIP_CHECK(hipMemcpyAsync(d_poly_xy, gt->poly_xy, (size_t)npoly * 8, hipMemcpyHostToDevice, ctx->stream));
         AMP_TRY(amp_anchor_labels(ctx, &T.lv, B, d_gt_boxes, d_gt_off, total_gt, c.rpn_iou_lo, c.rpn_iou_hi, match_val, match_idx, gt_best, label));
-        AMP_TRY(amp_rpn_sample_loss(ctx, &T.lv, nullptr, B, d_gt_boxes, d_gt_off, label, match_idx, keys, c.rpn_batch, c.rpn_pos_frac, seed,
+        AMP_TRY(amp_rpn_sample_loss(ctx, &T.lv, backward ? d_rpn_pred : nullptr, B, d_gt_boxes, d_gt_off, label, match_idx, keys, c.rpn_batch, c.rpn_pos_frac, seed,
                                     rpn_sampled, rpn_counts, rpn_partial));
         tap(m, "rpn_label", label, 3, {B, A});
         tap(m, "rpn_match_idx", match_idx, 1, {B, A});
@@ -576,6 +608,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(fc2, float, (size_t)R * 1024);
     AMP_ALLOC(box_pred, float, (size_t)R * ld_box);
     AMP_ALLOC(box_partial, float, (size_t)B * 2);
+    float* d_box_pred = nullptr;
+    if (backward) { AMP_ALLOC(dbp, float, (size_t)R * ld_box); d_box_pred = dbp; }
     std::vector<int> h_counts(2 * B, 0), h_cls, h_gti;
     if (!dry) {
         AMP_TRY(amp_roi_sample(ctx, B, PR.boxes, PR.count, PR.Rcap, d_gt_boxes, d_gt_cls, d_gt_off, K, RB, c.roi_fg_frac, c.roi_iou, seed, rkeys,
@@ -605,7 +639,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     if (!dry) {
         for (int b = 0; b < B; ++b) { total_rois += h_counts[2 * b] + h_counts[2 * b + 1]; fg_off[b + 1] = fg_off[b] + h_counts[2 * b]; }
         N = fg_off[B];
-        AMP_TRY(amp_box_loss(ctx, B, RB, K, box_pred, ld_box, nullptr, rois, roi_cls, roi_gti, d_gt_boxes, d_gt_off, c.bbox_reg_weights, total_rois,
+        AMP_TRY(amp_box_loss(ctx, B, RB, K, box_pred, ld_box, d_box_pred, rois, roi_cls, roi_gti, d_gt_boxes, d_gt_off, c.bbox_reg_weights, total_rois,
                              box_partial));
     }
     // mask branch on the foreground RoIs (the first nfg of every image's sample)
@@ -621,9 +655,16 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(mlogits, float, (size_t)Nc * 784 * Kp);
     AMP_ALLOC(m_partial, float, (size_t)Nc);
     AMP_ALLOC(m_targets, unsigned char, (size_t)Nc * 784);
-    if (dry) return AMP_OK;
+    float *macts[5] = {mpooled, mt_a, mpooled, mt_a, mpooled};   // input, fcn1..fcn4 outputs (ping-pong in eval mode)
+    float* d_mlogits = nullptr;
+    if (backward) {
+        for (int i = 1; i <= 4; ++i) { AMP_ALLOC(ma, float, (size_t)Nc * 196 * 256); macts[i] = ma; }
+        AMP_ALLOC(dml, float, (size_t)Nc * 784 * Kp);
+        d_mlogits = dml;
+    }
+    if (dry && !backward) return AMP_OK;
     std::vector<float> h_mpart(N);
-    if (N > 0) {
+    if (N > 0 && !dry) {
         std::vector<int> hb(N), hc(N), hp(N);
         for (int b = 0; b < B; ++b) {
             const int nb = fg_off[b + 1] - fg_off[b];
@@ -640,30 +681,241 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_HIP_CHECK(hipMemcpyAsync(m_poly, hp.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // hb/hc/hp are temporaries
         AMP_TRY(amp_roi_align(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
+        for (int i = 1; i <= 4; ++i) {
+            const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
+            AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i]));
+        }
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
-        AMP_TRY(amp_mask_target_loss(ctx, N, Kp, mlogits, nullptr, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
+        AMP_TRY(amp_mask_target_loss(ctx, N, Kp, mlogits, d_mlogits, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
         AMP_HIP_CHECK(hipMemcpyAsync(h_mpart.data(), m_partial, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
         tap(m, "train_mask_targets", m_targets, 4, {N, 28, 28});
         tap(m, "train_mask_logits", mlogits, 0, {N, 28, 28, Kp});
     }
-    std::vector<float> h_rpn(2 * B), h_box(2 * B);
-    AMP_HIP_CHECK(hipMemcpyAsync(h_rpn.data(), rpn_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    AMP_HIP_CHECK(hipMemcpyAsync(h_box.data(), box_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    float s_bce = 0.f, s_loc = 0.f, s_ce = 0.f, s_l1 = 0.f, s_mask = 0.f;
-    for (int b = 0; b < B; ++b) { s_bce += h_rpn[2 * b]; s_loc += h_rpn[2 * b + 1]; s_ce += h_box[2 * b]; s_l1 += h_box[2 * b + 1]; }
-    for (int i = 0; i < N; ++i) s_mask += h_mpart[i];
-    const float rpn_norm = (float)(c.rpn_batch * B);
-    losses[0] = total_rois ? s_ce / (float)total_rois : 0.f;
-    losses[1] = s_l1 / (float)std::max(total_rois, 1);
-    losses[2] = N ? s_mask / ((float)N * 784.f) : 0.f;
-    losses[3] = s_bce / rpn_norm;
-    losses[4] = s_loc / rpn_norm;
+    if (!dry) {
+        std::vector<float> h_rpn(2 * B), h_box(2 * B);
+        AMP_HIP_CHECK(hipMemcpyAsync(h_rpn.data(), rpn_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(h_box.data(), box_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        float s_bce = 0.f, s_loc = 0.f, s_ce = 0.f, s_l1 = 0.f, s_mask = 0.f;
+        for (int b = 0; b < B; ++b) { s_bce += h_rpn[2 * b]; s_loc += h_rpn[2 * b + 1]; s_ce += h_box[2 * b]; s_l1 += h_box[2 * b + 1]; }
+        for (int i = 0; i < N; ++i) s_mask += h_mpart[i];
+        const float rpn_norm = (float)(c.rpn_batch * B);
+        losses[0] = total_rois ? s_ce / (float)total_rois : 0.f;
+        losses[1] = s_l1 / (float)std::max(total_rois, 1);
+        losses[2] = N ? s_mask / ((float)N * 784.f) : 0.f;
+        losses[3] = s_bce / rpn_norm;
+        losses[4] = s_loc / rpn_norm;
+    }
+    if (!backward) return AMP_OK;
+
+    // =============================================== backward ===============================================
+    // Gradients of the five losses (each with weight 1) w.r.t. every trainable parameter, into m->garena (same offsets as the
+    // parameters).  Stem and res2 are frozen (FREEZE_AT = 2), FrozenBN has no parameters; its scale is folded into the weight
+    // transforms (data gradients) and the wgrad reduce (weight gradients).
+    const size_t WG_SCRATCH = (size_t)64 << 20;     // floats: split-K slabs of the largest layer
+    const size_t WT_SCRATCH = (size_t)13 << 20;     // floats: transformed weights of the largest layer (fc1: 12.85 M)
+    AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
+    AMP_ALLOC(wt_scratch, float, WT_SCRATCH);
+    AMP_ALLOC(cs_scratch, float, (size_t)1 << 20);
+    auto GW = [&](const ConvW& cw) { return m->garena + (cw.w - m->parena); };
+    auto GB = [&](const ConvW& cw) { return m->garena + (cw.shift - m->parena); };
+    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc) -> int {
+        amp_conv_desc d;
+        d.B = B_; d.H = H_; d.W = W_; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw; d.stride = stride; d.pad = pad;
+        d.relu = 0; d.res_mode = 0; d.out_mode = 0;
+        AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
+        return amp_conv2d_wgrad(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0);
+    };
+    auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
+        return amp_colsum(ctx, dy, (int)M_, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0);
+    };
+    // dx = conv(dy, flipped/transposed/scaled w) (+ res) (* mask>0); dy is [B_,Hy,Wy,cw.cout]
+    auto dgrad = [&](const ConvW& cw, const float* dy, int B_, int Hy, int Wy, int fwd_pad, const float* res, const float* mask, float* dx) -> int {
+        AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
+        AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
+        amp_conv_desc d;
+        d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
+        d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
+        return amp_conv2d_nhwc_ex(ctx, &d, dy, wt_scratch, nullptr, nullptr, res, mask, dx);
+    };
+
+    // ---- gradient buffers of the FPN outputs p2..p6 ----
+    float* d_feat[5];
+    for (int l = 0; l < 5; ++l) {
+        AMP_ALLOC(df, float, (size_t)B * T.fh[l] * T.fw[l] * 256);
+        d_feat[l] = df;
+        if (!dry) AMP_HIP_CHECK(hipMemsetAsync(df, 0, (size_t)B * T.fh[l] * T.fw[l] * 256 * 4, ctx->stream));
+    }
+    int fstr[4] = {4, 8, 16, 32};
+
+    // ---- mask head ----
+    AMP_ALLOC(d_mtb, float, (size_t)Nc * 784 * 256);
+    AMP_ALLOC(d_ma, float, (size_t)Nc * 196 * 256);
+    AMP_ALLOC(d_mb, float, (size_t)Nc * 196 * 256);
+    AMP_ALLOC(dwd_t, float, (size_t)256 * 4 * 256);
+    AMP_ALLOC(dbd_t, float, 256);
+    if (!dry && N > 0) {
+        const ConvW& cp = CONV("roi_heads.mask_head.predictor");
+        AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false));
+        AMP_TRY(bgrad(cp, d_mlogits, (long long)N * 784, false));
+        AMP_TRY(amp_small_k_dgrad(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, (size_t)N * 784));
+        const ConvW& cd = CONV("roi_heads.mask_head.deconv");
+        {   // weight gradient in [ci][tap][co] form, then transposed into the forward layout [(tap,co)][ci]
+            amp_conv_desc d;
+            d.B = N; d.H = 28; d.W = 28; d.Cin = 256; d.Cout = 256; d.KH = 2; d.KW = 2; d.stride = 2; d.pad = 0; d.relu = 0; d.res_mode = 0; d.out_mode = 0;
+            AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
+            AMP_TRY(amp_conv2d_wgrad(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0));
+            AMP_TRY(amp_deconv_grad_transpose(ctx, dwd_t, GW(cd), 256, 4, 256, 0));
+            AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
+            for (int q = 0; q < 4; ++q) AMP_HIP_CHECK(hipMemcpyAsync(GB(cd) + q * 256, dbd_t, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            // data gradient: a 2x2 stride-2 convolution of d_mtb with w[ci][ky][kx][co], masked by fcn4's ReLU
+            AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
+            amp_conv_desc g;
+            g.B = N; g.H = 28; g.W = 28; g.Cin = 256; g.Cout = 256; g.KH = 2; g.KW = 2; g.stride = 2; g.pad = 0; g.relu = 0; g.res_mode = 0; g.out_mode = 0;
+            AMP_TRY(amp_conv2d_nhwc_ex(ctx, &g, d_mtb, wt_scratch, nullptr, nullptr, nullptr, macts[4], d_ma));
+        }
+        float* dcur = d_ma;
+        float* dnext = d_mb;
+        for (int i = 4; i >= 1; --i) {
+            const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
+            const ConvW& cf = CONV(key.c_str());
+            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false));
+            AMP_TRY(bgrad(cf, dcur, (long long)N * 196, false));
+            AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext));
+            std::swap(dcur, dnext);
+        }
+        AMP_TRY(amp_roi_align_bwd(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur));
+    } else if (!dry) {
+        for (const char* key : {"roi_heads.mask_head.predictor", "roi_heads.mask_head.deconv", "roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2",
+                                "roi_heads.mask_head.mask_fcn3", "roi_heads.mask_head.mask_fcn4"}) {
+            const ConvW& cw = CONV(key);
+            AMP_HIP_CHECK(hipMemsetAsync(GW(cw), 0, (size_t)cw.cout * cw.kh * cw.kw * cw.cin * 4, ctx->stream));
+            AMP_HIP_CHECK(hipMemsetAsync(GB(cw), 0, (size_t)cw.cout * 4, ctx->stream));
+        }
+    }
+
+    // ---- box head ----
+    AMP_ALLOC(d_fc2, float, (size_t)R * 1024);
+    AMP_ALLOC(d_fc1, float, (size_t)R * 1024);
+    AMP_ALLOC(d_pooled, float, (size_t)R * 49 * 256);
+    if (!dry) {
+        const ConvW& cb = CONV("roi_heads.box_predictor");
+        AMP_TRY(wgrad(cb, fc2, 1, 1, R, 1, 0, d_box_pred, false));
+        AMP_TRY(bgrad(cb, d_box_pred, R, false));
+        AMP_TRY(dgrad(cb, d_box_pred, 1, 1, R, 0, nullptr, fc2, d_fc2));
+        const ConvW& c2 = CONV("roi_heads.box_head.fc2");
+        AMP_TRY(wgrad(c2, fc1, 1, 1, R, 1, 0, d_fc2, false));
+        AMP_TRY(bgrad(c2, d_fc2, R, false));
+        AMP_TRY(dgrad(c2, d_fc2, 1, 1, R, 0, nullptr, fc1, d_fc1));
+        const ConvW& c1 = CONV("roi_heads.box_head.fc1");
+        AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false));
+        AMP_TRY(bgrad(c1, d_fc1, R, false));
+        AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
+        AMP_TRY(amp_roi_align_bwd(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled));
+    }
+
+    // ---- RPN head (shared weights: gradients accumulate over the 5 levels) ----
+    for (int l = 0; l < 5; ++l) {
+        AMP_ALLOC(d_t, float, (size_t)B * T.fh[l] * T.fw[l] * 256);
+        if (dry) continue;
+        const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
+        const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
+        AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0));
+        AMP_TRY(bgrad(cpred, d_rpn_pred[l], (long long)B * T.fh[l] * T.fw[l], l > 0));
+        AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t));
+        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0));
+        AMP_TRY(bgrad(cconv, d_t, (long long)B * T.fh[l] * T.fw[l], l > 0));
+        AMP_TRY(dgrad(cconv, d_t, B, T.fh[l], T.fw[l], 1, d_feat[l], nullptr, d_feat[l]));   // accumulate in place
+    }
+
+    // ---- FPN ----
+    if (!dry) AMP_TRY(amp_subsample2_bwd(ctx, d_feat[4], d_feat[3], B, T.fh[3], T.fw[3], 256));    // p6 = p5[::2, ::2]
+    float* d_res[4] = {nullptr, nullptr, nullptr, nullptr};   // gradients w.r.t. res3..res5 outputs (index = stage)
+    float* d_lat_prev = nullptr;                              // 2x2 sums of the finer level's lateral gradient
+    for (int l = 2; l <= 5; ++l) {
+        const int s_ = l - 2;
+        const int fh_ = T.fh[s_], fw_ = T.fw[s_];
+        AMP_ALLOC(d_lat, float, (size_t)B * fh_ * fw_ * 256);
+        float* d_lat_next = nullptr;
+        if (l < 5) { AMP_ALLOC(dln, float, (size_t)B * T.fh[s_ + 1] * T.fw[s_ + 1] * 256); d_lat_next = dln; }
+        if (l >= 3) { AMP_ALLOC(dr, float, (size_t)B * fh_ * fw_ * kOut[s_]); d_res[s_] = dr; }
+        if (dry) { d_lat_prev = d_lat_next; continue; }
+        const std::string ln = "backbone.fpn_lateral" + std::to_string(l), on = "backbone.fpn_output" + std::to_string(l);
+        const ConvW& co = CONV(on.c_str());
+        const ConvW& cl = CONV(ln.c_str());
+        AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false));
+        AMP_TRY(bgrad(co, d_feat[s_], (long long)B * fh_ * fw_, false));
+        AMP_TRY(dgrad(co, d_feat[s_], B, fh_, fw_, 1, d_lat_prev, nullptr, d_lat));      // + top-down share from the finer level
+        if (l < 5) {
+            AMP_HIP_CHECK(hipMemsetAsync(d_lat_next, 0, (size_t)B * T.fh[s_ + 1] * T.fw[s_ + 1] * 256 * 4, ctx->stream));
+            AMP_TRY(amp_upsample2_bwd(ctx, d_lat, d_lat_next, B, T.fh[s_ + 1], T.fw[s_ + 1], 256));
+        }
+        const float* res_in = nullptr;   // input of the lateral conv = output of stage s_
+        for (auto& ba : m->blocks) if (ba.stage == s_) res_in = ba.out;
+        AMP_TRY(wgrad(cl, res_in, B, fh_, fw_, 1, 0, d_lat, false));
+        AMP_TRY(bgrad(cl, d_lat, (long long)B * fh_ * fw_, false));
+        if (l >= 3) AMP_TRY(dgrad(cl, d_lat, B, fh_, fw_, 0, nullptr, nullptr, d_res[s_]));
+        d_lat_prev = d_lat_next;
+    }
+
+    // ---- ResNet res5 .. res3 (reverse block order) ----
+    float* dcur = nullptr;
+    const int nblk = dry ? 0 : (int)m->blocks.size();
+    // dry run: reserve the worst-case gradient buffers of every trainable block
+    if (dry) {
+        int hh = ((H + 31) / 32 * 32) / 4, ww = ((W + 31) / 32 * 32) / 4;
+        for (int s_ = 1; s_ < 4; ++s_) {
+            hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1;
+            for (int b_ = 0; b_ < kBlocks[s_]; ++b_) {
+                AMP_ALLOC(r1, float, (size_t)B * hh * ww * kMid[s_]);
+                AMP_ALLOC(r2, float, (size_t)B * hh * ww * kMid[s_]);
+                AMP_ALLOC(r3, float, (size_t)B * hh * ww * kOut[s_]);
+                AMP_ALLOC(r4, float, (size_t)B * hh * ww * kOut[s_]);
+                (void)r1; (void)r2; (void)r3; (void)r4;
+            }
+        }
+    }
+    for (int bi = nblk - 1; bi >= 0; --bi) {
+        const amp_model::BlockAct& ba = m->blocks[bi];
+        if (ba.stage == 0) break;                               // res2 is frozen
+        const bool last_of_stage = (bi + 1 == nblk) || m->blocks[bi + 1].stage != ba.stage;
+        if (last_of_stage) {
+            // gradient from the FPN lateral; the next stage's first block (if any) has already added its share into d_res
+            dcur = d_res[ba.stage];
+        }
+        const size_t out_elems = (size_t)B * ba.oh * ba.ow * ba.cout;
+        AMP_TRY(amp_relu_mask(ctx, dcur, ba.out, out_elems));  // d(pre-activation) = d(out) * (out > 0)
+        const ConvW& c3 = CONV((ba.key + ".conv3").c_str());
+        const ConvW& c2 = CONV((ba.key + ".conv2").c_str());
+        const ConvW& c1 = CONV((ba.key + ".conv1").c_str());
+        AMP_ALLOC(d_t2, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+        AMP_ALLOC(d_t1, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+        AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false));
+        AMP_TRY(dgrad(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2));
+        AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false));
+        AMP_TRY(dgrad(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1));
+        AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false));
+        const bool need_dx = !(ba.stage == 1 && ba.has_sc);   // the input of res3.0 is the frozen res2 output
+        if (ba.has_sc) {
+            const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
+            AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false));
+            if (need_dx) {
+                AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                AMP_ALLOC(tmp_in, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                AMP_TRY(dgrad(cs, dcur, B, ba.oh, ba.ow, 0, nullptr, nullptr, tmp_sc));
+                AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, tmp_sc, nullptr, tmp_in));
+                float* dprev = d_res[ba.stage - 1];             // already holds the FPN lateral's share
+                if (ba.stride == 2) AMP_TRY(amp_subsample2_bwd(ctx, tmp_in, dprev, B, ba.in_h, ba.in_w, ba.cin));
+                else { amp::set_error("backward: stride-1 projection block is not expected here"); return AMP_ERR_STATE; }
+            }
+        } else {
+            AMP_ALLOC(d_in, float, out_elems);
+            AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, nullptr, d_in));   // + identity shortcut
+            dcur = d_in;
+        }
+    }
+    if (!dry) m->grads_valid = true;
     return AMP_OK;
 }
 
@@ -717,7 +969,7 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     int st = run(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, oh.data(), ow.data());
     if (st == AMP_OK && cfg->train_enable) {
         float dummy[5];
-        st = run_train(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, nullptr, 0, dummy);
+        st = run_train(m, nullptr, cfg->max_batch, cfg->max_h, cfg->max_w, nullptr, 0, dummy, true);
     }
     if (st != AMP_OK) { (void)hipFree(m->parena); delete m; return st; }
     m->ws.dry = false;
@@ -727,6 +979,16 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
         (void)hipFree(m->parena);
         delete m;
         return AMP_ERR_HIP;
+    }
+    if (cfg->train_enable) {
+        if (hipMalloc(&m->garena, m->parena_floats * sizeof(float)) != hipSuccess || hipMalloc(&m->varena, m->parena_floats * sizeof(float)) != hipSuccess) {
+            amp::set_error("amp_model_create: hipMalloc of the gradient / momentum arenas failed");
+            (void)hipFree(m->parena); (void)hipFree(m->ws.base);
+            delete m;
+            return AMP_ERR_HIP;
+        }
+        (void)hipMemset(m->garena, 0, m->parena_floats * sizeof(float));
+        (void)hipMemset(m->varena, 0, m->parena_floats * sizeof(float));
     }
     const int R = cfg->max_batch * cfg->post_nms_topk;
     std::vector<int> iota(R);
@@ -911,6 +1173,16 @@ int amp_model_finalize(amp_model* m) {
     AMP_TRY(fuse("proposal_generator.rpn_head.pred", "proposal_generator.rpn_head.objectness_logits",
                  "proposal_generator.rpn_head.anchor_deltas", 3, 12, 256));
     AMP_TRY(fuse("roi_heads.box_predictor", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred", K + 1, 4 * K, 1024));
+    // trainable tensors: every conv / fc weight and true bias outside the frozen stem + res2 (FREEZE_AT = 2); FrozenBN has none
+    m->trainable.clear();
+    for (auto& kv : m->conv) {
+        const std::string& key = kv.first;
+        if (key.rfind("backbone.bottom_up.stem", 0) == 0 || key.rfind("backbone.bottom_up.res2", 0) == 0) continue;
+        const ConvW& cw = kv.second;
+        m->trainable.push_back({cw.w, (size_t)cw.cout * cw.kh * cw.kw * cw.cin});
+        const bool has_bn = m->host_raw.count(key + ".norm.weight") != 0;
+        if (!has_bn && cw.shift) m->trainable.push_back({cw.shift, (size_t)cw.cout});
+    }
     m->finalized = true;
     return AMP_OK;
 }
@@ -952,8 +1224,37 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
     return AMP_OK;
 }
 
+static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                       unsigned int seed, float losses_h[5], int backward);
+
 int amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
                              unsigned int seed, float losses_h[5]) {
+    return train_entry(m, imgs_bgr, imgs_on_host, B, H, W, gt, seed, losses_h, 0);
+}
+
+int amp_model_forward_backward(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                               unsigned int seed, float losses_h[5]) {
+    return train_entry(m, imgs_bgr, imgs_on_host, B, H, W, gt, seed, losses_h, 1);
+}
+
+int amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale) {
+    AMP_REQUIRE(m && m->garena && m->varena, "amp_model_sgd_step: the model was created without cfg.train_enable");
+    AMP_REQUIRE(m->grads_valid, "amp_model_sgd_step: no gradients (call amp_model_forward_backward first)");
+    for (auto& t : m->trainable)
+        AMP_TRY(amp_sgd_update(m->ctx, t.p, m->garena + (t.p - m->parena), m->varena + (t.p - m->parena), t.n, lr, momentum, weight_decay, grad_scale));
+    m->grads_valid = false;
+    return AMP_OK;
+}
+
+int amp_model_grad_arena(amp_model* m, float** grads, size_t* nfloats) {
+    AMP_REQUIRE(m && grads && nfloats && m->garena, "amp_model_grad_arena: the model was created without cfg.train_enable");
+    *grads = m->garena;
+    *nfloats = m->parena_used;
+    return AMP_OK;
+}
+
+static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                       unsigned int seed, float losses_h[5], int backward) {
     AMP_REQUIRE(m && imgs_bgr && gt && losses_h, "amp_model_forward_losses: null argument");
     AMP_REQUIRE(m->finalized, "amp_model_forward_losses: call amp_model_finalize after loading every tensor");
     AMP_REQUIRE(m->cfg.train_enable, "amp_model_forward_losses: the model was created with cfg.train_enable = 0");
@@ -968,9 +1269,69 @@ int amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_
         AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
         imgs_d = staged;
     }
-    const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h);
+    const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
     if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     return st;
+}
+
+int amp_model_get_tensor(amp_model* m, const char* name_c, int want_grad, float* out, size_t cap) {
+    AMP_REQUIRE(m && name_c && out, "amp_model_get_tensor: null argument");
+    AMP_REQUIRE(m->finalized, "amp_model_get_tensor: model not finalized");
+    AMP_REQUIRE(!want_grad || m->garena, "amp_model_get_tensor: no gradient arena (cfg.train_enable = 0)");
+    const std::string name(name_c);
+    const std::string prefix = name.substr(0, name.rfind('.'));
+    const bool is_w = ends_with(name, ".weight");
+    const int K = m->cfg.num_classes;
+    AMP_REQUIRE(name.find(".norm.") == std::string::npos, "amp_model_get_tensor: FrozenBN statistics have no gradient / are kept on the host");
+    AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    auto fetch = [&](const float* dev, size_t n, std::vector<float>& h) -> int {
+        const float* src = want_grad ? m->garena + (dev - m->parena) : dev;
+        h.resize(n);
+        AMP_HIP_CHECK(hipMemcpy(h.data(), src, n * 4, hipMemcpyDeviceToHost));
+        return AMP_OK;
+    };
+    std::vector<float> h;
+    std::string key = prefix;
+    int row0 = 0, rows = -1;   // row slice of a fused tensor
+    if (prefix == "roi_heads.box_predictor.cls_score") { key = "roi_heads.box_predictor"; row0 = 0; rows = K + 1; }
+    else if (prefix == "roi_heads.box_predictor.bbox_pred") { key = "roi_heads.box_predictor"; row0 = K + 1; rows = 4 * K; }
+    else if (prefix == "proposal_generator.rpn_head.objectness_logits") { key = "proposal_generator.rpn_head.pred"; row0 = 0; rows = 3; }
+    else if (prefix == "proposal_generator.rpn_head.anchor_deltas") { key = "proposal_generator.rpn_head.pred"; row0 = 3; rows = 12; }
+    else if (prefix == "roi_heads.mask_head.predictor") { row0 = 0; rows = K; }
+    auto it = m->conv.find(key);
+    AMP_REQUIRE(it != m->conv.end(), "amp_model_get_tensor: unknown tensor '%s'", name_c);
+    const ConvW& cw = it->second;
+    if (!is_w) {
+        AMP_REQUIRE(cw.shift, "amp_model_get_tensor: '%s' has no bias", name_c);
+        AMP_TRY(fetch(cw.shift, (size_t)cw.cout, h));
+        const int n = (prefix == "roi_heads.mask_head.deconv") ? 256 : (rows >= 0 ? rows : cw.cout);
+        AMP_REQUIRE((size_t)n <= cap, "amp_model_get_tensor: output buffer too small");
+        memcpy(out, h.data() + row0, (size_t)n * 4);
+        return AMP_OK;
+    }
+    const size_t kk = (size_t)cw.kh * cw.kw * cw.cin;
+    AMP_TRY(fetch(cw.w, (size_t)cw.cout * kk, h));
+    if (prefix == "backbone.bottom_up.stem.conv1") {
+        AMP_REQUIRE(cap >= (size_t)64 * 3 * 49, "amp_model_get_tensor: output buffer too small");
+        for (int o = 0; o < 64; ++o) for (int i = 0; i < 3; ++i) for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x)
+            out[((o * 3 + i) * 7 + y) * 7 + x] = h[(((size_t)o * 7 + y) * 8 + x) * 4 + i];
+    } else if (prefix == "roi_heads.box_head.fc1") {
+        AMP_REQUIRE(cap >= (size_t)1024 * 12544, "amp_model_get_tensor: output buffer too small");
+        for (int o = 0; o < 1024; ++o) for (int ch = 0; ch < 256; ++ch) for (int p = 0; p < 49; ++p)
+            out[(size_t)o * 12544 + ch * 49 + p] = h[(size_t)o * 12544 + p * 256 + ch];
+    } else if (prefix == "roi_heads.mask_head.deconv") {
+        AMP_REQUIRE(cap >= (size_t)256 * 256 * 4, "amp_model_get_tensor: output buffer too small");
+        for (int ci = 0; ci < 256; ++ci) for (int co = 0; co < 256; ++co) for (int ky = 0; ky < 2; ++ky) for (int kx = 0; kx < 2; ++kx)
+            out[(((size_t)ci * 256 + co) * 2 + ky) * 2 + kx] = h[((size_t)(ky * 2 + kx) * 256 + co) * 256 + ci];
+    } else if (rows >= 0) {
+        AMP_REQUIRE(cap >= (size_t)rows * kk, "amp_model_get_tensor: output buffer too small");
+        memcpy(out, h.data() + (size_t)row0 * kk, (size_t)rows * kk * 4);
+    } else {   // [O][KH][KW][I] -> OIHW
+        AMP_REQUIRE(cap >= (size_t)cw.cout * kk, "amp_model_get_tensor: output buffer too small");
+        for (int o = 0; o < cw.cout; ++o) for (int i = 0; i < cw.cin; ++i) for (int y = 0; y < cw.kh; ++y) for (int x = 0; x < cw.kw; ++x)
+            out[(((size_t)o * cw.cin + i) * cw.kh + y) * cw.kw + x] = h[(((size_t)o * cw.kh + y) * cw.kw + x) * cw.cin + i];
+    }
+    return AMP_OK;
 }
 
 int amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]) {

@@ -116,9 +116,10 @@ class MaskRCNN:
 
     LOSS_NAMES = ("loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc")
 
-    def forward_losses(self, images, gt, seed=0):
+    def forward_losses(self, images, gt, seed=0, backward=False):
         """Training-mode forward: the loss dict `model(data)` returns to LossEvalHook (ampis/data_utils.py:111-122).
-        images uint8 [B,H,W,3]; gt: per image dict(boxes [G,4], classes [G], polygons list of flat xy arrays)."""
+        images uint8 [B,H,W,3]; gt: per image dict(boxes [G,4], classes [G], polygons list of flat xy arrays).
+        backward=True also runs the backward pass (gradients stay on the device until sgd_step / get_tensor)."""
         images = np.ascontiguousarray(images, dtype=np.uint8)
         B, H, W, _ = images.shape
         assert len(gt) == B
@@ -138,9 +139,32 @@ class MaskRCNN:
                classes.ctypes.data_as(C.POINTER(C.c_int)), poff.ctypes.data_as(C.POINTER(C.c_int)),
                pxy.ctypes.data_as(C.POINTER(C.c_double)))
         out = (C.c_float * 5)()
-        check(lib().amp_model_forward_losses(self._h, images.ctypes.data_as(C.c_void_p), 1, B, H, W, C.byref(g), int(seed) & 0xFFFFFFFF, out),
-              "amp_model_forward_losses")
+        fn = lib().amp_model_forward_backward if backward else lib().amp_model_forward_losses
+        check(fn(self._h, images.ctypes.data_as(C.c_void_p), 1, B, H, W, C.byref(g), int(seed) & 0xFFFFFFFF, out),
+              "amp_model_forward_backward" if backward else "amp_model_forward_losses")
         return {n: float(out[i]) for i, n in enumerate(self.LOSS_NAMES)}
+
+    def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
+        check(lib().amp_model_sgd_step(self._h, float(lr), float(momentum), float(weight_decay), float(grad_scale)), "amp_model_sgd_step")
+
+    def grad_arena(self):
+        """(device pointer, number of floats) of the flat gradient arena (for the RCCL all-reduce)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().amp_model_grad_arena(self._h, C.byref(p), C.byref(n)), "amp_model_grad_arena")
+        return p.value, n.value
+
+    def get_tensor(self, name, grad=False):
+        """Current value (or gradient) of a parameter in detectron2 / torch layout."""
+        from . import params as P
+        shape = P.param_shapes(self.num_classes)[name]
+        out = np.empty(shape, dtype=np.float32)
+        check(lib().amp_model_get_tensor(self._h, name.encode(), int(bool(grad)), out.ctypes.data_as(C.c_void_p), out.size), "amp_model_get_tensor")
+        return out
+
+    def state_dict(self):
+        """All trainable tensors + the FrozenBN statistics they were loaded with are not tracked here; returns the trainable part."""
+        from . import params as P
+        return {k: self.get_tensor(k) for k in P.param_shapes(self.num_classes) if ".norm." not in k}
 
     def tap(self, name):
         """Copy an intermediate device buffer of the last infer call to the host (parity tests)."""

@@ -259,6 +259,15 @@ int  amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, in
  * losses_h[5] = loss_cls, loss_box_reg, loss_mask, loss_rpn_cls, loss_rpn_loc. Sub-sampling is seeded (oracle/train.py). */
 int  amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
                               unsigned int seed, float losses_h[5]);
+/* Same forward, then the backward pass: gradients of the summed losses w.r.t. every trainable tensor land in
+ * the gradient arena (same offsets as the parameters; amp_model_grad_arena exposes it for the RCCL all-reduce of row a20). */
+int  amp_model_forward_backward(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
+                                unsigned int seed, float losses_h[5]);
+int  amp_model_grad_arena(amp_model* m, float** grads_dev, size_t* nfloats);
+/* torch.optim.SGD step on every trainable tensor: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
+int  amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale);
+/* Gradient / current value of one tensor, converted back to the torch layout of detectron2's state_dict entry `name` (host). */
+int  amp_model_get_tensor(amp_model* m, const char* name, int want_grad, float* out_h, size_t capacity_floats);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
 int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
 

@@ -164,6 +164,72 @@ def rasterize_polygon_within_box(poly, box, size):
     return R.decode_counts(fr_poly(p, size, size), size, size)
 
 
+# ------------------------------------------------------------------------------------------------ differentiable RoIAlign
+def roi_align_torch(feat, rois, out_size, spatial_scale):
+    """Same arithmetic as M.roi_align (torchvision roi_align, aligned=True, sampling_ratio=0) in torch ops, so autograd gives
+    the reference gradient w.r.t. `feat` [C,H,W] (what roi_align_backward_kernel computes). rois [R,4] are constants."""
+    C, H, W = feat.shape
+    outs = []
+    f32 = torch.float32
+    for r in rois.detach():
+        sw, sh = r[0] * spatial_scale - 0.5, r[1] * spatial_scale - 0.5
+        rw, rh = (r[2] * spatial_scale - 0.5) - sw, (r[3] * spatial_scale - 0.5) - sh
+        bh, bw = rh / out_size, rw / out_size
+        gh, gw = int(torch.ceil(bh)), int(torch.ceil(bw))
+        if gh <= 0 or gw <= 0:
+            outs.append(feat.new_zeros((C, out_size, out_size)))
+            continue
+        ph = torch.arange(out_size, dtype=f32)
+
+        def prep(start, b, g, size):
+            v = start + ph[:, None] * b + (torch.arange(g, dtype=f32)[None, :] + 0.5) * b / g      # [P, g]
+            bad = (v < -1.0) | (v > size)
+            v = torch.where(v <= 0, torch.zeros_like(v), v)
+            lo = v.to(torch.int64)
+            clip = lo >= size - 1
+            lo = torch.where(clip, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(clip, torch.full_like(lo, size - 1), lo + 1)
+            v = torch.where(clip, lo.to(f32), v)
+            l = v - lo.to(f32)
+            return bad, lo, hi, l, 1.0 - l
+
+        ybad, ylo, yhi, ly, hy = prep(sh, bh, gh, H)
+        xbad, xlo, xhi, lx, hx = prep(sw, bw, gw, W)
+        acc = feat.new_zeros((C, out_size, out_size))
+        for iy in range(gh):
+            for ix in range(gw):
+                w1 = (hy[:, iy, None] * hx[None, :, ix])
+                w2 = (hy[:, iy, None] * lx[None, :, ix])
+                w3 = (ly[:, iy, None] * hx[None, :, ix])
+                w4 = (ly[:, iy, None] * lx[None, :, ix])
+                v1 = feat[:, ylo[:, iy][:, None], xlo[:, ix][None, :]]
+                v2 = feat[:, ylo[:, iy][:, None], xhi[:, ix][None, :]]
+                v3 = feat[:, yhi[:, iy][:, None], xlo[:, ix][None, :]]
+                v4 = feat[:, yhi[:, iy][:, None], xhi[:, ix][None, :]]
+                val = ((w1 * v1 + w2 * v2) + w3 * v3) + w4 * v4
+                ok = ~(ybad[:, iy][:, None] | xbad[:, ix][None, :])
+                acc = acc + val * ok
+        outs.append(acc / float(max(gh * gw, 1)))
+    return torch.stack(outs) if outs else feat.new_zeros((0, C, out_size, out_size))
+
+
+def roi_pool_torch(features, boxes_per_img, out_size):
+    """M.roi_pool with the differentiable RoIAlign."""
+    boxes = torch.cat(boxes_per_img) if boxes_per_img else torch.zeros(0, 4)
+    bidx = torch.cat([torch.full((len(b),), i, dtype=torch.int64) for i, b in enumerate(boxes_per_img)])
+    lv = M.assign_levels(boxes)
+    C = features[0].shape[1]
+    out = [None] * len(boxes)
+    for l in range(4):
+        for b in range(len(boxes_per_img)):
+            sel = torch.nonzero((lv == l) & (bidx == b)).squeeze(1)
+            if len(sel):
+                o = roi_align_torch(features[l][b], boxes[sel], out_size, 1.0 / M.STRIDES[l])
+                for j, i in enumerate(sel.tolist()):
+                    out[i] = o[j]
+    return torch.stack(out) if out else features[0].new_zeros((0, C, out_size, out_size))
+
+
 # ------------------------------------------------------------------------------------------------ the forward
 class TrainCfg(M.Cfg):
     def __init__(self, **kw):
@@ -263,7 +329,8 @@ def forward_losses(images_u8, gt, params, cfg, stages=None):
         roi_gtidx.append(matches[sel])
         roi_gt.append(gtb[matches[sel]] if len(gtb) else pb[sel])
     # ---- box head + losses (FastRCNNOutputLayers.losses) ----
-    pooled, _, _ = M.roi_pool(feats[:4], rois, 7)
+    diff = any(getattr(v, 'requires_grad', False) for v in params.values())
+    pooled = roi_pool_torch(feats[:4], rois, 7) if diff else M.roi_pool(feats[:4], rois, 7)[0]
     scores, bdeltas = M.box_head(pooled, params)
     gcls = torch.cat(roi_cls)
     losses["loss_cls"] = F.cross_entropy(scores, gcls, reduction="mean")
@@ -274,7 +341,7 @@ def forward_losses(images_u8, gt, params, cfg, stages=None):
     losses["loss_box_reg"] = (fg_pred - gd).abs().sum() / max(gcls.numel(), 1.0)
     # ---- mask head + loss (mask_rcnn_loss) on the foreground rois ----
     fg_rois = [r[c != K] for r, c in zip(rois, roi_cls)]
-    mpooled, _, _ = M.roi_pool(feats[:4], fg_rois, 14)
+    mpooled = roi_pool_torch(feats[:4], fg_rois, 14) if diff else M.roi_pool(feats[:4], fg_rois, 14)[0]
     h = mpooled
     pre = "roi_heads.mask_head."
     for i in range(1, 5):

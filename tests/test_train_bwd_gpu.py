@@ -1,0 +1,67 @@
+"""Backward pass + SGD (amp_model_forward_backward / amp_model_sgd_step, through the C ABI) against torch autograd of the
+training oracle on identical inputs, weights and sampling seed.  RoIAlign backward uses float atomics, so gradients are
+compared with a relative tolerance (not bitwise)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_ctx):
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    K, B, H, W = 2, 2, 192, 256
+    imgs, gts = synth.batch(B, H, W, seed=9)
+    gts = [dict(boxes=g["boxes"][:40], classes=g["classes"][:40], polygons=g["polygons"][:40]) for g in gts]
+    npp = P.init_params(K, seed=2, style="spread")
+    tp = M.to_torch_params(npp)
+    train_names = [k for k in tp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    for k in train_names:
+        tp[k].requires_grad_(True)
+    cfg = T.TrainCfg(num_classes=K, seed=3)
+    ref = T.forward_losses(imgs, gts, tp, cfg)
+    sum(ref.values()).backward()
+    ref_grads = {k: tp[k].grad.detach().numpy() for k in train_names}
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=2048, max_poly_doubles=2048 * 64)
+    model.load_params(npp)
+    got = model.forward_losses(imgs, gts, seed=3, backward=True)
+    return dict(model=model, got=got, ref={k: float(v) for k, v in ref.items()}, ref_grads=ref_grads, names=train_names, npp=npp)
+
+
+def test_losses_unchanged_by_backward(setup):
+    for k, v in setup["ref"].items():
+        assert setup["got"][k] == pytest.approx(v, rel=2e-4, abs=1e-6), k
+
+
+def test_gradients_match_autograd(setup):
+    m = setup["model"]
+    worst = []
+    for name in setup["names"]:
+        g = m.get_tensor(name, grad=True)
+        r = setup["ref_grads"][name]
+        assert g.shape == r.shape, name
+        scale = max(float(np.abs(r).max()), 1e-8)
+        err = float(np.abs(g - r).max()) / scale
+        worst.append((err, name))
+    worst.sort(reverse=True)
+    bad = [(e, n) for e, n in worst if e > 2e-3]
+    assert not bad, f"{len(bad)} tensors off: {bad[:8]}"
+
+
+def test_sgd_step_matches_torch(setup):
+    """One SGD step (lr, momentum, weight decay) == torch.optim.SGD on the oracle's gradients."""
+    m, npp = setup["model"], setup["npp"]
+    lr, mu, wd = 0.01, 0.9, 1e-4
+    m.sgd_step(lr, mu, wd)
+    for name in ("backbone.fpn_output3.weight", "roi_heads.box_head.fc2.bias", "backbone.bottom_up.res4.2.conv2.weight",
+                 "roi_heads.mask_head.deconv.weight", "proposal_generator.rpn_head.anchor_deltas.weight"):
+        p0 = npp[name]
+        g = setup["ref_grads"][name]
+        expect = p0 - lr * (g + wd * p0)      # first step: momentum buffer = g'
+        got = m.get_tensor(name)
+        assert np.abs(got - expect).max() <= 2e-3 * lr * max(np.abs(g).max(), 1e-6) + 1e-7, name
+    # frozen tensors did not move
+    assert np.array_equal(m.get_tensor("backbone.bottom_up.res2.0.conv1.weight"), npp["backbone.bottom_up.res2.0.conv1.weight"])
