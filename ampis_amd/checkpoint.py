@@ -44,3 +44,12 @@ def save_checkpoint(path, np_params, iteration=None):
     if iteration is not None:
         obj["iteration"] = int(iteration)
     torch.save(obj, str(path))
+
+
+def checkpoint_iteration(path):
+    """iteration stored in a .pth written by save_checkpoint (None when absent)."""
+    try:
+        d = torch.load(str(path), map_location="cpu", weights_only=False)
+        return int(d["iteration"]) if isinstance(d, dict) and "iteration" in d else None
+    except Exception:
+        return None

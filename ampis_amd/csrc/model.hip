@@ -92,6 +92,7 @@ struct amp_model {
     struct Trainable { float* p; size_t n; };
     std::vector<Trainable> trainable;
     bool grads_valid = false;
+    std::vector<int> img_hw;            // optional per-image valid sizes for the next batches
 };
 
 namespace {
@@ -195,7 +196,15 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
 
     // ---------------- backbone ----------------
     AMP_ALLOC(x0, float, (size_t)B * Hp * Wp * 4);
-    if (!dry) AMP_TRY(amp_preprocess(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, x0));
+    AMP_ALLOC(d_img_hw, int, (size_t)2 * B);
+    if (!dry) {
+        const bool sized = (int)m->img_hw.size() == 2 * B;
+        if (sized) {
+            AMP_HIP_CHECK(hipMemcpyAsync(d_img_hw, m->img_hw.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, ctx->stream));
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        AMP_TRY(amp_preprocess(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0));
+    }
     int h = Hp / 2, w = Wp / 2;
     AMP_ALLOC(stem, float, (size_t)B * h * w * 64);
     if (!dry) AMP_TRY(launch_conv(m, CONV("backbone.bottom_up.stem.conv1"), x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
@@ -1272,6 +1281,12 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
     const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
     if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     return st;
+}
+
+int amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B) {
+    AMP_REQUIRE(m && B >= 0, "amp_model_set_image_sizes: bad argument");
+    if (hw_h) m->img_hw.assign(hw_h, hw_h + 2 * B); else m->img_hw.clear();
+    return AMP_OK;
 }
 
 int amp_model_get_tensor(amp_model* m, const char* name_c, int want_grad, float* out, size_t cap) {

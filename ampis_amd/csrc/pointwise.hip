@@ -11,7 +11,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int B, int H, int W, int Hp,
-                                  int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
+                                  int Wp, float m0, float m1, float m2, float s0, float s1, float s2, const int* __restrict__ img_hw) {
     const size_t total = (size_t)B * Hp * Wp;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % Wp);
@@ -19,7 +19,8 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __rest
         const int y = (int)(t % Hp);
         const int b = (int)(t / Hp);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y < H && x < W) {
+        const int vh = img_hw ? img_hw[2 * b] : H, vw = img_hw ? img_hw[2 * b + 1] : W;   // ImageList.from_tensors pads with 0 AFTER normalising
+        if (y < vh && x < vw) {
             const uint8_t* p = img + ((size_t)(b * H + y) * W + x) * 3;
             v[0] = __fdiv_rn(__fsub_rn((float)p[0], m0), s0);
             v[1] = __fdiv_rn(__fsub_rn((float)p[1], m1), s1);
@@ -82,12 +83,12 @@ inline int grid_for(size_t total, int block) {
 extern "C" {
 
 int amp_preprocess(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3],
-                   const float std[3], float* out) {
+                   const float std[3], const int* img_hw, float* out) {
     AMP_REQUIRE(ctx && img_bgr && out && mean && std, "amp_preprocess: null argument");
     AMP_REQUIRE(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "amp_preprocess: bad shape");
     const size_t total = (size_t)B * Hp * Wp;
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, img_bgr, out, B, H, W,
-                       Hp, Wp, mean[0], mean[1], mean[2], std[0], std[1], std[2]);
+                       Hp, Wp, mean[0], mean[1], mean[2], std[0], std[1], std[2], img_hw);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -1,6 +1,12 @@
-"""detectron2.data façade: DatasetCatalog / MetadataCatalog (notebook cells 13, 16, 18, 28; ampis/visualize.py:152) and the
-loader pieces AmpisTrainer names (ampis/data_utils.py:24,171-175)."""
+"""detectron2.data façade: DatasetCatalog / MetadataCatalog (notebook cells 13, 16, 18, 28; ampis/visualize.py:152), the
+DatasetMapper and the loaders AmpisTrainer names (ampis/data_utils.py:24,171-175).
+
+A mapped sample is a dict: image_bgr uint8 [h,w,3] (after ResizeShortestEdge / RandomFlip), height / width of the ORIGINAL image,
+and in training mode gt = dict(boxes f32 [G,4] XYXY, classes i64 [G], polygons list[G] of flat xy float64) in resized coordinates.
+Only polygon ground truth (INPUT.MASK_FORMAT='polygon', what the tutorial uses, notebook cell 20) is supported for training."""
 import types
+
+import numpy as np
 
 
 class _DatasetCatalog(dict):
@@ -60,21 +66,68 @@ DatasetCatalog = _DatasetCatalog()
 MetadataCatalog = _MetadataCatalog()
 
 
-class DatasetMapper:
-    """Turns a dataset dict into model input (image read + resize).  Training-mode mapping (flip, polygon -> mask
-    targets) belongs to the training path, which this round does not build: constructing with is_train=True works
-    (ampis/data_utils.py:174 does so), calling it raises."""
+def transform_annotations(annos, scale_x, scale_y, flip, new_w, new_h):
+    """detectron2 detection_utils.transform_instance_annotations + annotations_to_instances + filter_empty_instances for
+    polygon masks: boxes and polygon vertices are scaled (and mirrored), boxes clipped, empty boxes dropped."""
+    boxes, classes, polys = [], [], []
+    for a in annos:
+        if a.get("iscrowd", 0):
+            continue
+        seg = a.get("segmentation")
+        if not isinstance(seg, (list, tuple)) or len(seg) == 0:
+            raise NotImplementedError("ampis_amd training supports polygon ground truth only (INPUT.MASK_FORMAT='polygon')")
+        if len(seg) != 1:
+            raise NotImplementedError("ampis_amd training expects one polygon per instance (as ampis.data_utils.get_ddicts emits)")
+        b = np.asarray(a["bbox"], dtype=np.float64).copy()
+        if int(a.get("bbox_mode", 0)) == 1:   # XYWH_ABS -> XYXY_ABS
+            b[2:] += b[:2]
+        p = np.asarray(seg[0], dtype=np.float64).reshape(-1).copy()
+        b[0::2] *= scale_x; b[1::2] *= scale_y
+        p[0::2] *= scale_x; p[1::2] *= scale_y
+        if flip:
+            b[0], b[2] = new_w - b[2], new_w - b[0]
+            p[0::2] = new_w - p[0::2]
+        b = np.clip(b, 0, [new_w, new_h, new_w, new_h])
+        if b[2] - b[0] <= 1e-5 or b[3] - b[1] <= 1e-5:
+            continue
+        boxes.append(b.astype(np.float32))
+        classes.append(int(a["category_id"]))
+        polys.append(p)
+    return dict(boxes=np.asarray(boxes, np.float32).reshape(-1, 4), classes=np.asarray(classes, np.int64), polygons=polys)
 
-    def __init__(self, cfg, is_train=True):
+
+class DatasetMapper:
+    """DatasetMapper(cfg, is_train): image read + ResizeShortestEdge (+ RandomFlip and ground truth in training mode)."""
+
+    def __init__(self, cfg, is_train=True, seed=0):
         self.cfg = cfg
         self.is_train = is_train
+        self._rng = np.random.default_rng(seed)
+        self.force_size = None      # set by the train loader so that all images of a batch share one scale choice
 
     def __call__(self, dataset_dict):
+        from .engine.defaults import read_image_bgr, resize_shortest_edge
+        c = self.cfg
+        img = dataset_dict["image_bgr"] if "image_bgr" in dataset_dict else read_image_bgr(dataset_dict["file_name"])
+        h, w = img.shape[:2]
         if self.is_train:
-            raise NotImplementedError("ampis_amd: the training-mode DatasetMapper is not built yet (SURVEY §8 f1)")
-        from .engine.defaults import read_image_bgr
-        d = dict(dataset_dict)
-        d["image_bgr"] = read_image_bgr(d["file_name"])
+            sizes = c.INPUT.MIN_SIZE_TRAIN
+            sizes = (sizes,) if isinstance(sizes, int) else tuple(sizes)
+            min_size = self.force_size if self.force_size is not None else int(sizes[self._rng.integers(len(sizes))])
+            max_size = int(c.INPUT.MAX_SIZE_TRAIN)
+        else:
+            min_size, max_size = int(c.INPUT.MIN_SIZE_TEST), int(c.INPUT.MAX_SIZE_TEST)
+        out = resize_shortest_edge(np.ascontiguousarray(img), min_size, max_size)
+        nh, nw = out.shape[:2]
+        d = {k: v for k, v in dataset_dict.items() if k not in ("annotations", "image_bgr")}
+        d["height"], d["width"] = h, w
+        flip = False
+        if self.is_train:
+            flip = str(c.INPUT.get("RANDOM_FLIP", "horizontal")) == "horizontal" and bool(self._rng.random() < 0.5)
+            if flip:
+                out = out[:, ::-1]
+            d["gt"] = transform_annotations(dataset_dict.get("annotations", []), nw / w, nh / h, flip, nw, nh)
+        d["image_bgr"] = np.ascontiguousarray(out)
         return d
 
 
@@ -92,3 +145,40 @@ def build_detection_test_loader(cfg, dataset_name, mapper=None):
                 yield [mapper(d)]
 
     return _Loader()
+
+
+def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0):
+    """Infinite iterator of per-rank batches (lists of mapped dicts). TrainingSampler semantics: an infinite stream of seeded
+    shuffles of the dataset indices, rank r takes elements r, r+world, ...; IMS_PER_BATCH is the GLOBAL batch.  All images of
+    one batch use the same MIN_SIZE_TRAIN choice so they can be stacked (detectron2 draws it per image and pads)."""
+    names = cfg.DATASETS.TRAIN
+    dicts = [d for n in names for d in DatasetCatalog.get(n)]
+    dicts = [d for d in dicts if len(d.get("annotations", [])) > 0]       # FILTER_EMPTY_ANNOTATIONS
+    assert len(dicts) > 0, "empty training set"
+    total = int(cfg.SOLVER.IMS_PER_BATCH)
+    assert total % world_size == 0, "SOLVER.IMS_PER_BATCH must be divisible by the number of GPUs"
+    per_rank = total // world_size
+    mapper = mapper or DatasetMapper(cfg, True, seed=seed + 1000 * rank)
+    sizes = cfg.INPUT.MIN_SIZE_TRAIN
+    sizes = (sizes,) if isinstance(sizes, int) else tuple(sizes)
+
+    def stream():
+        g = np.random.default_rng(seed)
+        while True:
+            yield from g.permutation(len(dicts)).tolist()
+
+    def batches():
+        s = stream()
+        size_rng = np.random.default_rng(seed + 7)
+        k = 0
+        while True:
+            batch = []
+            mapper.force_size = int(sizes[size_rng.integers(len(sizes))])
+            while len(batch) < per_rank:
+                idx = next(s)
+                if k % world_size == rank:
+                    batch.append(mapper(dicts[idx]))
+                k += 1
+            yield batch
+
+    return batches()

@@ -1,4 +1,5 @@
 from . import hooks
-from .defaults import DefaultPredictor, DefaultTrainer
+from .defaults import DefaultPredictor, DefaultTrainer, TrainModel
+from .hooks import HookBase
 
-__all__ = ["DefaultPredictor", "DefaultTrainer", "hooks"]
+__all__ = ["DefaultPredictor", "DefaultTrainer", "TrainModel", "HookBase", "hooks"]

@@ -106,26 +106,125 @@ class DefaultPredictor:
         return {"instances": inst}
 
 
+class TrainModel:
+    """What `trainer.model` is: callable on a batch (list of mapped dicts).  In training mode (the default, and what
+    LossEvalHook relies on: ampis/data_utils.py:116) it returns the dict of the five losses as floats."""
+
+    def __init__(self, net, ctx):
+        self.net, self.ctx = net, ctx
+        self.training = True
+        self._seed = 0
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    @staticmethod
+    def stack(batch):
+        hs = [d["image_bgr"].shape[0] for d in batch]
+        ws = [d["image_bgr"].shape[1] for d in batch]
+        H, W = max(hs), max(ws)
+        imgs = np.zeros((len(batch), H, W, 3), dtype=np.uint8)
+        for i, d in enumerate(batch):
+            imgs[i, : hs[i], : ws[i]] = d["image_bgr"]
+        sizes = None if (min(hs) == H and min(ws) == W) else list(zip(hs, ws))
+        return imgs, sizes
+
+    def __call__(self, batch, backward=False, seed=None):
+        assert self.training, "TrainModel is the training-mode surface; use DefaultPredictor for inference"
+        imgs, sizes = self.stack(batch)
+        self.net.set_image_sizes(sizes)
+        if seed is None:
+            self._seed += 1
+            seed = 0x5EED0000 + self._seed
+        return self.net.forward_losses(imgs, [d["gt"] for d in batch], seed=seed, backward=backward)
+
+
 class DefaultTrainer:
-    """Surface of detectron2's DefaultTrainer that AMPIS subclasses (ampis/data_utils.py:135-177; notebook cell 22).
-    The training hot path (losses, backward, SGD, RCCL gradient all-reduce) is not built in this
-    round: constructing the trainer works (cfg, hooks list, checkpoint naming), train() fails loudly."""
+    """detectron2's DefaultTrainer surface (notebook cell 22; subclassed by AmpisTrainer, ampis/data_utils.py:135-177):
+    DefaultTrainer(cfg) -> .resume_or_load(resume=False) -> .train(); .model, .cfg, .iter, .max_iter, .storage, build_hooks().
+    One process per GPU; with torch.distributed initialised (backend nccl = RCCL) each rank trains on its shard of the global
+    batch and the flat gradient arena is all-reduced before the SGD step."""
 
     def __init__(self, cfg):
+        from ..data import build_detection_train_loader
+        from ..utils import comm
         self.cfg = cfg
         self.iter = self.start_iter = 0
         self.max_iter = int(cfg.SOLVER.MAX_ITER)
-        self.model = None
+        self.storage = None
+        self.is_main_process = comm.is_main_process()
+        self.world_size = comm.get_world_size()
+        self.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+        dev = _device_index(cfg.MODEL.DEVICE) if ":" in str(cfg.MODEL.DEVICE) else (int(os.environ.get("LOCAL_RANK", "0")) if not str(cfg.MODEL.DEVICE).startswith("cpu") else _device_index(cfg.MODEL.DEVICE))
+        self.ctx = _lib.Context(dev)
+        self.params = P.init_params(self.num_classes, seed=max(int(cfg.get("SEED", -1)), 0), style="d2")
+        self._net = None
+        self.model = TrainModel(None, self.ctx)            # net attached lazily (capacity depends on the first batch)
+        self._per_rank = int(cfg.SOLVER.IMS_PER_BATCH) // self.world_size
+        self.data_loader = build_detection_train_loader(cfg, rank=comm.get_rank(), world_size=self.world_size,
+                                                        seed=max(int(cfg.get("SEED", -1)), 0))
         self._hooks = []
         self.register_hooks(self.build_hooks())
 
+    # ---- model / weights ----
+    def _ensure_net(self, h, w):
+        hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        cap = getattr(self, "_cap", (0, 0))
+        if self._net is not None and hp <= cap[0] and wp <= cap[1]:
+            return
+        if self._net is not None:
+            self._sync_params()
+            self._net.close()
+        c = self.cfg
+        cap = (max(hp, cap[0]), max(wp, cap[1]))
+        self._net = MaskRCNN(self.ctx, self.num_classes, max_batch=self._per_rank, max_h=cap[0], max_w=cap[1], max_out_hw=max(cap),
+                             train=True, max_gt=self._per_rank * 2048, max_poly_doubles=self._per_rank * 2048 * 128,
+                             pre_nms_topk_train=int(c.MODEL.RPN.PRE_NMS_TOPK_TRAIN), post_nms_topk_train=int(c.MODEL.RPN.POST_NMS_TOPK_TRAIN),
+                             rpn_batch=int(c.MODEL.RPN.BATCH_SIZE_PER_IMAGE), roi_batch=int(c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE),
+                             pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD))
+        self._net.load_params(self.params)
+        self._cap = cap
+        self.model.net = self._net
+
+    def _sync_params(self):
+        if self._net is not None:
+            self.params.update(self._net.state_dict())
+
+    def resume_or_load(self, resume=True):
+        """resume=False: start from cfg.MODEL.WEIGHTS at iteration 0.  A detectron2:// or http(s) path cannot be fetched here
+        (no network): training then starts from the seeded random initialisation, with a warning."""
+        w = str(self.cfg.MODEL.WEIGHTS)
+        if resume:
+            last = os.path.join(self.cfg.OUTPUT_DIR, "last_checkpoint")
+            if os.path.isfile(last):
+                w = os.path.join(self.cfg.OUTPUT_DIR, open(last).read().strip())
+        if w and not w.startswith(("detectron2://", "http://", "https://")):
+            self.params = checkpoint.load_checkpoint(w, self.num_classes)
+            if resume:
+                it = checkpoint.checkpoint_iteration(w)
+                self.start_iter = self.iter = (it + 1) if it is not None else 0
+        elif w:
+            logger.warning(f"cfg.MODEL.WEIGHTS={w!r} needs a download; no network: training from the seeded random initialisation")
+        if self._net is not None:
+            self._net.load_params(self.params)
+
+    def save_checkpoint(self, path):
+        self._sync_params()
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        checkpoint.save_checkpoint(path, self.params, iteration=self.iter)
+        with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
+            f.write(os.path.basename(path))
+
+    # ---- hooks ----
     def build_hooks(self):
-        from .hooks import HookBase
-
-        class _PeriodicWriter(HookBase):
-            pass
-
-        return [_PeriodicWriter()]
+        """[PeriodicCheckpointer, PeriodicWriter]: the writer is last (AmpisTrainer does hooks.insert(-1, LossEvalHook(...)))."""
+        from .train_loop import PeriodicCheckpointer, PeriodicWriter
+        out = str(self.cfg.OUTPUT_DIR)
+        return [PeriodicCheckpointer(int(self.cfg.SOLVER.CHECKPOINT_PERIOD), out), PeriodicWriter(out, period=20)]
 
     def register_hooks(self, hooks):
         for h in hooks:
@@ -133,9 +232,45 @@ class DefaultTrainer:
                 h.trainer = self
         self._hooks.extend([h for h in hooks if h is not None])
 
-    def resume_or_load(self, resume=True):
-        self.start_iter = 0
+    # ---- loop ----
+    def lr_at(self, it):
+        from .train_loop import warmup_multistep_lr
+        s = self.cfg.SOLVER
+        return warmup_multistep_lr(it, float(s.BASE_LR), tuple(s.STEPS), float(s.GAMMA), int(s.WARMUP_ITERS), float(s.WARMUP_FACTOR))
+
+    def run_step(self):
+        from ..utils import comm
+        batch = next(self.data_loader)
+        h = max(d["image_bgr"].shape[0] for d in batch)
+        w = max(d["image_bgr"].shape[1] for d in batch)
+        self._ensure_net(h, w)
+        losses = self.model(batch, backward=True, seed=(self.iter * 7919 + comm.get_rank()) & 0x7FFFFFFF)
+        scale = comm.all_reduce_gradients(self._net, self.ctx)
+        lr = self.lr_at(self.iter)
+        s = self.cfg.SOLVER
+        self._net.sgd_step(lr, float(s.MOMENTUM), float(s.WEIGHT_DECAY), grad_scale=scale)
+        total = sum(losses.values())
+        if not np.isfinite(total):
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {losses}")
+        self.storage.put_scalars(total_loss=total, lr=lr, **losses)
 
     def train(self):
-        raise NotImplementedError("ampis_amd: the MI355X training path (SURVEY.md §8a rows a18-a20) is not built yet; "
-                                  "inference (DefaultPredictor) is.")
+        from .train_loop import EventStorage
+        os.makedirs(str(self.cfg.OUTPUT_DIR), exist_ok=True)
+        logger.info(f"Starting training from iteration {self.start_iter}")
+        self.storage = EventStorage(self.start_iter)
+        self.iter = self.start_iter
+        for h in self._hooks:
+            h.before_train()
+        try:
+            for self.iter in range(self.start_iter, self.max_iter):
+                for h in self._hooks:
+                    h.before_step()
+                self.run_step()
+                for h in self._hooks:
+                    h.after_step()
+                self.storage.step()
+        finally:
+            for h in self._hooks:
+                h.after_train()
+        self._sync_params()

@@ -144,6 +144,14 @@ class MaskRCNN:
               "amp_model_forward_backward" if backward else "amp_model_forward_losses")
         return {n: float(out[i]) for i, n in enumerate(self.LOSS_NAMES)}
 
+    def set_image_sizes(self, sizes):
+        """sizes: list of (h, w) valid extents inside the common frame for the next batches, or None."""
+        if sizes is None:
+            check(lib().amp_model_set_image_sizes(self._h, None, 0), "amp_model_set_image_sizes")
+        else:
+            a = np.ascontiguousarray(np.asarray(sizes, dtype=np.int32).reshape(-1, 2))
+            check(lib().amp_model_set_image_sizes(self._h, a.ctypes.data_as(C.c_void_p), len(a)), "amp_model_set_image_sizes")
+
     def sgd_step(self, lr, momentum=0.9, weight_decay=1e-4, grad_scale=1.0):
         check(lib().amp_model_sgd_step(self._h, float(lr), float(momentum), float(weight_decay), float(grad_scale)), "amp_model_sgd_step")
 

@@ -113,9 +113,10 @@ int amp_sgd_update(amp_ctx* ctx, float* p, const float* g, float* v, size_t n, f
 
 
 /* Stage a8 / a9 / a10: memory-bound NHWC helpers --------------------------------------------- */
-/* uint8 BGR [B,H,W,3] -> fp32 [B,Hp,Wp,4] = (x - mean) / std, zero padded (4th channel 0). */
+/* uint8 BGR [B,H,W,3] -> fp32 [B,Hp,Wp,4] = (x - mean) / std, zero padded (4th channel 0). img_hw: optional device [B][2]
+ * valid (h,w) of each image inside the common HxW frame; pixels beyond it are 0 after normalisation (ImageList.from_tensors). */
 int amp_preprocess(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3],
-                   const float std[3], float* out);
+                   const float std[3], const int* img_hw, float* out);
 int amp_maxpool3x3s2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y);   /* k3 s2 p1 */
 int amp_subsample2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y);     /* x[:, ::2, ::2] */
 
@@ -268,6 +269,8 @@ int  amp_model_grad_arena(amp_model* m, float** grads_dev, size_t* nfloats);
 int  amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale);
 /* Gradient / current value of one tensor, converted back to the torch layout of detectron2's state_dict entry `name` (host). */
 int  amp_model_get_tensor(amp_model* m, const char* name, int want_grad, float* out_h, size_t capacity_floats);
+/* Valid (h,w) of each image of the NEXT batches inside the common frame (host [B][2]); NULL = every image fills the frame. */
+int  amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
 int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
 

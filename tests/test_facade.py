@@ -132,14 +132,24 @@ def test_resize_shortest_edge_rule():
     assert resize_shortest_edge(np.zeros((400, 2000, 3), np.uint8), 800, 1333).shape == (267, 1333, 3)
 
 
-def test_trainer_surface_fails_loudly_on_train():
+def test_trainer_needs_a_gpu_and_says_so():
+    """No CPU fallback: without a HIP device the trainer refuses to construct (this container has no GPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ampis_amd import _lib
     from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog
     from ampis_amd.engine import DefaultTrainer
-    t = DefaultTrainer(get_cfg())
-    hooks = t.build_hooks()
-    assert isinstance(hooks, list) and len(hooks) >= 1
-    with pytest.raises(NotImplementedError):
-        t.train()
+    DatasetCatalog.clear()
+    DatasetCatalog.register("t_Train", lambda: [{"annotations": [{"bbox": [0, 0, 4, 4], "bbox_mode": 0, "segmentation": [[0, 0, 4, 0, 4, 4]], "category_id": 0}],
+                                                 "image_bgr": np.zeros((32, 32, 3), np.uint8)}])
+    cfg = get_cfg()
+    cfg.DATASETS.TRAIN = ("t_Train",)
+    cfg.SOLVER.IMS_PER_BATCH = 1
+    with pytest.raises(_lib.AmpError):
+        DefaultTrainer(cfg)
+    DatasetCatalog.clear()
 
 
 def test_c_abi_exports_every_declared_symbol():

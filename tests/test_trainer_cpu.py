@@ -1,0 +1,103 @@
+"""CPU tests of the training host logic: LR schedule, EventStorage, annotation transforms, the sharded
+train loader, hook ordering, and the N>1 gradient exchange with world_size-2 gloo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_warmup_multistep_lr_matches_detectron2_formula():
+    from ampis_amd.engine.train_loop import warmup_multistep_lr as lr
+    # mask_rcnn_R_50_FPN_3x: base 0.02, steps (210000, 250000), gamma 0.1, warm-up 1000 iters from factor 0.001
+    assert lr(0, 0.02, (210000, 250000), 0.1, 1000, 0.001) == pytest.approx(0.02 * 0.001)
+    assert lr(500, 0.02, (210000, 250000), 0.1, 1000, 0.001) == pytest.approx(0.02 * (0.001 * 0.5 + 0.5))
+    assert lr(1000, 0.02, (210000, 250000), 0.1, 1000, 0.001) == pytest.approx(0.02)
+    assert lr(210000, 0.02, (210000, 250000), 0.1, 1000, 0.001) == pytest.approx(0.002)
+    assert lr(260000, 0.02, (210000, 250000), 0.1, 1000, 0.001) == pytest.approx(0.0002)
+
+
+def test_event_storage_surface():
+    from ampis_amd.engine.train_loop import EventStorage
+    st = EventStorage(5)
+    st.put_scalar("validation_loss", 1.5)          # ampis/data_utils.py:104
+    st.put_scalars(timetest=12)                    # ampis/data_utils.py:132
+    st.step()
+    st.put_scalar("validation_loss", 1.0)
+    assert st.iter == 6
+    assert st.history("validation_loss") == [(1.5, 5), (1.0, 6)]
+    assert st.latest()["timetest"] == (12.0, 5)
+
+
+def test_transform_annotations_scale_and_flip():
+    from ampis_amd.data import transform_annotations
+    annos = [{"bbox": [10, 20, 50, 60], "bbox_mode": 0, "segmentation": [[10.5, 20.5, 50.5, 20.5, 50.5, 60.5]], "category_id": 0},
+             {"bbox": [0, 0, 0.000001, 5], "bbox_mode": 0, "segmentation": [[0, 0, 0, 5, 0, 2]], "category_id": 0}]   # empty after clip
+    g = transform_annotations(annos, 0.5, 0.5, False, 100, 100)
+    assert g["boxes"].tolist() == [[5, 10, 25, 30]] and len(g["polygons"]) == 1
+    assert g["polygons"][0][:2].tolist() == [5.25, 10.25]
+    f = transform_annotations(annos[:1], 0.5, 0.5, True, 100, 100)
+    assert f["boxes"].tolist() == [[75, 10, 95, 30]]
+    assert f["polygons"][0][0] == pytest.approx(100 - 5.25)
+    with pytest.raises(NotImplementedError):
+        transform_annotations([{"bbox": [0, 0, 5, 5], "segmentation": {"size": [5, 5], "counts": b"0"}, "category_id": 0}], 1, 1, False, 5, 5)
+
+
+def _register(n=7):
+    from ampis_amd.data import DatasetCatalog
+    DatasetCatalog.clear()
+    dd = [{"image_id": i, "image_bgr": np.full((40, 64, 3), i, np.uint8), "height": 40, "width": 64,
+           "annotations": [{"bbox": [4, 4, 30, 30], "bbox_mode": 0, "segmentation": [[4, 4, 30, 4, 30, 30, 4, 30]], "category_id": 0}]} for i in range(n)]
+    DatasetCatalog.register("cpu_Train", lambda: dd)
+
+
+def test_train_loader_shards_the_same_stream():
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog, build_detection_train_loader
+    _register()
+    cfg = get_cfg()
+    cfg.DATASETS.TRAIN = ("cpu_Train",)
+    cfg.SOLVER.IMS_PER_BATCH = 4
+    cfg.INPUT.MIN_SIZE_TRAIN = (40,)
+    cfg.INPUT.MAX_SIZE_TRAIN = 64
+    one = build_detection_train_loader(cfg, rank=0, world_size=1, seed=3)
+    r0 = build_detection_train_loader(cfg, rank=0, world_size=2, seed=3)
+    r1 = build_detection_train_loader(cfg, rank=1, world_size=2, seed=3)
+    for _ in range(5):
+        full = [d["image_id"] for d in next(one)]
+        a, b = [d["image_id"] for d in next(r0)], [d["image_id"] for d in next(r1)]
+        assert len(full) == 4 and len(a) == 2 and len(b) == 2
+        assert full == [a[0], b[0], a[1], b[1]]          # rank r takes elements r, r + world, ...
+    d = next(one)[0]
+    assert d["image_bgr"].shape == (40, 64, 3) and d["gt"]["boxes"].shape == (1, 4) and d["height"] == 40
+    DatasetCatalog.clear()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ampis_amd.utils import comm
+    g = torch.full((1000,), float(rank + 1))
+    scale = comm.all_reduce_sum_(g)
+    comm.synchronize()
+    q.put((rank, float(g[0]), scale, comm.get_world_size(), comm.is_main_process()))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world_size_2_gloo():
+    """The N>1 data path: SUM all-reduce of the flat gradient tensor + the 1/world factor, two CPU processes over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r[1] for r in res] == [3.0, 3.0]             # 1 + 2 on both ranks
+    assert all(r[2] == 0.5 and r[3] == 2 for r in res)
+    assert [r[4] for r in res] == [True, False]

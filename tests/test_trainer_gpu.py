@@ -1,0 +1,103 @@
+"""End-to-end mini training through the DefaultTrainer façade (notebook cells 13, 20, 22, 24; ampis/data_utils.py:135-177):
+register a dataset, subclass the trainer the way AmpisTrainer does (validation-loss hook inserted before the writer), train a
+few iterations, check the scalars / checkpoints, then load the final checkpoint into DefaultPredictor."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ddicts(n, h, w, seed):
+    from ampis_amd import synth
+    out = []
+    for i in range(n):
+        img, gt = synth.micrograph(i, h, w, seed=seed)
+        annos = [{"bbox": b.tolist(), "bbox_mode": 0, "segmentation": [p.tolist()], "category_id": 0}
+                 for b, p in list(zip(gt["boxes"], gt["polygons"]))[:50]]
+        out.append({"file_name": f"synthetic_{i}.png", "image_bgr": img, "height": h, "width": w, "image_id": i, "annotations": annos,
+                    "mask_format": "polygonmask", "num_instances": len(annos)})
+    return out
+
+
+def test_train_validate_checkpoint_predict(tmp_path):
+    from ampis_amd import model_zoo
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog, DatasetMapper, MetadataCatalog, build_detection_test_loader
+    from ampis_amd.engine import DefaultPredictor, DefaultTrainer
+    from ampis_amd.engine.hooks import HookBase
+    from ampis_amd.utils import comm
+
+    DatasetCatalog.clear()
+    train, val = _ddicts(4, 192, 256, 50), _ddicts(2, 192, 256, 60)
+    DatasetCatalog.register("particle_Train", lambda: train)
+    DatasetCatalog.register("particle_Val", lambda: val)
+    for d in ("particle_Train", "particle_Val"):
+        MetadataCatalog.get(d).set(**{"thing_classes": ["particle"]})
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.INPUT.MASK_FORMAT = "polygon"
+    cfg.DATASETS.TRAIN = ("particle_Train",)
+    cfg.DATASETS.TEST = ("particle_Val",)
+    cfg.SOLVER.IMS_PER_BATCH = 2
+    cfg.SOLVER.CHECKPOINT_PERIOD = 4
+    cfg.SOLVER.MAX_ITER = 10
+    cfg.SOLVER.BASE_LR = 0.002
+    cfg.SOLVER.WARMUP_ITERS = 2
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
+    cfg.TEST.DETECTIONS_PER_IMAGE = 50
+    cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (192,), 256
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 192, 256
+    cfg.OUTPUT_DIR = str(tmp_path / "particle_output")
+
+    class LossEval(HookBase):          # the call pattern of ampis.data_utils.LossEvalHook (:62-132)
+        def __init__(self, period, model, loader):
+            self._model, self._period, self._loader = model, period, loader
+
+        def after_step(self):
+            nxt = self.trainer.iter + 1
+            if nxt == self.trainer.max_iter or (self._period > 0 and nxt % self._period == 0):
+                losses, mds = [], []
+                for inputs in self._loader:
+                    md = {k: float(v) for k, v in self._model(inputs).items()}
+                    losses.append(sum(md.values()))
+                    mds.append(md)
+                self.trainer.storage.put_scalar("validation_loss", np.mean(losses))
+                for k in mds[0]:
+                    self.trainer.storage.put_scalar("valid_" + k, np.mean([m[k] for m in mds]))
+                comm.synchronize()
+            self.trainer.storage.put_scalars(timetest=12)
+
+    class AmpisLikeTrainer(DefaultTrainer):
+        def build_hooks(self):
+            hooks = super().build_hooks()
+            hooks.insert(-1, LossEval(self.cfg.SOLVER.CHECKPOINT_PERIOD, self.model,
+                                      build_detection_test_loader(self.cfg, self.cfg.DATASETS.TEST[0], DatasetMapper(self.cfg, True))))
+            return hooks
+
+    trainer = AmpisLikeTrainer(cfg)
+    assert type(trainer._hooks[-1]).__name__ == "PeriodicWriter" and isinstance(trainer._hooks[-2], LossEval)
+    trainer.resume_or_load(resume=False)          # MODEL.WEIGHTS is a detectron2:// URL -> warning + random init
+    trainer.train()
+
+    st = trainer.storage
+    tl = [v for v, _ in st.history("total_loss")]
+    assert len(tl) == 10 and all(np.isfinite(tl))
+    assert set(["loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc", "lr", "validation_loss", "valid_loss_mask"]) <= set(st.histories())
+    assert [i for _, i in st.history("validation_loss")] == [3, 7, 9]
+    assert st.history("lr")[0][0] == pytest.approx(0.002 * 0.001) and st.history("lr")[-1][0] == pytest.approx(0.002)
+    assert np.mean(tl[-3:]) < np.mean(tl[:3])          # it learns something on 4 images
+    ckpts = sorted(glob.glob(os.path.join(cfg.OUTPUT_DIR, "*.pth")))
+    assert [os.path.basename(c) for c in ckpts] == ["model_0000003.pth", "model_0000007.pth", "model_final.pth"]
+    assert os.path.isfile(os.path.join(cfg.OUTPUT_DIR, "metrics.json"))
+    assert json.loads(open(os.path.join(cfg.OUTPUT_DIR, "metrics.json")).readlines()[-1])["iteration"] == 9
+
+    # notebook cell 24: the last checkpoint feeds the predictor
+    cfg.MODEL.WEIGHTS = str(ckpts[-1])
+    predictor = DefaultPredictor(cfg)
+    outs = predictor(val[0]["image_bgr"])
+    assert outs["instances"].image_size == (192, 256)
+    DatasetCatalog.clear()
