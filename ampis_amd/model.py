@@ -98,7 +98,7 @@ class MaskRCNN:
         off = np.ctypeslib.as_array(d.rle_off, (B, D))
         ln = np.ctypeslib.as_array(d.rle_len, (B, D))
         total = int((off[ln > 0] + ln[ln > 0]).max()) if (ln > 0).any() else 0
-        pool = np.ctypeslib.as_array(d.rle_counts, (max(total, 1),))
+        pool = np.ctypeslib.as_array(d.rle_counts, (total,)) if total > 0 else np.zeros(1, dtype=np.uint32)
         out = []
         for b in range(B):
             k = int(n[b])

@@ -45,8 +45,13 @@ def test_train_validate_checkpoint_predict(tmp_path):
     cfg.SOLVER.IMS_PER_BATCH = 2
     cfg.SOLVER.CHECKPOINT_PERIOD = 4
     cfg.SOLVER.MAX_ITER = 10
-    cfg.SOLVER.BASE_LR = 0.002
+    cfg.SOLVER.BASE_LR = 0.001
     cfg.SOLVER.WARMUP_ITERS = 2
+    # like the tutorial, start from a checkpoint on disk (here a well-conditioned seeded one: no pretrained weights offline)
+    from ampis_amd import checkpoint, params as P
+    os.makedirs(tmp_path / "models", exist_ok=True)
+    checkpoint.save_checkpoint(tmp_path / "models" / "init.pth", P.init_params(1, seed=4, style="spread"))
+    cfg.MODEL.WEIGHTS = str(tmp_path / "models" / "init.pth")
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
     cfg.TEST.DETECTIONS_PER_IMAGE = 50
     cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (192,), 256
@@ -80,7 +85,7 @@ def test_train_validate_checkpoint_predict(tmp_path):
 
     trainer = AmpisLikeTrainer(cfg)
     assert type(trainer._hooks[-1]).__name__ == "PeriodicWriter" and isinstance(trainer._hooks[-2], LossEval)
-    trainer.resume_or_load(resume=False)          # MODEL.WEIGHTS is a detectron2:// URL -> warning + random init
+    trainer.resume_or_load(resume=False)
     trainer.train()
 
     st = trainer.storage
@@ -88,7 +93,7 @@ def test_train_validate_checkpoint_predict(tmp_path):
     assert len(tl) == 10 and all(np.isfinite(tl))
     assert set(["loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc", "lr", "validation_loss", "valid_loss_mask"]) <= set(st.histories())
     assert [i for _, i in st.history("validation_loss")] == [3, 7, 9]
-    assert st.history("lr")[0][0] == pytest.approx(0.002 * 0.001) and st.history("lr")[-1][0] == pytest.approx(0.002)
+    assert st.history("lr")[0][0] == pytest.approx(0.001 * 0.001) and st.history("lr")[-1][0] == pytest.approx(0.001)
     assert np.mean(tl[-3:]) < np.mean(tl[:3])          # it learns something on 4 images
     ckpts = sorted(glob.glob(os.path.join(cfg.OUTPUT_DIR, "*.pth")))
     assert [os.path.basename(c) for c in ckpts] == ["model_0000003.pth", "model_0000007.pth", "model_final.pth"]
