@@ -65,3 +65,19 @@ def test_sgd_step_matches_torch(setup):
         assert np.abs(got - expect).max() <= 2e-3 * lr * max(np.abs(g).max(), 1e-6) + 1e-7, name
     # frozen tensors did not move
     assert np.array_equal(m.get_tensor("backbone.bottom_up.res2.0.conv1.weight"), npp["backbone.bottom_up.res2.0.conv1.weight"])
+
+
+def test_grad_arena_torch_view_is_zero_copy(setup, gpu_ctx):
+    """The RCCL all-reduce runs on a torch tensor that aliases the gradient arena (no copy): writes through the view are seen by
+    amp_model_get_tensor."""
+    from ampis_amd.utils import comm
+    m = setup["model"]
+    ptr, n = m.grad_arena()
+    t = comm.arena_as_tensor(ptr, n, torch.device("cuda", 0))
+    assert t.is_cuda and t.dtype == torch.float32 and t.numel() == n and t.data_ptr() == ptr
+    before = m.get_tensor("backbone.fpn_output3.weight", grad=True)
+    t.mul_(2.0)
+    torch.cuda.synchronize()
+    after = m.get_tensor("backbone.fpn_output3.weight", grad=True)
+    assert np.allclose(after, 2.0 * before)
+    assert comm.all_reduce_gradients(m, gpu_ctx) == 1.0      # single process: no-op, scale 1
