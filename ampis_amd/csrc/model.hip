@@ -726,7 +726,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const size_t WT_SCRATCH = (size_t)13 << 20;     // floats: transformed weights of the largest layer (fc1: 12.85 M)
     AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
     AMP_ALLOC(wt_scratch, float, WT_SCRATCH);
-    AMP_ALLOC(cs_scratch, float, (size_t)1 << 20);
+    AMP_ALLOC(cs_scratch, float, (size_t)4 << 20);   // ceil(M/512) * N floats of the largest bias-gradient reduction
     auto GW = [&](const ConvW& cw) { return m->garena + (cw.w - m->parena); };
     auto GB = [&](const ConvW& cw) { return m->garena + (cw.shift - m->parena); };
     auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc) -> int {

@@ -152,14 +152,40 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
     }
 }
 
-// column sums of dY [M][N] (bias gradients): two passes, fixed order
-__global__ void colsum_partial_kernel(const float* __restrict__ dy, int M, int N, int rows_per_block, float* __restrict__ partial) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    if (n >= N) return;
-    float s = 0.f;
-    for (int m = r0; m < r1; ++m) s = __fadd_rn(s, dy[(size_t)m * N + n]);
-    partial[(size_t)blockIdx.y * N + n] = s;
+// column sums of dY [M][N] (bias gradients): two passes, fixed order.  Pass 1: a workgroup owns COLSUM_ROWS rows; a thread owns one
+// 16-byte column group and every (256 / N4)-th row, so a wave reads whole 1 KiB row segments; row lanes are combined through LDS.
+constexpr int COLSUM_ROWS = 512;
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int M, int N4, float* __restrict__ partial) {
+    __shared__ cs_f4 red[256];
+    const int tid = threadIdx.x;
+    const int cols = min(N4, 256);               // column groups handled per sweep
+    const int nrl = 256 / cols;                  // row lanes
+    const int c4 = tid % cols, rl = tid / cols;
+    const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+    const cs_f4* src = reinterpret_cast<const cs_f4*>(dy);
+    for (int cbase = 0; cbase < N4; cbase += cols) {
+        const int c = cbase + c4;
+        cs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (rl < nrl && c < N4)
+            for (int r = r0 + rl; r < r1; r += nrl) {
+                const cs_f4 v = src[(size_t)r * N4 + c];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __fadd_rn(acc[q], v[q]);
+            }
+        __syncthreads();
+        red[tid] = acc;
+        __syncthreads();
+        if (rl == 0 && c < N4) {
+            cs_f4 s = red[c4];
+            for (int k = 1; k < nrl; ++k) {
+                const cs_f4 v = red[k * cols + c4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] = __fadd_rn(s[q], v[q]);
+            }
+            reinterpret_cast<cs_f4*>(partial)[(size_t)blockIdx.x * N4 + c] = s;
+        }
+    }
 }
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,12 +258,11 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
     return AMP_OK;
 }
 
-/* out[n] (= or +=) sum_m dy[m][n]; scratch: >= ceil(M/4096)*N floats */
+/* out[n] (= or +=) sum_m dy[m][n]; N % 4 == 0; scratch: >= ceil(M/512)*N floats */
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate) {
-    AMP_REQUIRE(ctx && dy && scratch && out && M >= 0 && N > 0, "amp_colsum: bad argument");
-    const int rows = 4096;
-    const int parts = std::max(1, amp::cdiv(M, rows));
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(amp::cdiv(N, 64), parts), dim3(64), 0, ctx->stream, dy, M, N, rows, scratch);
+    AMP_REQUIRE(ctx && dy && scratch && out && M >= 0 && N > 0 && N % 4 == 0, "amp_colsum: bad argument (N %% 4 != 0?)");
+    const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N / 4, scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 64)), dim3(64), 0, ctx->stream, scratch, parts, N, out, accumulate);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;

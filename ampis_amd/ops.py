@@ -73,7 +73,7 @@ def dgrad_weights(ctx, w, scale=None):
 
 def colsum(ctx, dy):
     M, N = dy.shape
-    scratch = torch.empty(((M + 4095) // 4096 + 1) * N, device=dy.device)
+    scratch = torch.empty(((M + 511) // 512 + 1) * N, device=dy.device)
     out = torch.empty(N, device=dy.device)
     check(lib().amp_colsum(ctx.handle, ptr(_f32c(dy)), M, N, ptr(scratch), ptr(out), 0), "amp_colsum")
     return out

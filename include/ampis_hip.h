@@ -96,7 +96,7 @@ int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, con
 size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d);
 int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                      float* grad, int accumulate);
-/* out[n] (= or +=) sum_m dy[m][n]; scratch >= ceil(M/4096)*N floats */
+/* out[n] (= or +=) sum_m dy[m][n]; N % 4 == 0; scratch >= ceil(M/512)*N floats */
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
