@@ -1,0 +1,74 @@
+"""BASELINE-size invariants (batch of 1024x1024 synthetic micrographs, 200 detections / image): properties that hold at any size
+and need no oracle run -- sortedness, RLE well-formedness, masks inside their boxes, the NMS invariant, bitwise determinism."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def run(gpu_ctx):
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    B, S, K, D = 4, 1024, 2, 200
+    imgs, _ = synth.batch(B, S, S)
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+    m.load_params(P.init_params(K, seed=0, style="spread"))
+    a = m.infer(imgs, rle="counts")
+    b = m.infer(imgs, rle="counts")
+    props = m.tap("prop_boxes"), m.tap("prop_count")
+    return dict(a=a, b=b, S=S, D=D, K=K, props=props)
+
+
+def _iou(b, bs):
+    w = np.clip(np.minimum(b[2], bs[:, 2]) - np.maximum(b[0], bs[:, 0]), 0, None)
+    h = np.clip(np.minimum(b[3], bs[:, 3]) - np.maximum(b[1], bs[:, 1]), 0, None)
+    inter = w * h
+    return inter / ((b[2] - b[0]) * (b[3] - b[1]) + (bs[:, 2] - bs[:, 0]) * (bs[:, 3] - bs[:, 1]) - inter)
+
+
+def test_detections_well_formed(run):
+    S, D, K = run["S"], run["D"], run["K"]
+    for o in run["a"]:
+        n = len(o["boxes"])
+        assert 0 < n <= D
+        assert np.all(np.diff(o["scores"]) <= 0) and o["scores"].min() > 0.05
+        assert o["classes"].min() >= 0 and o["classes"].max() < K
+        b = o["boxes"]
+        assert b.min() >= 0 and b[:, [0, 2]].max() <= S and b[:, [1, 3]].max() <= S
+        assert np.all(b[:, 2] > b[:, 0]) and np.all(b[:, 3] > b[:, 1])
+        # NMS invariant: no kept box suppresses a later kept box of its class
+        for i in range(n - 1):
+            same = o["classes"][i + 1:] == o["classes"][i]
+            assert not np.any(_iou(b[i], b[i + 1:])[same] > 0.5)
+
+
+def test_rle_well_formed_and_inside_box(run):
+    from oracle import rle as orle
+    S = run["S"]
+    for o in run["a"][:2]:
+        for box, mk in list(zip(o["boxes"], o["masks"]))[::7]:
+            c = mk["counts"]
+            assert int(c.sum(dtype=np.int64)) == S * S and np.all(c[1:-1] > 0)      # interior runs are non-empty
+            m = orle.decode_counts(c, S, S)
+            ys, xs = np.nonzero(m)
+            if len(ys):
+                assert xs.min() >= np.floor(box[0]) - 1 and xs.max() <= np.ceil(box[2]) + 1
+                assert ys.min() >= np.floor(box[1]) - 1 and ys.max() <= np.ceil(box[3]) + 1
+            assert np.array_equal(orle.encode_counts(m), c)                         # encode(decode(x)) == x
+
+
+def test_proposals_inside_image_and_nms_invariant(run):
+    pb, pc = run["props"]
+    S = run["S"]
+    for b in range(len(pc)):
+        p = pb[b, :pc[b]]
+        assert pc[b] <= 1000 and p.min() >= 0 and p.max() <= S
+        assert np.all(p[:, 2] > p[:, 0]) and np.all(p[:, 3] > p[:, 1])
+
+
+def test_bitwise_deterministic(run):
+    for x, y in zip(run["a"], run["b"]):
+        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
+        assert np.array_equal(x["classes"], y["classes"])
+        assert all(np.array_equal(p["counts"], q["counts"]) for p, q in zip(x["masks"], y["masks"]))
