@@ -6,6 +6,8 @@
 // char = group + 48, bit 0x20 = continuation, bit 0x10 of the last group = sign, runs i > 2 stored as a delta against
 // run i-2.  Byte format pinned by the reference's five result pickles (tests/golden/rle_pickles.json).
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -175,6 +177,63 @@ int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int int
     }
     AMP_REQUIRE(!overflow, "amp_rle_merge2: more than cap=%d runs", cap);
     *m_out = m;
+    return AMP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// Polygon (flat x0,y0,x1,y1,... ; k vertices) -> run lengths of an h x w mask: pycocotools maskApi.c rleFrPoly, the routine behind
+// RLE.frPyObjects (ampis/structures.py:677) and detectron2's polygons_to_bitmask.  Boundary is traced on a 5x upsampled grid,
+// x-crossings become run boundaries, sorted, differenced, zero-length runs merged.
+int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, int cap, int* m_out) {
+    AMP_REQUIRE(xy && cnts && m_out && k >= 1 && h > 0 && w > 0, "amp_rle_from_polygon: bad argument");
+    const double scale = 5.0;
+    std::vector<int> x(k + 1), y(k + 1);
+    for (int j = 0; j < k; ++j) { x[j] = (int)(scale * xy[2 * j] + 0.5); y[j] = (int)(scale * xy[2 * j + 1] + 0.5); }
+    x[k] = x[0]; y[k] = y[0];
+    std::vector<unsigned long long> a;
+    for (int j = 0; j < k; ++j) {
+        int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1];
+        const int dx = std::abs(xe - xs), dy = std::abs(ys - ye);
+        const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+        if (flip) { std::swap(xs, xe); std::swap(ys, ye); }
+        const int len = dx >= dy ? dx : dy;
+        const double s = dx >= dy ? (dx ? (double)(ye - ys) / dx : 0.0) : (double)(xe - xs) / dy;
+        int pu = 0, pv = 0;
+        for (int d = 0; d <= len; ++d) {
+            const int t = flip ? len - d : d;
+            int u, v;
+            if (dx >= dy) { u = t + xs; v = (int)(ys + s * t + 0.5); } else { v = t + ys; u = (int)(xs + s * t + 0.5); }
+            if (d > 0 && u != pu) {   // consecutive edges share their vertex, so pairs across edges never differ
+                double xd = (double)(u < pu ? u : u - 1);
+                xd = (xd + 0.5) / scale - 0.5;
+                if (std::floor(xd) == xd && xd >= 0 && xd <= w - 1) {
+                    double yd = (double)(v < pv ? v : pv);
+                    yd = (yd + 0.5) / scale - 0.5;
+                    if (yd < 0) yd = 0; else if (yd > h) yd = h;
+                    yd = std::ceil(yd);
+                    a.push_back((unsigned long long)xd * (unsigned long long)h + (unsigned long long)yd);
+                }
+            }
+            pu = u; pv = v;
+        }
+    }
+    a.push_back((unsigned long long)h * (unsigned long long)w);
+    std::sort(a.begin(), a.end());
+    unsigned long long p = 0;
+    for (auto& v : a) { const unsigned long long t = v; v -= p; p = t; }
+    std::vector<unsigned long long> b;
+    size_t j = 0;
+    b.push_back(a[j++]);
+    while (j < a.size()) {
+        if (a[j] > 0) b.push_back(a[j++]);
+        else { ++j; if (j < a.size()) b.back() += a[j++]; }
+    }
+    AMP_REQUIRE((int)b.size() <= cap, "amp_rle_from_polygon: more than cap=%d runs", cap);
+    for (size_t i = 0; i < b.size(); ++i) cnts[i] = (uint32_t)b[i];
+    *m_out = (int)b.size();
     return AMP_OK;
 }
 

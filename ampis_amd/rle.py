@@ -94,3 +94,21 @@ def merge(rles, intersect=False):
                                    int(bool(intersect)), out.ctypes.data_as(C.c_void_p), cap, C.byref(m)), "amp_rle_merge2")
         cur = out[: m.value].copy()
     return {"size": [h, w], "counts": counts_to_string(cur)}
+
+
+def frPyObjects(polys, h, w):
+    """Polygons -> RLE, like pycocotools.mask.frPyObjects for polygon input: `polys` is a list of flat [x0,y0,x1,y1,...]
+    polygons (or one such flat list); returns a list of RLE dicts (or one dict)."""
+    single = len(polys) > 0 and np.isscalar(polys[0])
+    plist = [polys] if single else polys
+    out = []
+    for p in plist:
+        xy = np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1))
+        k = len(xy) // 2
+        cap = 2 * 5 * (4 * (h + w) + 8 * k) + 16
+        buf = np.empty(cap, dtype=np.uint32)
+        m = C.c_int()
+        check(lib().amp_rle_from_polygon(xy.ctypes.data_as(C.c_void_p), k, int(h), int(w), buf.ctypes.data_as(C.c_void_p), cap, C.byref(m)),
+              "amp_rle_from_polygon")
+        out.append({"size": [int(h), int(w)], "counts": counts_to_string(buf[: m.value])})
+    return out[0] if single else out

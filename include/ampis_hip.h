@@ -194,6 +194,8 @@ int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colm
 int amp_rle_area(const uint32_t* cnts, int m, unsigned long long* area);
 int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscrowd, double* iou);
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out);
+/* polygon (k vertices, flat xy) -> runs of an h x w mask (pycocotools rleFrPoly / frPyObjects) */
+int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, int cap, int* m_out);
 
 /* The model: DefaultPredictor(cfg) / predictor(img) ---------------------------------------------- */
 typedef struct amp_model amp_model;

@@ -77,5 +77,24 @@ def main():
     print("wrote", dst, os.path.getsize(dst), "bytes;", n_masks, "masks")
 
 
+def make_via_subset():
+    """tests/golden/via_subset.json: the first two images (all regions) of the reference's VIA particle training annotations plus
+    the per-image region counts of its four VIA files -- input / expected output of get_ddicts('via2')."""
+    src = os.path.join(REF, "examples/powder/data/via_2.0.8")
+    out = {"_via_settings": None, "_via_img_metadata": {}}
+    counts = {}
+    for fn in ["via_powder_particle_masks_training.json", "via_powder_particle_masks_validation.json",
+               "via_powder_satellite_masks_training.json", "via_powder_satellite_masks_validation.json"]:
+        j = json.load(open(os.path.join(src, fn)))
+        counts[fn] = [len(v["regions"]) for v in j["_via_img_metadata"].values()]
+        if fn == "via_powder_particle_masks_training.json":
+            out["_via_settings"] = {"core": {"default_filepath": j["_via_settings"]["core"]["default_filepath"]}}
+            for k, v in list(j["_via_img_metadata"].items())[:2]:
+                out["_via_img_metadata"][k] = v
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "via_subset.json")
+    json.dump({"via": out, "region_counts": counts, "source": "rccohn/AMPIS examples/powder/data/via_2.0.8/*.json"}, open(dst, "w"))
+
+
 if __name__ == "__main__":
     main()
+    make_via_subset()
