@@ -11,6 +11,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -118,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=4, help="timed training steps of the secondary `train` object (0 = skip)")
+    ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog for the training leg, seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,15 +171,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- secondary measurement: one training step (BASELINE configs[2] / [3]): local batch 16, forward + 5 losses + backward +
-    # gradient all-reduce over RCCL (N > 1) + SGD.  Never allowed to break the headline line above.
-    train_obj = None
-    if args.train_steps > 0:
-        try:
-            train_obj = train_leg(ctx, model, dev, rank, world, args.train_steps, barrier)
-        except Exception as e:   # noqa: BLE001
-            train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
-
+    out = None
     if rank == 0:
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         try:
@@ -208,11 +202,37 @@ def main():
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
                          "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
         }
+
+    emitted = threading.Lock()
+
+    def emit(train_obj):
+        """Rank 0 prints the ONE JSON line, exactly once (also from the watchdog below)."""
+        if not emitted.acquire(blocking=False) or out is None:
+            return
         if train_obj is not None:
             out["train"] = train_obj
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out), flush=True)
+
+    # ---- secondary measurement: one training step (BASELINE configs[2] / [3]): local batch 16, forward + 5 losses + backward +
+    # gradient all-reduce over RCCL (N > 1) + SGD.  Never allowed to break the headline line above: an exception is reported in the
+    # object, and a collective that does not return (a rank died) is cut off by a watchdog that prints the headline and exits.
+    train_obj = None
+    if args.train_steps > 0:
+        def on_stall():
+            log(f"rank {rank}: training leg exceeded {args.train_timeout} s; emitting the inference line without it")
+            emit({"error": f"training leg did not finish within {args.train_timeout} s"})
+            os._exit(0)
+        dog = threading.Timer(args.train_timeout, on_stall)
+        dog.daemon = True
+        dog.start()
+        try:
+            train_obj = train_leg(ctx, model, dev, rank, world, args.train_steps, barrier)
+        except Exception as e:   # noqa: BLE001
+            train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+    emit(train_obj)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -106,3 +106,42 @@ def test_deconv2x2_scatter(gpu_ctx):
     torch.cuda.synchronize()
     assert y.shape == (3, 28, 28, 64)
     assert (y.cpu() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["plain", "res", "up", "deconv", "s2scatter_mask", "ragged"])
+def test_fast_epilogue_equals_generic_bitwise(gpu_ctx, mode):
+    """The straight-line epilogue (Cout % 4 == 0) and the generic one do the same fp32 operations: outputs must be identical."""
+    import ctypes as C
+    from ampis_amd._lib import ConvDesc, check, lib, ptr
+    g = torch.Generator().manual_seed(3)
+    d = "cuda:0"
+    B, H, W, Cin, Cout = (2, 18, 22, 64, 192) if mode != "ragged" else (1, 13, 7, 32, 72)
+    x = torch.randn(B, H, W, Cin, generator=g).to(d)
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) * 0.1).to(d)
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(d), torch.randn(Cout, generator=g).to(d)
+    res = mask = None
+    res_mode = out_mode = 0
+    yshape = (B, H, W, Cout)
+    if mode in ("res", "ragged"):
+        res, res_mode = torch.randn(B, H, W, Cout, generator=g).to(d), 1
+    elif mode == "up":
+        res, res_mode = torch.randn(B, H // 2, W // 2, Cout, generator=g).to(d), 2
+    elif mode == "deconv":
+        out_mode, yshape = 1, (B, 2 * H, 2 * W, Cout // 4)
+    elif mode == "s2scatter_mask":
+        out_mode, yshape = 2, (B, 2 * H, 2 * W, Cout)
+        mask = torch.randn(*yshape, generator=g).to(d)
+    desc = ConvDesc(B, H, W, Cin, Cout, 1, 1, 1, 0, 1, res_mode, out_mode)
+    outs = []
+    for generic in (0, 1):
+        lib().amp_debug_set_conv_generic_epilogue(generic)
+        y = torch.full(yshape, 7.0, device=d)
+        try:
+            check(lib().amp_conv2d_nhwc_ex(gpu_ctx.handle, C.byref(desc), ptr(x), ptr(w), ptr(sc), ptr(sh),
+                                           None if res is None else ptr(res), None if mask is None else ptr(mask), ptr(y)))
+            torch.cuda.synchronize()
+        finally:
+            lib().amp_debug_set_conv_generic_epilogue(0)
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert outs[0].abs().max() > 0

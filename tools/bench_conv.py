@@ -32,10 +32,13 @@ SHAPES = [
 
 def main():
     ctx = ops.torch_context(0)
+    only = os.environ.get("AMP_ONLY")
     d = "cuda:0"
     out = []
     for shp in SHAPES:
         name, B, H, W, Cin, Cout, k, s, p = shp[:9]
+        if only and not any(name.startswith(o) for o in only.split(',')):
+            continue
         mode = shp[9] if len(shp) > 9 else ""
         kh, kw = (k if isinstance(k, tuple) else (k, k))
         x = torch.randn(B, H, W, Cin, device=d)
