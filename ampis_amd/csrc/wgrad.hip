@@ -29,7 +29,21 @@ struct WgradArgs {
     int rows_per_split;     // multiple of 32
     int ntn, ntc, nsplit;
     unsigned int dy_bytes, x_bytes;
+    const unsigned int* rowtab;   // [KH*KW][Mpad] X-row byte offsets (wgrad_rowtab_kernel)
+    int Mpad;
+    unsigned int div_howo_mul, div_wo_mul;   // x / d == (x * mul) >> shr for x < 2^29 (mul = ceil(2^shr / d))
+    int div_howo_shr, div_wo_shr;
 };
+
+__device__ __forceinline__ unsigned int fastdiv(unsigned int x, unsigned int mul, int shr) {
+    return (unsigned int)(((unsigned long long)x * mul) >> shr);
+}
+void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
+    int l = 0;
+    while ((1ull << l) < d) ++l;
+    *shr = 29 + l;
+    *mul = (unsigned int)(((1ull << *shr) + d - 1) / d);
+}
 
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BKW * 128];   // 2 buffers x (P 32x128 + Q 32x128)
@@ -39,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     const int wm = wave >> 1, wn = wave & 1;       // wave tile: 64 (n) x 64 (c')
     const int l31 = lane & 31, lh = lane >> 5;
 
-    int bid = blockIdx.x;
+    int bid = amp::xcd_remap(blockIdx.x, gridDim.x);   // splits sharing a pixel range (same dY / X rows) stay inside one XCD's L2
     const int tile_c = bid % a.ntc; bid /= a.ntc;
     const int tile_n = bid % a.ntn; bid /= a.ntn;
     const int split = bid;
@@ -47,7 +61,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     const int kp0 = tile_c * TC;
     const int tap = kp0 / a.Cin;
     const int c0 = kp0 - tap * a.Cin;
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
     const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BKW - 1) / BKW : 0;
@@ -55,46 +68,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
 
-    // staging: DMA instruction g (0..3) of this wave fills tile rows 8*wave + 2g + (lane>>5), 16-B chunk lane&31
+    // staging: DMA instruction g (0..3) of this wave fills tile rows 8*wave + 2g + (lane>>5), 16-B chunk lane&31.
+    // dY: the row byte offset is linear in m -> the step part rides in the scalar soffset, the lane part is constant.  Rows past
+    // the slice need no predicate: their X rows are zero-filled, and rows past the tensor are out of the buffer (zero fill).
+    // X: pixel -> (b,oy,ox) -> tap shift -> bounds -> byte offset is ~40 integer operations per row.  Done per lane in front of
+    // the MFMAs it cost 20 % of the kernel, done on the scalar unit 9 %; it depends only on (pixel, tap), so wgrad_rowtab_kernel
+    // tabulates it once per call ([tap][Mpad] byte offsets, 0x80000000 = zero row) and a lane fetches its row's entry one step
+    // ahead: 4 dword loads + 4 adds per step.
     const int chunk = lane & 31;
-    const int HoWo = a.Ho * a.Wo;
-    int r_b[4], r_oy[4], r_ox[4];          // pixel of this lane's 4 rows (advanced by 32 pixels per step)
-    unsigned int p_voff[4];                // dY row byte offset (+ n0 + chunk), OOB when n is out of range
+    unsigned int p_voff[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int r = 8 * wave + 2 * g + lh;
-        const int m = m_begin + r;
-        r_b[g] = m / HoWo;
-        const int rem = m - r_b[g] * HoWo;
-        r_oy[g] = rem / a.Wo;
-        r_ox[g] = rem - r_oy[g] * a.Wo;
-        const int n = n0 + 4 * chunk;
-        p_voff[g] = (n < a.N) ? (unsigned int)(((size_t)m * a.N + n) * 4) : OOB;   // N % 4 == 0: a chunk is all-in or all-out
+        const int n = n0 + 4 * chunk;               // N % 4 == 0: a chunk is all-in or all-out
+        p_voff[g] = (n < a.N) ? (unsigned int)(((8 * wave + 2 * g + lh) * a.N + n) * 4) : OOB;
     }
-    const unsigned int p_step = (unsigned int)(BKW * a.N * 4);
-    int staged = 0;                        // steps staged so far
-
-    auto stage = [&](int buf) {
+    const unsigned int q_lane = (unsigned int)((c0 + 4 * chunk) * 4);
+    const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * wave + lh;   // + 32*step + 2g
+    unsigned int q_voff[4];                // table entries of the step whose DMA is issued next
+    auto fetch_rows = [&](int step) {      // step < nsteps: m_begin + 32*step + 31 < Mpad
+#pragma unroll
+        for (int g = 0; g < 4; ++g) q_voff[g] = tab[step * BKW + 2 * g];
+    };
+    auto stage_dma = [&](int buf, int step) {
         float* P = lds + buf * (2 * BKW * 128);
         float* Q = P + BKW * 128;
+        const int p_soff = (m_begin + step * BKW) * a.N * 4;              // uniform; < 2^31: dy_bytes < 2 GiB
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int r = 8 * wave + 2 * g + lh;
-            const int m = m_begin + staged * BKW + r;
-            // dY rows: m beyond the slice / tensor contribute nothing
-            const unsigned int pv = (m < m_end && p_voff[g] != OOB) ? p_voff[g] + (unsigned int)staged * p_step : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (__attribute__((address_space(3))) void*)(P + (8 * wave + 2 * g) * 128), 16,
-                                                     (int)pv, 0, 0, 0);
-            const int iy = r_oy[g] * a.stride - a.pad + ky, ix = r_ox[g] * a.stride - a.pad + kx;
-            const bool v = m < m_end && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned int qv = v ? (unsigned int)((((size_t)(r_b[g] * a.H + iy) * a.W + ix) * a.Cin + c0 + 4 * chunk) * 4) : OOB;
+                                                     (int)p_voff[g], p_soff, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(Q + (8 * wave + 2 * g) * 128), 16,
-                                                     (int)qv, 0, 0, 0);
-            // advance this row by 32 pixels
-            r_ox[g] += BKW;
-            while (r_ox[g] >= a.Wo) { r_ox[g] -= a.Wo; if (++r_oy[g] == a.Ho) { r_oy[g] = 0; ++r_b[g]; } }
+                                                     (int)(q_voff[g] + q_lane), 0, 0, 0);   // 0x80000000 + (< 64 KiB) stays out of range
         }
-        ++staged;
     };
 
     f32x16 acc[2][2];
@@ -106,22 +111,46 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (nsteps > 0) {
-        stage(0);
+        fetch_rows(0);
+        stage_dma(0, 0);
+        if (nsteps > 1) fetch_rows(1);
         __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             const int cur = step & 1;
-            if (step + 1 < nsteps) stage(cur ^ 1);
-            const float* P = lds + cur * (2 * BKW * 128) + wm * 64 + l31;
-            const float* Q = lds + cur * (2 * BKW * 128) + BKW * 128 + wn * 64 + l31;
+            const bool more = step + 1 < nsteps;
+            if (more) {
+                stage_dma(cur ^ 1, step + 1);
+                if (step + 2 < nsteps) fetch_rows(step + 2);
+            }
+            const float* P = lds + cur * (2 * BKW * 128) + wm * 64 + l31 + lh * 128;
+            const float* Q = lds + cur * (2 * BKW * 128) + BKW * 128 + wn * 64 + l31 + lh * 128;
+            // fragments of 4 k-pairs per group (8 ds_read2 feed 16 MFMAs), fetched one group ahead into the other register set.
+            // The sched_barriers pin that order: left alone the scheduler sinks every read to just before its first use
+            // (2 reads / wait / 4 MFMAs), which exposes the LDS latency after every 4th MFMA (104 TF).
+            float fa[2][4][2], fb[2][4][2];
+            auto fetch = [&](int tg, int bufi) {
 #pragma unroll
-            for (int t = 0; t < BKW / 2; ++t) {
-                const int k = 2 * t + lh;
-                const float a0 = P[k * 128], a1 = P[k * 128 + 32];
-                const float b0 = Q[k * 128], b1 = Q[k * 128 + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                for (int u = 0; u < 4; ++u) {
+                    const float* p = P + (tg * 4 + u) * 256;
+                    const float* q = Q + (tg * 4 + u) * 256;
+                    fa[bufi][u][0] = p[0]; fa[bufi][u][1] = p[32];
+                    fb[bufi][u][0] = q[0]; fb[bufi][u][1] = q[32];
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tg = 0; tg < BKW / 8; ++tg) {
+                const int c = tg & 1;
+                if (tg + 1 < BKW / 8) fetch(tg + 1, c ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][u][0], fb[c][u][0], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][u][0], fb[c][u][1], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][u][1], fb[c][u][0], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][u][1], fb[c][u][1], acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
@@ -139,6 +168,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
                 if (n < a.N && kp < a.Kp) out[(size_t)n * a.Kp + kp] = acc[i][j][e];
             }
         }
+}
+
+// rowtab[tap][m] = byte offset of the input pixel that output pixel m sees through tap (ky,kx), or 0x80000000 (outside the image, or
+// m >= M): the operand staging of wgrad_mfma_kernel reads it instead of redoing the index arithmetic every step.
+__global__ void wgrad_rowtab_kernel(const WgradArgs a, unsigned int* __restrict__ tab) {
+    const size_t total = (size_t)a.KH * a.KW * a.Mpad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i / a.Mpad);
+        const unsigned int m = (unsigned int)(i - (size_t)tap * a.Mpad);
+        const int ky = tap / a.KW, kx = tap - ky * a.KW;
+        const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+        const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
+        const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+        const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+        const int iy = (int)oy * a.stride - a.pad + ky, ix = (int)ox * a.stride - a.pad + kx;
+        const bool v = (int)m < a.M && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        tab[i] = v ? (unsigned int)(((b * a.H + iy) * a.W + ix) * a.Cin) * 4u : OOB;
+    }
 }
 
 // grad[n][k'] (= or +=) scale[n] * sum_s partial[s][n][k']   (fixed order -> reproducible)
@@ -225,7 +272,8 @@ size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d) {
     const int Kp = d->KH * d->KW * d->Cin;
     const int tiles = amp::cdiv(d->Cout, TN) * amp::cdiv(Kp, TC);
     int nsplit = (int)std::max(1LL, std::min((long long)amp::cdiv(2048, tiles), (M + 1023) / 1024));
-    return (size_t)nsplit * d->Cout * Kp;
+    const long long Mpad = (M + BKW - 1) / BKW * BKW;
+    return (size_t)nsplit * d->Cout * Kp + (size_t)d->KH * d->KW * Mpad;   // partial slabs + the row table (4-byte entries)
 }
 
 int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
@@ -250,6 +298,14 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
     const size_t dyb = (size_t)M * a.N * 4, xb = (size_t)a.B * a.H * a.W * a.Cin * 4;
     AMP_REQUIRE(dyb < (size_t)OOB && xb < (size_t)OOB, "amp_conv2d_wgrad: operand larger than 2 GiB (split the batch)");
     a.dy_bytes = (unsigned int)dyb; a.x_bytes = (unsigned int)xb;
+    AMP_REQUIRE(M + 64 < (1ll << 29), "amp_conv2d_wgrad: too many output pixels for the multiply-shift division");
+    set_fastdiv((unsigned int)(a.Ho * a.Wo), &a.div_howo_mul, &a.div_howo_shr);
+    set_fastdiv((unsigned int)a.Wo, &a.div_wo_mul, &a.div_wo_shr);
+    a.Mpad = amp::cdiv(a.M, BKW) * BKW;
+    unsigned int* rowtab = reinterpret_cast<unsigned int*>(scratch + (size_t)a.nsplit * a.N * a.Kp);
+    a.rowtab = rowtab;
+    const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
+    hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
     hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
     const size_t nk = (size_t)a.N * a.Kp;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, ctx->stream, scratch,
