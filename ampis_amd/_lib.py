@@ -38,7 +38,8 @@ class ModelCfg(C.Structure):
                 ("train_enable", C.c_int), ("pre_nms_topk_train", C.c_int), ("post_nms_topk_train", C.c_int),
                 ("rpn_batch", C.c_int), ("rpn_pos_frac", C.c_float), ("rpn_iou_lo", C.c_float), ("rpn_iou_hi", C.c_float),
                 ("roi_batch", C.c_int), ("roi_fg_frac", C.c_float), ("roi_iou", C.c_float),
-                ("max_gt", C.c_int), ("max_poly_doubles", C.c_int)]
+                ("max_gt", C.c_int), ("max_poly_doubles", C.c_int),
+                ("resnet_depth", C.c_int), ("num_groups", C.c_int), ("width_per_group", C.c_int), ("stride_in_1x1", C.c_int)]
 
 
 class Gt(C.Structure):
@@ -95,6 +96,8 @@ def _declare(L):
         "amp_memset": ([vp, vp, i, C.c_size_t], i),
         "amp_conv2d_nhwc": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp], i),
         "amp_conv2d_nhwc_ex": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_group_expand_weights": ([vp, vp, i, i, i, i, vp], i),
+        "amp_conv2d_grouped_nhwc": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, vp], i),
         "amp_conv_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
         "amp_conv2d_wgrad": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i], i),
         "amp_colsum": ([vp, vp, i, i, vp, vp, i], i),

@@ -11,7 +11,7 @@ import torch
 from . import params as P
 
 
-def load_checkpoint(path, num_classes):
+def load_checkpoint(path, num_classes, arch="R50"):
     path = str(path)
     if path.startswith(("http://", "https://", "detectron2://")):
         raise FileNotFoundError(f"{path}: fetching weights needs a network; put the file on disk and set cfg.MODEL.WEIGHTS to its path")
@@ -25,7 +25,7 @@ def load_checkpoint(path, num_classes):
         data = torch.load(path, map_location="cpu", weights_only=False)
         state = data["model"] if isinstance(data, dict) and "model" in data else data
     out = {}
-    want = P.param_shapes(num_classes)
+    want = P.param_shapes(num_classes, arch)
     for name, shape in want.items():
         if name not in state:
             raise KeyError(f"{path}: checkpoint has no tensor '{name}'")

@@ -39,6 +39,7 @@ struct ConvArgs {
     int M, K, nsteps;
     int relu, res_mode, out_mode;
     int ntn;  // number of N tiles
+    int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
     unsigned int div_howo_mul, div_wo_mul;   // x / d == (x * mul) >> shr for every x < 2^29 (Granlund-Montgomery, mul = ceil(2^shr / d))
     int div_howo_shr, div_wo_shr;
@@ -485,7 +486,8 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     }
     unsigned int a_voff[GA];              // byte offset of the input pixel of the current tap (+ swizzled chunk), or OOB
 
-    const int csteps = STEM ? 1 : a.Cin / BK;   // K-steps per tap
+    const int csteps = STEM ? 1 : a.cin_win / BK;   // K-steps per tap
+    const int a_win = a.grouped ? n0 * 4 : 0;   // bytes: first input channel of this N-tile's window (grouped conv)
     const int kw_taps = STEM ? 1 : a.KW;        // STEM: the 8 taps of a row travel inside one K-step
     int ky = 0, kx = 0, cs = 0;           // block-uniform tap state of the tile being STAGED
     int kstep = 0;                        // index of the tile being staged
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
         }
         float* As = lds + buf * TILE_FLOATS;
         float* Bs = As + BM * BK;
-        const int a_soff = cs * (BK * 4);         // bytes, block-uniform
+        const int a_soff = cs * (BK * 4) + a_win;   // bytes, block-uniform
         const int b_soff = kstep * (BK * 4);
 #pragma unroll
         for (int g = 0; g < GA; ++g)
@@ -588,16 +590,56 @@ extern "C" void amp_debug_set_conv_generic_epilogue(int on) { g_conv_generic_epi
 static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
 extern "C" void amp_debug_set_conv_ablate(int mode) { g_conv_ablate = mode; }
 
+static int conv_impl(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* scale,
+                     const float* shift, const float* res, const float* mask, float* y);
+
 extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
-                                  const float* shift, const float* res, const float* mask, float* y);
+                                  const float* shift, const float* res, const float* mask, float* y) {
+    return conv_impl(ctx, d, 1, x, w, scale, shift, res, mask, y);
+}
+
+// Grouped convolution (ResNeXt conv2: Cin == Cout, groups | Cin, channels per group in {8,16,32,64}).  The kernel is the dense
+// LDS-DMA kernel with 64-wide N tiles whose K range is restricted to the tile's own 64 input channels; `w_win` is the
+// block-diagonal window layout [Cout][KH][KW][64] produced by amp_group_expand_weights (zeros outside the channel's group).
+extern "C" int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
+                                       const float* scale, const float* shift, const float* res, float* y) {
+    AMP_REQUIRE(d && groups >= 1, "amp_conv2d_grouped_nhwc: bad argument");
+    return conv_impl(ctx, d, groups, x, w_win, scale, shift, res, nullptr, y);
+}
+
+namespace {
+__global__ void group_expand_kernel(const float* __restrict__ w, int Cout, int taps, int cpg, float* __restrict__ out) {
+    const size_t total = (size_t)Cout * taps * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 63);
+        const size_t nt = i >> 6;
+        const int t = (int)(nt % taps), n = (int)(nt / taps);
+        const int c = (n & ~63) + j;                  // input channel of window slot j
+        const int g = n / cpg;
+        out[i] = (c / cpg == g) ? w[((size_t)n * taps + t) * cpg + (c - g * cpg)] : 0.f;
+    }
+}
+}  // namespace
+
+// w [Cout][KH][KW][cpg] (grouped OHWI) -> w_win [Cout][KH][KW][64]
+extern "C" int amp_group_expand_weights(amp_ctx* ctx, const float* w, int Cout, int KH, int KW, int cpg, float* w_win) {
+    AMP_REQUIRE(ctx && w && w_win && Cout > 0 && KH > 0 && KW > 0, "amp_group_expand_weights: bad argument");
+    AMP_REQUIRE((cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64) && Cout % 64 == 0,
+                "amp_group_expand_weights: channels per group must be 8/16/32/64 and Cout a multiple of 64 (got %d, %d)", cpg, Cout);
+    const size_t total = (size_t)Cout * KH * KW * 64;
+    hipLaunchKernelGGL(group_expand_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream, w, Cout,
+                       KH * KW, cpg, w_win);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
 
 extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                                const float* scale, const float* shift, const float* res, float* y) {
     return amp_conv2d_nhwc_ex(ctx, d, x, w, scale, shift, res, nullptr, y);
 }
 
-extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
-                                  const float* shift, const float* res, const float* mask, float* y) {
+static int conv_impl(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* scale,
+                     const float* shift, const float* res, const float* mask, float* y) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -619,7 +661,17 @@ extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const fl
     AMP_REQUIRE(Mll < (1ll << 31) / 4 && (long long)a.B * a.H * a.W < (1ll << 31),
                 "amp_conv2d_nhwc: tensor too large for 32-bit pixel indices");
     a.M = (int)Mll;
-    a.K = a.KH * a.KW * a.Cin;
+    a.grouped = groups > 1;
+    a.cin_win = a.Cin;
+    int cpg = a.Cin;
+    if (a.grouped) {
+        AMP_REQUIRE(d->Cin == d->Cout && d->Cin % groups == 0 && d->Cout % 64 == 0 && d->out_mode == 0,
+                    "amp_conv2d_grouped_nhwc: needs Cin == Cout, a multiple of 64 and of groups, out_mode 0");
+        cpg = d->Cin / groups;
+        AMP_REQUIRE(cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64, "amp_conv2d_grouped_nhwc: %d channels per group (8/16/32/64 supported)", cpg);
+        a.cin_win = 64;
+    }
+    a.K = a.KH * a.KW * a.cin_win;
     a.nsteps = amp::cdiv(a.K, BK);
     a.relu = d->relu; a.res_mode = d->res_mode; a.out_mode = d->out_mode;
 
@@ -633,8 +685,8 @@ extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const fl
     if (ctx->prof_on) {
         if (ctx->prof_used < ctx->prof_pool.size()) {
             rec = &ctx->prof_pool[ctx->prof_used++];
-            rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)d->Cin;
-            rec->variant = (a.Cout > 64 && (a.Cin % BK != 0 || ntm * amp::cdiv(a.Cout, 128) >= 512)) ? 0 : 1;
+            rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)cpg;   // useful work
+            rec->variant = (!a.grouped && a.Cout > 64 && (a.Cin % BK != 0 || ntm * amp::cdiv(a.Cout, 128) >= 512)) ? 0 : 1;
             AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
         } else {
             ctx->prof_truncated = true;
@@ -645,6 +697,7 @@ extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const fl
     // LDS-DMA kernel: every layer but the stem (Cin = 4); buffers must stay below the out-of-range marker (2 GiB)
     const bool small = g_conv_ablate == 0 && x_bytes < (size_t)OOB_VOFF && w_bytes < (size_t)OOB_VOFF;
     const bool glds = (a.Cin % BK == 0) && small;
+    AMP_REQUIRE(!a.grouped || glds, "amp_conv2d_grouped_nhwc: operands must stay below 2 GiB");
     const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
     if (stem) {
         a.ntn = 1;
@@ -653,7 +706,7 @@ extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const fl
     } else if (glds) {
         const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
         // BN = 64 also for wide layers whose 128-wide grid would leave CUs idle (2 workgroups fit per CU)
-        if (a.Cout > 64 && nblk128 >= 512) {
+        if (!a.grouped && a.Cout > 64 && nblk128 >= 512) {
             a.ntn = amp::cdiv(a.Cout, 128);
             a.nblk = ntm * a.ntn;
             launch_glds<128, false>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

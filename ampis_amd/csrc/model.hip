@@ -22,6 +22,7 @@ struct ConvW {
     float* scale = nullptr;  // device [Cout] or null
     float* shift = nullptr;  // device [Cout] or null
     int cout = 0, cin = 0, kh = 0, kw = 0;
+    int groups = 1;          // > 1: w is the window layout [Cout][KH][KW][64] of amp_group_expand_weights (ResNeXt conv2)
 };
 
 struct NamedBuf {
@@ -47,8 +48,6 @@ struct Bump {
 };
 
 const char* kStage[4] = {"res2", "res3", "res4", "res5"};
-const int kBlocks[4] = {3, 4, 6, 3};
-const int kMid[4] = {64, 128, 256, 512};
 const int kOut[4] = {256, 512, 1024, 2048};
 const int kStride[4] = {1, 2, 2, 2};
 
@@ -57,6 +56,8 @@ const int kStride[4] = {1, 2, 2, 2};
 struct amp_model {
     amp_ctx* ctx = nullptr;
     amp_model_cfg cfg;
+    int nblk[4] = {3, 4, 6, 3};          // RESNETS.DEPTH 50 / 101
+    int mid[4] = {64, 128, 256, 512};     // NUM_GROUPS * WIDTH_PER_GROUP * 2^stage
     // ---- parameters ----
     float* parena = nullptr;
     size_t parena_floats = 0, parena_used = 0;
@@ -118,7 +119,7 @@ void expect_conv_bn(amp_model* m, const std::string& p) {
 void build_expected(amp_model* m) {
     expect_conv_bn(m, "backbone.bottom_up.stem.conv1");
     for (int s = 0; s < 4; ++s)
-        for (int b = 0; b < kBlocks[s]; ++b) {
+        for (int b = 0; b < m->nblk[s]; ++b) {
             const std::string p = std::string("backbone.bottom_up.") + kStage[s] + "." + std::to_string(b);
             if (b == 0) expect_conv_bn(m, p + ".shortcut");
             expect_conv_bn(m, p + ".conv1");
@@ -157,6 +158,7 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
     amp_conv_desc d;
     d.B = B; d.H = H; d.W = W; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw;
     d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
+    if (cw.groups > 1) return amp_conv2d_grouped_nhwc(m->ctx, &d, cw.groups, x, cw.w, cw.scale, cw.shift, res, y);
     return amp_conv2d_nhwc(m->ctx, &d, x, cw.w, cw.scale, cw.shift, res, y);
 }
 
@@ -218,7 +220,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     float* res_out[4];
     int res_h[4], res_w[4];
     for (int s = 0; s < 4; ++s) {
-        for (int b = 0; b < kBlocks[s]; ++b) {
+        for (int b = 0; b < m->nblk[s]; ++b) {
             const std::string p = std::string("backbone.bottom_up.") + kStage[s] + "." + std::to_string(b);
             const int st = (b == 0) ? kStride[s] : 1;
             const int oh = (ch - 1) / st + 1, ow = (cw_ - 1) / st + 1;
@@ -232,11 +234,14 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
                 if (!dry) AMP_TRY(launch_conv(m, CONV((p + ".shortcut").c_str()), cur, B, ch, cw_, st, 0, false, 0, nullptr, 0, sc));
                 shortcut = sc;
             }
-            AMP_ALLOC(t1, float, (size_t)B * oh * ow * kMid[s]);
-            AMP_ALLOC(t2, float, (size_t)B * oh * ow * kMid[s]);
+            // RESNETS.STRIDE_IN_1X1: the block's stride sits in conv1 (MSRA R50) or in the 3x3 conv2 (ResNeXt)
+            const int st1 = c.stride_in_1x1 ? st : 1, st2 = c.stride_in_1x1 ? 1 : st;
+            const int h1 = (ch - 1) / st1 + 1, w1 = (cw_ - 1) / st1 + 1;
+            AMP_ALLOC(t1, float, (size_t)B * h1 * w1 * m->mid[s]);
+            AMP_ALLOC(t2, float, (size_t)B * oh * ow * m->mid[s]);
             if (!dry) {
-                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st, 0, true, 0, nullptr, 0, t1));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, oh, ow, 1, 1, true, 0, nullptr, 0, t2));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2));
                 AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out));
             }
             (void)mark;
@@ -244,7 +249,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
                 amp_model::BlockAct ba;
                 ba.key = p; ba.x_in = cur; ba.t1 = t1; ba.t2 = t2; ba.sc = (b == 0) ? const_cast<float*>(shortcut) : nullptr; ba.out = out;
                 ba.in_h = ch; ba.in_w = cw_; ba.oh = oh; ba.ow = ow; ba.cin = (b == 0) ? (s == 0 ? 64 : kOut[s - 1]) : kOut[s];
-                ba.mid = kMid[s]; ba.cout = kOut[s]; ba.stride = st; ba.stage = s; ba.has_sc = (b == 0);
+                ba.mid = m->mid[s]; ba.cout = kOut[s]; ba.stride = st; ba.stage = s; ba.has_sc = (b == 0);
                 if (!dry) m->blocks.push_back(ba);
             } else {
                 ws.off = keep;   // release sc/t1/t2 (stream order makes reuse safe)
@@ -876,9 +881,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         int hh = ((H + 31) / 32 * 32) / 4, ww = ((W + 31) / 32 * 32) / 4;
         for (int s_ = 1; s_ < 4; ++s_) {
             hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1;
-            for (int b_ = 0; b_ < kBlocks[s_]; ++b_) {
-                AMP_ALLOC(r1, float, (size_t)B * hh * ww * kMid[s_]);
-                AMP_ALLOC(r2, float, (size_t)B * hh * ww * kMid[s_]);
+            for (int b_ = 0; b_ < m->nblk[s_]; ++b_) {
+                AMP_ALLOC(r1, float, (size_t)B * hh * ww * m->mid[s_]);
+                AMP_ALLOC(r2, float, (size_t)B * hh * ww * m->mid[s_]);
                 AMP_ALLOC(r3, float, (size_t)B * hh * ww * kOut[s_]);
                 AMP_ALLOC(r4, float, (size_t)B * hh * ww * kOut[s_]);
                 (void)r1; (void)r2; (void)r3; (void)r4;
@@ -949,6 +954,7 @@ int amp_model_cfg_default(amp_model_cfg* c) {
     c->rpn_batch = 256; c->rpn_pos_frac = 0.5f; c->rpn_iou_lo = 0.3f; c->rpn_iou_hi = 0.7f;
     c->roi_batch = 512; c->roi_fg_frac = 0.25f; c->roi_iou = 0.5f;
     c->max_gt = 16384; c->max_poly_doubles = 16384 * 80;
+    c->resnet_depth = 50; c->num_groups = 1; c->width_per_group = 64; c->stride_in_1x1 = 1;
     return AMP_OK;
 }
 
@@ -964,9 +970,35 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     if (m->cfg.rle_pool_counts == 0)
         m->cfg.rle_pool_counts = (size_t)m->cfg.max_batch * m->cfg.detections_per_image * 16384;
     const int K = cfg->num_classes;
+    {   // backbone variant: R50 (3,4,6,3) or R101 / X101 (3,4,23,3); ResNeXt = grouped 3x3 with the stride in it
+        amp_model_cfg& c = m->cfg;
+        if (c.resnet_depth == 0) { c.resnet_depth = 50; c.num_groups = 1; c.width_per_group = 64; c.stride_in_1x1 = 1; }
+        const bool ok_depth = c.resnet_depth == 50 || c.resnet_depth == 101;
+        const int width = c.num_groups * c.width_per_group;
+        if (!ok_depth || c.num_groups < 1 || width < 64 || width % 64 != 0 ||
+            (c.num_groups > 1 && !(c.width_per_group == 8 || c.width_per_group == 16 || c.width_per_group == 32 || c.width_per_group == 64)) ||
+            (c.num_groups > 1 && c.train_enable)) {
+            amp::set_error("amp_model_create: unsupported backbone (depth %d, groups %d x width %d%s)", c.resnet_depth, c.num_groups,
+                           c.width_per_group, (c.num_groups > 1 && c.train_enable) ? ", training a grouped backbone is not built" : "");
+            delete m;
+            return AMP_ERR_ARG;
+        }
+        m->nblk[2] = (c.resnet_depth == 101) ? 23 : 6;
+        for (int s_ = 0; s_ < 4; ++s_) m->mid[s_] = width << s_;
+    }
     build_expected(m);
-    // parameter arena: ~44.5 M floats + padding
-    m->parena_floats = (size_t)46 * 1000 * 1000 + (size_t)K * 6 * 1024 + 65536;
+    // parameter arena: every tensor (R50-FPN ~44.5 M floats) + the 64-wide window copies of grouped 3x3 weights + padding
+    {
+        size_t n = (size_t)27 * 1000 * 1000 + (size_t)K * 6 * 1024 + 65536;   // stem, FPN, RPN, heads
+        int cin = 64;
+        for (int s_ = 0; s_ < 4; ++s_)
+            for (int b_ = 0; b_ < m->nblk[s_]; ++b_) {
+                const size_t mid = m->mid[s_], cout = kOut[s_];
+                n += (size_t)cin * mid + mid * 9 * (m->cfg.num_groups > 1 ? 64 : mid) + mid * cout + (b_ == 0 ? (size_t)cin * cout : 0) + 8 * (mid + cout) + 1024;
+                cin = (int)cout;
+            }
+        m->parena_floats = n;
+    }
     if (hipMalloc(&m->parena, m->parena_floats * sizeof(float)) != hipSuccess) {
         amp::set_error("amp_model_create: hipMalloc of the parameter arena failed");
         delete m;
@@ -1125,7 +1157,24 @@ int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, c
         AMP_REQUIRE(ndim == 4, "%s: expected a 4-d conv weight", name_c);
         const int O = (int)shape[0], I = (int)shape[1], KH = (int)shape[2], KW = (int)shape[3];
         AMP_REQUIRE(I % 4 == 0, "%s: Cin %% 4 != 0", name_c);
-        AMP_TRY(put_conv(prefix, oihw_to_ohwi(data, O, I, KH, KW, I, KW), O, I, KH, KW));
+        const int G = m->cfg.num_groups;
+        if (G > 1 && ends_with(prefix, ".conv2") && prefix.rfind("backbone.bottom_up.res", 0) == 0) {
+            // grouped 3x3 [O, O/G, 3, 3] -> block-diagonal window layout [O][KH][KW][64] (see amp_group_expand_weights)
+            const int cpg = I;
+            AMP_REQUIRE(O == cpg * G && O % 64 == 0 && 64 % cpg == 0, "%s: expected [%d,%d,3,3] with %d groups", name_c, O, O / G, G);
+            std::vector<float> v((size_t)O * KH * KW * 64, 0.f);
+            for (int o = 0; o < O; ++o) {
+                const int j0 = (o / cpg) * cpg - (o & ~63);          // window slot of the group's first channel
+                for (int i = 0; i < cpg; ++i)
+                    for (int y = 0; y < KH; ++y)
+                        for (int x = 0; x < KW; ++x)
+                            v[(((size_t)o * KH + y) * KW + x) * 64 + j0 + i] = data[(((size_t)o * I + i) * KH + y) * KW + x];
+            }
+            AMP_TRY(put_conv(prefix, std::move(v), O, O, KH, KW));
+            m->conv[prefix].groups = G;
+        } else {
+            AMP_TRY(put_conv(prefix, oihw_to_ohwi(data, O, I, KH, KW, I, KW), O, I, KH, KW));
+        }
     } else {
         AMP_TRY(put_shift(prefix, std::vector<float>(data, data + numel)));
     }
@@ -1188,7 +1237,7 @@ int amp_model_finalize(amp_model* m) {
         const std::string& key = kv.first;
         if (key.rfind("backbone.bottom_up.stem", 0) == 0 || key.rfind("backbone.bottom_up.res2", 0) == 0) continue;
         const ConvW& cw = kv.second;
-        m->trainable.push_back({cw.w, (size_t)cw.cout * cw.kh * cw.kw * cw.cin});
+        m->trainable.push_back({cw.w, (size_t)cw.cout * cw.kh * cw.kw * (cw.groups > 1 ? 64 : cw.cin)});
         const bool has_bn = m->host_raw.count(key + ".norm.weight") != 0;
         if (!has_bn && cw.shift) m->trainable.push_back({cw.shift, (size_t)cw.cout});
     }
@@ -1322,6 +1371,17 @@ int amp_model_get_tensor(amp_model* m, const char* name_c, int want_grad, float*
         const int n = (prefix == "roi_heads.mask_head.deconv") ? 256 : (rows >= 0 ? rows : cw.cout);
         AMP_REQUIRE((size_t)n <= cap, "amp_model_get_tensor: output buffer too small");
         memcpy(out, h.data() + row0, (size_t)n * 4);
+        return AMP_OK;
+    }
+    if (cw.groups > 1) {   // window layout [O][KH][KW][64] -> grouped OIHW [O][O/G][KH][KW]
+        const int cpg = cw.cout / cw.groups;
+        AMP_TRY(fetch(cw.w, (size_t)cw.cout * cw.kh * cw.kw * 64, h));
+        AMP_REQUIRE(cap >= (size_t)cw.cout * cpg * cw.kh * cw.kw, "amp_model_get_tensor: output buffer too small");
+        for (int o = 0; o < cw.cout; ++o) {
+            const int j0 = (o / cpg) * cpg - (o & ~63);
+            for (int i = 0; i < cpg; ++i) for (int y = 0; y < cw.kh; ++y) for (int x = 0; x < cw.kw; ++x)
+                out[(((size_t)o * cpg + i) * cw.kh + y) * cw.kw + x] = h[(((size_t)o * cw.kh + y) * cw.kw + x) * 64 + j0 + i];
+        }
         return AMP_OK;
     }
     const size_t kk = (size_t)cw.kh * cw.kw * cw.cin;

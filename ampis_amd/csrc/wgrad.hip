@@ -234,12 +234,31 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         }
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// Pass 2: 32 columns x 8 part-lanes per workgroup; part-lane l adds parts l, l+8, ... in order (4 independent loads in flight),
+// the 8 lanes are combined in lane order: a fixed summation tree -> run-to-run reproducible.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
+                                                           int accumulate) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + col;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s = __fadd_rn(s, partial[(size_t)p * N + n]);
-    out[n] = accumulate ? __fadd_rn(out[n], s) : s;
+    if (n < N) {
+        int p = pl;
+        for (; p + 24 < nparts; p += 32) {
+            const float v0 = partial[(size_t)p * N + n], v1 = partial[(size_t)(p + 8) * N + n];
+            const float v2 = partial[(size_t)(p + 16) * N + n], v3 = partial[(size_t)(p + 24) * N + n];
+            s = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(s, v0), v1), v2), v3);
+        }
+        for (; p < nparts; p += 8) s = __fadd_rn(s, partial[(size_t)p * N + n]);
+    }
+    red[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && n < N) {
+        float t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t = __fadd_rn(t, red[k][col]);
+        out[n] = accumulate ? __fadd_rn(out[n], t) : t;
+    }
 }
 
 // dgrad weights: Wt[c][KH-1-ky][KW-1-kx][n] = W[n][ky][kx][c] * scale[n]   (scale may be null)
@@ -319,7 +338,7 @@ int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, floa
     AMP_REQUIRE(ctx && dy && scratch && out && M >= 0 && N > 0 && N % 4 == 0, "amp_colsum: bad argument (N %% 4 != 0?)");
     const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N / 4, scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 64)), dim3(64), 0, ctx->stream, scratch, parts, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, scratch, parts, N, out, accumulate);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

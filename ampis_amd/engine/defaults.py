@@ -61,11 +61,12 @@ class DefaultPredictor:
         self.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         self.ctx = _lib.Context(_device_index(cfg.MODEL.DEVICE))
         w = str(cfg.MODEL.WEIGHTS)
+        self.arch = P.arch_from_cfg(cfg)
         if w:
-            self.params = checkpoint.load_checkpoint(w, self.num_classes)
+            self.params = checkpoint.load_checkpoint(w, self.num_classes, self.arch)
         else:
             logger.warning("cfg.MODEL.WEIGHTS is empty: using seeded random initialisation (like an un-loaded detectron2 model)")
-            self.params = P.init_params(self.num_classes, seed=0, style="d2")
+            self.params = P.init_params(self.num_classes, seed=0, style="d2", arch=self.arch)
         self._model = None
         self._cap = (0, 0, 0)
 
@@ -81,7 +82,7 @@ class DefaultPredictor:
                                    pre_nms_topk=int(c.MODEL.RPN.PRE_NMS_TOPK_TEST), post_nms_topk=int(c.MODEL.RPN.POST_NMS_TOPK_TEST),
                                    rpn_nms_thresh=float(c.MODEL.RPN.NMS_THRESH), score_thresh=float(c.MODEL.ROI_HEADS.SCORE_THRESH_TEST),
                                    nms_thresh=float(c.MODEL.ROI_HEADS.NMS_THRESH_TEST), pixel_mean=tuple(c.MODEL.PIXEL_MEAN),
-                                   pixel_std=tuple(c.MODEL.PIXEL_STD))
+                                   pixel_std=tuple(c.MODEL.PIXEL_STD), arch=self.arch)
             self._model.load_params(self.params)
             self._cap = cap
         return self._model
@@ -161,7 +162,8 @@ class DefaultTrainer:
         self.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         dev = _device_index(cfg.MODEL.DEVICE) if ":" in str(cfg.MODEL.DEVICE) else (int(os.environ.get("LOCAL_RANK", "0")) if not str(cfg.MODEL.DEVICE).startswith("cpu") else _device_index(cfg.MODEL.DEVICE))
         self.ctx = _lib.Context(dev)
-        self.params = P.init_params(self.num_classes, seed=max(int(cfg.get("SEED", -1)), 0), style="d2")
+        self.arch = P.arch_from_cfg(cfg)     # a grouped (ResNeXt) backbone is inference-only: amp_model_create refuses to train it
+        self.params = P.init_params(self.num_classes, seed=max(int(cfg.get("SEED", -1)), 0), style="d2", arch=self.arch)
         self._net = None
         self.model = TrainModel(None, self.ctx)            # net attached lazily (capacity depends on the first batch)
         self._per_rank = int(cfg.SOLVER.IMS_PER_BATCH) // self.world_size
@@ -185,7 +187,7 @@ class DefaultTrainer:
                              train=True, max_gt=self._per_rank * 2048, max_poly_doubles=self._per_rank * 2048 * 128,
                              pre_nms_topk_train=int(c.MODEL.RPN.PRE_NMS_TOPK_TRAIN), post_nms_topk_train=int(c.MODEL.RPN.POST_NMS_TOPK_TRAIN),
                              rpn_batch=int(c.MODEL.RPN.BATCH_SIZE_PER_IMAGE), roi_batch=int(c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE),
-                             pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD))
+                             pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD), arch=self.arch)
         self._net.load_params(self.params)
         self._cap = cap
         self.model.net = self._net
@@ -203,7 +205,7 @@ class DefaultTrainer:
             if os.path.isfile(last):
                 w = os.path.join(self.cfg.OUTPUT_DIR, open(last).read().strip())
         if w and not w.startswith(("detectron2://", "http://", "https://")):
-            self.params = checkpoint.load_checkpoint(w, self.num_classes)
+            self.params = checkpoint.load_checkpoint(w, self.num_classes, self.arch)
             if resume:
                 it = checkpoint.checkpoint_iteration(w)
                 self.start_iter = self.iter = (it + 1) if it is not None else 0

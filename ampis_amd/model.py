@@ -19,7 +19,7 @@ class MaskRCNN:
                  detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
                  score_thresh=0.05, nms_thresh=0.5, mask_threshold=0.5, pixel_mean=(103.530, 116.280, 123.675),
                  pixel_std=(1.0, 1.0, 1.0), rle_pool_counts=0, train=False, max_gt=16384, max_poly_doubles=16384 * 80,
-                 pre_nms_topk_train=2000, post_nms_topk_train=1000, rpn_batch=256, roi_batch=512):
+                 pre_nms_topk_train=2000, post_nms_topk_train=1000, rpn_batch=256, roi_batch=512, arch="R50"):
         self.ctx = ctx
         cfg = ModelCfg()
         check(lib().amp_model_cfg_default(C.byref(cfg)), "amp_model_cfg_default")
@@ -38,6 +38,11 @@ class MaskRCNN:
         cfg.max_gt, cfg.max_poly_doubles = int(max_gt), int(max_poly_doubles)
         cfg.pre_nms_topk_train, cfg.post_nms_topk_train = int(pre_nms_topk_train), int(post_nms_topk_train)
         cfg.rpn_batch, cfg.roi_batch = int(rpn_batch), int(roi_batch)
+        from .params import ARCHS
+        a = ARCHS[arch] if isinstance(arch, str) else arch      # MODEL.RESNETS.*: R50-FPN (default), R101, X101-32x8d
+        cfg.resnet_depth, cfg.num_groups = int(a["depth"]), int(a["groups"])
+        cfg.width_per_group, cfg.stride_in_1x1 = int(a["width_per_group"]), int(bool(a["stride_in_1x1"]))
+        self.arch = a
         self.cfg = cfg
         self.num_classes = int(num_classes)
         self._h = C.c_void_p()
@@ -164,7 +169,7 @@ class MaskRCNN:
     def get_tensor(self, name, grad=False):
         """Current value (or gradient) of a parameter in detectron2 / torch layout."""
         from . import params as P
-        shape = P.param_shapes(self.num_classes)[name]
+        shape = P.param_shapes(self.num_classes, self.arch)[name]
         out = np.empty(shape, dtype=np.float32)
         check(lib().amp_model_get_tensor(self._h, name.encode(), int(bool(grad)), out.ctypes.data_as(C.c_void_p), out.size), "amp_model_get_tensor")
         return out
@@ -172,7 +177,7 @@ class MaskRCNN:
     def state_dict(self):
         """All trainable tensors + the FrozenBN statistics they were loaded with are not tracked here; returns the trainable part."""
         from . import params as P
-        return {k: self.get_tensor(k) for k in P.param_shapes(self.num_classes) if ".norm." not in k}
+        return {k: self.get_tensor(k) for k in P.param_shapes(self.num_classes, self.arch) if ".norm." not in k}
 
     def tap(self, name):
         """Copy an intermediate device buffer of the last infer call to the host (parity tests)."""

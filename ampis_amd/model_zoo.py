@@ -25,9 +25,31 @@ _RCNN_FPN = {
     "VERSION": 2,
 }
 
-_CONFIGS = {"COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml": _RCNN_FPN}
-_CHECKPOINTS = {"COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml":
-                "https://dl.fbaipublicfiles.com/detectron2/COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x/137849600/model_final_f10217.pkl"}
+
+
+def _variant(**model):
+    import copy
+    c = copy.deepcopy(_RCNN_FPN)
+    for k, v in model.items():
+        if isinstance(v, dict):
+            c["MODEL"].setdefault(k, {}).update(v)
+        else:
+            c["MODEL"][k] = v
+    return c
+
+
+# mask_rcnn_X_101_32x8d_FPN_3x.yaml (BASELINE configs[4]): ResNeXt-101 32x8d, stride in the 3x3, caffe2-style pixel std
+_X101_FPN = _variant(WEIGHTS="detectron2://ImageNetPretrained/FAIR/X-101-32x8d.pkl", PIXEL_STD=[57.375, 57.120, 58.395],
+                     RESNETS={"DEPTH": 101, "NUM_GROUPS": 32, "WIDTH_PER_GROUP": 8, "STRIDE_IN_1X1": False})
+_R101_FPN = _variant(WEIGHTS="detectron2://ImageNetPretrained/MSRA/R-101.pkl", RESNETS={"DEPTH": 101})
+
+_CONFIGS = {"COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml": _RCNN_FPN,
+            "COCO-InstanceSegmentation/mask_rcnn_R_101_FPN_3x.yaml": _R101_FPN,
+            "COCO-InstanceSegmentation/mask_rcnn_X_101_32x8d_FPN_3x.yaml": _X101_FPN}
+_D2 = "https://dl.fbaipublicfiles.com/detectron2/COCO-InstanceSegmentation/"
+_CHECKPOINTS = {"COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml": _D2 + "mask_rcnn_R_50_FPN_3x/137849600/model_final_f10217.pkl",
+                "COCO-InstanceSegmentation/mask_rcnn_R_101_FPN_3x.yaml": _D2 + "mask_rcnn_R_101_FPN_3x/138205316/model_final_a3ec72.pkl",
+                "COCO-InstanceSegmentation/mask_rcnn_X_101_32x8d_FPN_3x.yaml": _D2 + "mask_rcnn_X_101_32x8d_FPN_3x/139653917/model_final_2d9806.pkl"}
 
 
 def get_config_file(config_path):

@@ -49,6 +49,23 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
     return y
 
 
+def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, stride=1, pad=0, relu=False):
+    """Grouped conv (ResNeXt conv2): x [B,H,W,C], w [C,KH,KW,C/groups] (grouped OHWI) -> y [B,Ho,Wo,C]."""
+    _f32c(x), _f32c(w), _f32c(scale), _f32c(shift), _f32c(res)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, cpg = w.shape
+    assert Cin == Cout and cpg * groups == Cin
+    w_win = torch.empty((Cout, KH, KW, 64), device=x.device, dtype=torch.float32)
+    check(lib().amp_group_expand_weights(ctx.handle, ptr(w), Cout, KH, KW, cpg, ptr(w_win)), "amp_group_expand_weights")
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), 0 if res is None else 1, 0)
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    check(lib().amp_conv2d_grouped_nhwc(ctx.handle, C.byref(d), int(groups), ptr(x), ptr(w_win), ptr(scale), ptr(shift), ptr(res), ptr(y)),
+          "amp_conv2d_grouped_nhwc")
+    return y
+
+
 def conv2d_wgrad(ctx, x, dy, w_shape, stride=1, pad=0, scale=None, grad=None):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dW [Cout,KH,KW,Cin] (accumulated into `grad` when given)."""
     _f32c(x), _f32c(dy)

@@ -10,6 +10,26 @@ from collections import OrderedDict
 import numpy as np
 
 RES_STAGES = (("res2", 3, 64, 256, 1), ("res3", 4, 128, 512, 2), ("res4", 6, 256, 1024, 2), ("res5", 3, 512, 2048, 2))
+# MODEL.RESNETS.{DEPTH, NUM_GROUPS, WIDTH_PER_GROUP, STRIDE_IN_1X1} of the detectron2 model-zoo backbones
+ARCHS = {
+    "R50": dict(depth=50, groups=1, width_per_group=64, stride_in_1x1=True),
+    "R101": dict(depth=101, groups=1, width_per_group=64, stride_in_1x1=True),
+    "X101": dict(depth=101, groups=32, width_per_group=8, stride_in_1x1=False),    # X-101-32x8d (BASELINE configs[4])
+}
+
+
+def arch_from_cfg(cfg):
+    """MODEL.RESNETS.* of a (façade) cfg -> the arch dict MaskRCNN / param_shapes take."""
+    r = cfg.MODEL.RESNETS
+    return dict(depth=int(r.DEPTH), groups=int(r.NUM_GROUPS), width_per_group=int(r.WIDTH_PER_GROUP), stride_in_1x1=bool(r.STRIDE_IN_1X1))
+
+
+def res_stages(arch="R50"):
+    """(name, blocks, bottleneck width, out channels, stride, groups) per stage."""
+    a = ARCHS[arch] if isinstance(arch, str) else arch
+    blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}[a["depth"]]
+    width = a["groups"] * a["width_per_group"]
+    return tuple((f"res{i + 2}", blocks[i], width << i, 256 << i, 1 if i == 0 else 2, a["groups"]) for i in range(4))
 FPN_LEVELS = (2, 3, 4, 5)
 FPN_IN = {2: 256, 3: 512, 4: 1024, 5: 2048}
 FPN_CH = 256
@@ -20,7 +40,7 @@ FC_DIM = 1024
 BN_EPS = 1e-5
 
 
-def param_shapes(num_classes):
+def param_shapes(num_classes, arch="R50"):
     """OrderedDict name -> shape in detectron2/torch layout (conv OIHW, ConvTranspose IOHW, linear [out,in])."""
     K = int(num_classes)
     s = OrderedDict()
@@ -32,13 +52,13 @@ def param_shapes(num_classes):
 
     conv_bn("backbone.bottom_up.stem.conv1", 64, 3, 7)
     cin = 64
-    for name, nblk, mid, cout, _stride in RES_STAGES:
+    for name, nblk, mid, cout, _stride, groups in res_stages(arch):
         for b in range(nblk):
             p = f"backbone.bottom_up.{name}.{b}"
             if b == 0:
                 conv_bn(p + ".shortcut", cout, cin, 1)
             conv_bn(p + ".conv1", mid, cin, 1)
-            conv_bn(p + ".conv2", mid, mid, 3)
+            conv_bn(p + ".conv2", mid, mid // groups, 3)
             conv_bn(p + ".conv3", cout, mid, 1)
             cin = cout
     for l in FPN_LEVELS:
@@ -71,11 +91,11 @@ def param_shapes(num_classes):
     return s
 
 
-def count_params(num_classes):
-    return int(sum(int(np.prod(v)) for v in param_shapes(num_classes).values()))
+def count_params(num_classes, arch="R50"):
+    return int(sum(int(np.prod(v)) for v in param_shapes(num_classes, arch).values()))
 
 
-def init_params(num_classes, seed=0, style="d2", dtype=np.float32):
+def init_params(num_classes, seed=0, style="d2", dtype=np.float32, arch="R50"):
     """Seeded random initialisation -> OrderedDict name -> np.ndarray (torch layout).
 
     style="d2":     detectron2's initialisers: c2_msra_fill (Kaiming normal, fan_out) for the
@@ -87,7 +107,7 @@ def init_params(num_classes, seed=0, style="d2", dtype=np.float32):
                     goal: oracle and HIP path read the same arrays.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
-    shapes = param_shapes(num_classes)
+    shapes = param_shapes(num_classes, arch)
     out = OrderedDict()
     spread = style == "spread"
     assert style in ("d2", "spread")

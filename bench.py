@@ -111,6 +111,46 @@ def train_leg(ctx, infer_model, dev, rank, world, steps, barrier):
             "last_losses": {k: round(v, 4) for k, v in losses.items()}}
 
 
+def x101_leg(ctx, dev, rank, world, steps, barrier):
+    """BASELINE configs[4] per GPU: X-101-32x8d-FPN inference on native 2048x2048 synthetic micrographs, 500 detections/image."""
+    S, D, XB = 2048, 500, 2
+    log(f"rank {rank}: creating the X-101-32x8d model (batch {XB} x {S}x{S})")
+    model = MaskRCNN(ctx, K, max_batch=XB, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D,
+                     pixel_std=(57.375, 57.120, 58.395), arch="X101")
+    p = P.init_params(K, seed=0, style="spread", arch="X101")
+    p["backbone.bottom_up.stem.conv1.weight"] = p["backbone.bottom_up.stem.conv1.weight"] * np.float32(57.0)   # seeded stem assumes unit std
+    model.load_params(p)
+    del p
+    imgs, _ = synth.batch(XB, S, S, first_index=2000 + rank * XB)
+    d_imgs = ctx.malloc(imgs.nbytes)
+    ctx.h2d(d_imgs, imgs)
+    for _ in range(2):
+        model.infer_raw(None, device_ptr=d_imgs, shape=(XB, S, S))
+    barrier()
+    ctx.prof_begin(max_launches=steps * 256)
+    t0 = time.perf_counter()
+    ndet = 0
+    for _ in range(steps):
+        d = model.infer_raw(None, device_ptr=d_imgs, shape=(XB, S, S))
+        ndet += sum(d.n[b] for b in range(XB))
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    prof = ctx.prof_end()
+    barrier()
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        el = float(t.item())
+    model.close()
+    conv_ms = prof["ms"][0] + prof["ms"][1]
+    return {"metric": "images/sec Mask R-CNN X-101-32x8d-FPN @2048x2048 inference", "value": round(world * XB * steps / el, 3),
+            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "batch_per_gpu": XB, "dtype": "f32",
+            "workload": "BASELINE configs[4]: native 2048x2048 (no tiling), K=2, 1000 proposals/img, TEST.DETECTIONS_PER_IMAGE=500, "
+                        "seeded random-init weights, grouped 3x3 convs as 64-wide block-diagonal MFMA tiles",
+            "detections_per_image_mean": round(ndet / (steps * XB), 1),
+            "conv_useful_tflops": round((prof["flops"][0] + prof["flops"][1]) / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,7 +159,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=4, help="timed training steps of the secondary `train` object (0 = skip)")
-    ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog for the training leg, seconds")
+    ap.add_argument("--x101-steps", type=int, default=5, help="timed steps of the secondary `x101_2048` object (0 = skip)")
+    ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog for the secondary legs, seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,10 +246,13 @@ def main():
 
     emitted = threading.Lock()
 
+    extra = {}
+
     def emit(train_obj):
         """Rank 0 prints the ONE JSON line, exactly once (also from the watchdog below)."""
         if not emitted.acquire(blocking=False) or out is None:
             return
+        out.update(extra)
         if train_obj is not None:
             out["train"] = train_obj
         if world == 1 and not args.no_cpu_baseline:
@@ -219,18 +263,25 @@ def main():
     # gradient all-reduce over RCCL (N > 1) + SGD.  Never allowed to break the headline line above: an exception is reported in the
     # object, and a collective that does not return (a rank died) is cut off by a watchdog that prints the headline and exits.
     train_obj = None
-    if args.train_steps > 0:
+    if args.train_steps > 0 or args.x101_steps > 0:
         def on_stall():
-            log(f"rank {rank}: training leg exceeded {args.train_timeout} s; emitting the inference line without it")
-            emit({"error": f"training leg did not finish within {args.train_timeout} s"})
+            log(f"rank {rank}: secondary legs exceeded {args.train_timeout} s; emitting the inference line without them")
+            emit(train_obj if train_obj is not None else {"error": f"secondary legs did not finish within {args.train_timeout} s"})
             os._exit(0)
         dog = threading.Timer(args.train_timeout, on_stall)
         dog.daemon = True
         dog.start()
-        try:
-            train_obj = train_leg(ctx, model, dev, rank, world, args.train_steps, barrier)
-        except Exception as e:   # noqa: BLE001
-            train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if args.train_steps > 0:
+            try:
+                train_obj = train_leg(ctx, model, dev, rank, world, args.train_steps, barrier)
+            except Exception as e:   # noqa: BLE001
+                train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if args.x101_steps > 0:
+            try:
+                model.close()
+                extra["x101_2048"] = x101_leg(ctx, dev, rank, world, args.x101_steps, barrier)
+            except Exception as e:   # noqa: BLE001
+                extra["x101_2048"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
     emit(train_obj)
     if world > 1:

@@ -86,6 +86,11 @@ typedef struct amp_conv_desc {
 /* y = act( conv(x, w) * scale[c] + shift[c] (+ res) ); scale may be NULL (= 1), shift may be NULL (= 0). */
 int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w,
                     const float* scale, const float* shift, const float* res, float* y);
+/* Grouped convolution (detectron2 ResNeXt `conv2`, groups = RESNETS.NUM_GROUPS): Cin == Cout, Cin / groups in {8,16,32,64}.
+ * w_win is the window layout [Cout][KH][KW][64] made by amp_group_expand_weights from grouped weights [Cout][KH][KW][Cin/groups]. */
+int amp_group_expand_weights(amp_ctx* ctx, const float* w, int Cout, int KH, int KW, int cpg, float* w_win);
+int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
+                            const float* scale, const float* shift, const float* res, float* y);
 /* same, with an optional mask tensor indexed like y: y = mask > 0 ? y : 0 (applied last; the ReLU backward of a data gradient) */
 int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                        const float* res, const float* mask, float* y);
@@ -222,6 +227,9 @@ typedef struct amp_model_cfg {
     float roi_iou;                   /* MODEL.ROI_HEADS.IOU_THRESHOLDS (0.5) */
     int max_gt;                      /* capacity: ground-truth instances per batch */
     int max_poly_doubles;            /* capacity: polygon coordinates (doubles) per batch */
+    /* backbone variant (inference; training a grouped backbone is not built): MODEL.RESNETS.{DEPTH, NUM_GROUPS, WIDTH_PER_GROUP,
+     * STRIDE_IN_1X1}.  R50-FPN = 50/1/64/1 (default, also when resnet_depth == 0); X101-32x8d-FPN = 101/32/8/0. */
+    int resnet_depth, num_groups, width_per_group, stride_in_1x1;
 } amp_model_cfg;
 /* Ground truth of one batch (all pointers HOST): instances of image b are [gt_off[b], gt_off[b+1]); one polygon per instance
  * (flat x0,y0,x1,y1,... in input-image pixels), polygon of instance i = poly_xy[poly_off[i] .. poly_off[i+1]). */

@@ -48,6 +48,10 @@ class Cfg:
         self.detections_per_image = 100
         self.bbox_reg_weights = (10.0, 10.0, 5.0, 5.0)
         self.mask_threshold = 0.5
+        # MODEL.RESNETS.*: blocks per stage, NUM_GROUPS (conv2), STRIDE_IN_1X1 -- R50 defaults; X101-32x8d = (3,4,23,3), 32, False
+        self.resnet_blocks = (3, 4, 6, 3)
+        self.num_groups = 1
+        self.stride_in_1x1 = True
         for k, v in kw.items():
             assert hasattr(self, k), k
             setattr(self, k, v)
@@ -65,24 +69,28 @@ def frozen_bn(x, p, prefix):
                         p[prefix + ".bias"], training=False, eps=BN_EPS)
 
 
-def conv_bn(x, p, prefix, stride=1, padding=0, relu=False):
-    y = F.conv2d(x, p[prefix + ".weight"], None, stride=stride, padding=padding)
+def conv_bn(x, p, prefix, stride=1, padding=0, relu=False, groups=1):
+    y = F.conv2d(x, p[prefix + ".weight"], None, stride=stride, padding=padding, groups=groups)
     y = frozen_bn(y, p, prefix + ".norm")
     return F.relu_(y) if relu else y
 
 
-def resnet50(x, p):
-    """detectron2 modeling/backbone/resnet.py: BasicStem + BottleneckBlock x (3,4,6,3), STRIDE_IN_1X1=True."""
+def resnet50(x, p, cfg=None):
+    """detectron2 modeling/backbone/resnet.py: BasicStem + BottleneckBlock x (3,4,6,3), STRIDE_IN_1X1=True (R50); with cfg:
+    blocks per stage, conv2 groups and the stride in conv1 or conv2 as BottleneckBlock.__init__ places them (ResNeXt)."""
+    blocks = cfg.resnet_blocks if cfg is not None else (3, 4, 6, 3)
+    groups = cfg.num_groups if cfg is not None else 1
+    s1x1 = cfg.stride_in_1x1 if cfg is not None else True
     x = conv_bn(x, p, "backbone.bottom_up.stem.conv1", stride=2, padding=3, relu=True)
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     outs = {}
-    for name, nblk, stride in RES_STAGES:
+    for (name, _, stride), nblk in zip(RES_STAGES, blocks):
         for b in range(nblk):
             pre = f"backbone.bottom_up.{name}.{b}"
             s = stride if b == 0 else 1
             shortcut = conv_bn(x, p, pre + ".shortcut", stride=s) if (pre + ".shortcut.weight") in p else x
-            y = conv_bn(x, p, pre + ".conv1", stride=s, relu=True)
-            y = conv_bn(y, p, pre + ".conv2", padding=1, relu=True)
+            y = conv_bn(x, p, pre + ".conv1", stride=s if s1x1 else 1, relu=True)
+            y = conv_bn(y, p, pre + ".conv2", stride=1 if s1x1 else s, padding=1, relu=True, groups=groups)
             y = conv_bn(y, p, pre + ".conv3")
             y = y + shortcut
             x = F.relu_(y)
@@ -458,7 +466,7 @@ def infer(images_u8, params, cfg, out_sizes=None, stages=None):
     B, H, W, _ = images_u8.shape
     with torch.no_grad():
         x = preprocess(images_u8, cfg)
-        res = resnet50(x, params)
+        res = resnet50(x, params, cfg)
         feats = fpn(res, params)
         rpn_outs = rpn_head(feats, params)
         shapes = [(f.shape[2], f.shape[3]) for f in feats]

@@ -145,3 +145,22 @@ def test_fast_epilogue_equals_generic_bitwise(gpu_ctx, mode):
         outs.append(y.cpu())
     assert torch.equal(outs[0], outs[1])
     assert outs[0].abs().max() > 0
+
+
+@pytest.mark.parametrize("case", [(2, 20, 24, 256, 32, 1), (1, 17, 19, 512, 32, 2), (1, 12, 12, 1024, 32, 2), (1, 8, 8, 2048, 32, 1), (2, 9, 9, 128, 2, 1)])
+def test_grouped_conv3x3_matches_torch(gpu_ctx, case):
+    """ResNeXt conv2 (groups=32, stride 1 or 2 in the 3x3) against torch conv2d(groups=...)."""
+    from ampis_amd import ops
+    B, H, W, Cw, groups, stride = case
+    g = torch.Generator().manual_seed(Cw + stride)
+    cpg = Cw // groups
+    x = torch.randn(B, H, W, Cw, generator=g)
+    w = torch.randn(Cw, 3, 3, cpg, generator=g) * (2.0 / (9 * cpg)) ** 0.5
+    scale, shift = torch.rand(Cw, generator=g) + 0.5, torch.randn(Cw, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), stride=stride, padding=1, groups=groups)
+    ref = F.relu(ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    d = "cuda:0"
+    y = ops.conv2d_grouped_nhwc(gpu_ctx, x.to(d), w.to(d), groups, scale.to(d), shift.to(d), stride=stride, pad=1, relu=True)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    assert (y.cpu() - ref).abs().max().item() <= RTOL * max(ref.abs().max().item(), 1.0)

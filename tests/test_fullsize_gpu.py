@@ -6,18 +6,28 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def run(gpu_ctx):
+# BASELINE configs[1] (R50-FPN, 1024^2, 200 detections) and configs[4] (X-101-32x8d-FPN, native 2048^2, dense: 500 detections)
+@pytest.fixture(scope="module", params=["R50-1024", "X101-2048"])
+def run(gpu_ctx, request):
     from ampis_amd import params as P, synth
     from ampis_amd.model import MaskRCNN
-    B, S, K, D = 4, 1024, 2, 200
+    x101 = request.param == "X101-2048"
+    B, S, K, D = (2, 2048, 2, 500) if x101 else (4, 1024, 2, 200)
     imgs, _ = synth.batch(B, S, S)
-    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
-    m.load_params(P.init_params(K, seed=0, style="spread"))
+    if x101:
+        m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D, arch="X101",
+                     pixel_std=(57.375, 57.120, 58.395))
+        p = P.init_params(K, seed=0, style="spread", arch="X101")
+        p["backbone.bottom_up.stem.conv1.weight"] = p["backbone.bottom_up.stem.conv1.weight"] * np.float32(57.0)
+    else:
+        m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+        p = P.init_params(K, seed=0, style="spread")
+    m.load_params(p)
     a = m.infer(imgs, rle="counts")
     b = m.infer(imgs, rle="counts")
     props = m.tap("prop_boxes"), m.tap("prop_count")
-    return dict(a=a, b=b, S=S, D=D, K=K, props=props)
+    yield dict(a=a, b=b, S=S, D=D, K=K, props=props)
+    m.close()
 
 
 def _iou(b, bs):
