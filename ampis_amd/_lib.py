@@ -97,6 +97,10 @@ def _declare(L):
         "amp_conv2d_nhwc": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp], i),
         "amp_conv2d_nhwc_ex": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp], i),
         "amp_group_expand_weights": ([vp, vp, i, i, i, i, vp], i),
+        "amp_set_conv_mode": ([vp, i], i),
+        "amp_get_conv_mode": ([vp], i),
+        "amp_conv_range_flag": ([vp, i, C.POINTER(C.c_int)], i),
+        "amp_split_weights": ([vp, vp, C.c_longlong, i, vp], i),
         "amp_conv2d_grouped_nhwc": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, vp], i),
         "amp_conv_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
         "amp_conv2d_wgrad": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i], i),
@@ -176,6 +180,23 @@ class Context:
             st = lib().amp_init(int(device), C.c_void_p(int(borrow_stream)), 1, C.byref(self._h))
         check(st, "amp_init")
         self.device = int(device)
+
+    CONV_F32, CONV_F16X3 = 0, 1
+
+    @property
+    def conv_mode(self):
+        """Convolution arithmetic: CONV_F32 (fp32 MFMA) or CONV_F16X3 (split-operand f16 MFMA, fp32-equivalent; the default)."""
+        return lib().amp_get_conv_mode(self._h)
+
+    @conv_mode.setter
+    def conv_mode(self, mode):
+        mode = {"f32": 0, "f16x3": 1}.get(mode, mode)
+        check(lib().amp_set_conv_mode(self._h, int(mode)), "amp_set_conv_mode")
+
+    def conv_range_flag(self, clear=True):
+        f = C.c_int()
+        check(lib().amp_conv_range_flag(self._h, int(clear), C.byref(f)), "amp_conv_range_flag")
+        return bool(f.value)
 
     def timer_start(self):
         check(lib().amp_timer_start(self._h), "amp_timer_start")

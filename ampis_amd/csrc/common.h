@@ -78,4 +78,16 @@ struct amp_ctx {
     std::vector<amp_prof_rec> prof_pool;   // pre-created events
     size_t prof_used = 0;
     bool prof_truncated = false;
+    // convolution arithmetic (amp_set_conv_mode): AMP_CONV_F32 = fp32 MFMA, AMP_CONV_F16X3 = split-operand f16 MFMA (default)
+    int conv_mode = 1;
+    int* d_conv_flag = nullptr;            // device int: an f16x3 convolution produced a non-finite accumulator (operand beyond fp16 range)
+    float* split_scratch = nullptr;        // split copy of the weights of a per-call f16x3 convolution
+    size_t split_bytes = 0;
 };
+
+namespace amp {
+// internal convolution entry (conv.hip): w_split = weights already in the f16x3 split layout (amp_split_weights) or null;
+// force_f32 = 1 runs the fp32-MFMA kernel whatever the context mode is.
+int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
+             const float* scale, const float* shift, const float* res, const float* mask, float* y);
+}

@@ -1,5 +1,6 @@
 // Context, error reporting and raw device-memory helpers of the C ABI.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -50,7 +51,33 @@ int amp_init(int device, void* hip_stream, int flags, amp_ctx** out) {
         delete c;
         return AMP_ERR_HIP;
     }
+    if (hipMalloc(&c->d_conv_flag, 16) != hipSuccess || hipMemset(c->d_conv_flag, 0, 16) != hipSuccess) {
+        amp::set_error("amp_init: flag allocation failed");
+        delete c;
+        return AMP_ERR_HIP;
+    }
+    c->conv_mode = AMP_CONV_F16X3;
+    if (const char* e = getenv("AMP_CONV_MODE")) {
+        if (!strcmp(e, "f32")) c->conv_mode = AMP_CONV_F32;
+        else if (!strcmp(e, "f16x3")) c->conv_mode = AMP_CONV_F16X3;
+        else { amp::set_error("amp_init: AMP_CONV_MODE must be f32 or f16x3, got '%s'", e); delete c; return AMP_ERR_ARG; }
+    }
     *out = c;
+    return AMP_OK;
+}
+
+int amp_set_conv_mode(amp_ctx* ctx, int mode) {
+    AMP_REQUIRE(ctx && (mode == AMP_CONV_F32 || mode == AMP_CONV_F16X3), "amp_set_conv_mode: bad argument");
+    ctx->conv_mode = mode;
+    return AMP_OK;
+}
+int amp_get_conv_mode(amp_ctx* ctx) { return ctx ? ctx->conv_mode : -1; }
+
+int amp_conv_range_flag(amp_ctx* ctx, int clear, int* flag_h) {
+    AMP_REQUIRE(ctx && flag_h, "amp_conv_range_flag: null argument");
+    AMP_HIP_CHECK(hipMemcpyAsync(flag_h, ctx->d_conv_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (clear && *flag_h) AMP_HIP_CHECK(hipMemsetAsync(ctx->d_conv_flag, 0, sizeof(int), ctx->stream));
     return AMP_OK;
 }
 
@@ -107,6 +134,8 @@ void amp_destroy(amp_ctx* ctx) {
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipFree(ctx->zero_page);
+    (void)hipFree(ctx->d_conv_flag);
+    (void)hipFree(ctx->split_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

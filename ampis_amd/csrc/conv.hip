@@ -39,6 +39,7 @@ struct ConvArgs {
     int M, K, nsteps;
     int relu, res_mode, out_mode;
     int ntn;  // number of N tiles
+    int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
     unsigned int div_howo_mul, div_wo_mul;   // x / d == (x * mul) >> shr for every x < 2^29 (Granlund-Montgomery, mul = ceil(2^shr / d))
@@ -54,9 +55,19 @@ __device__ __forceinline__ unsigned int fastdiv(unsigned int x, unsigned int mul
 // with a residual, 64 dependent dword loads.  Transposed through LDS every lane owns 4 consecutive n of one row per step:
 // 16-B coalesced residual loads (all issued before the first store) and 16-B stores.  Callers pass the wave's tile origin
 // (mw0, nw0) and must have synchronised the workgroup after the last operand reads.
-template <int WTM, int WTN, int MT, int NT>
+template <int WTM, int WTN, int MT, int NT, bool CHECK = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* lds, int wave, int lane,
                                               int mw0, int nw0, int HoWo) {
+    if (CHECK) {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bad = bad || !(fabsf(acc[i][j][e]) <= 3.0e38f);
+        if (bad) atomicOr(a.range_flag, 1);
+    }
     const int l31 = lane & 31, lh = lane >> 5;
     constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
     constexpr int F4R = WTN / 4;                       // float4 per row
@@ -163,7 +174,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 // two multiply-shift divisions per row (SPATIAL = true: upsampled residual, deconv / stride-2 scatter); residual and mask loads of
 // all rows are issued before the first store; a block-uniform `full` flag removes the per-row bounds predicates from every tile
 // but the last one.  (Measured on gfx950: the generic epilogue's per-row branches cost 13-55 % of the short-K layers.)
-template <int WTM, int WTN, int MT, int NT, bool SPATIAL>
+template <int WTM, int WTN, int MT, int NT, bool SPATIAL, bool CHECK = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* lds, int wave, int lane,
                                                    int mw0, int nw0) {
     const int l31 = lane & 31, lh = lane >> 5;
@@ -243,9 +254,11 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
                 if (mv[it]) mk[it] = *reinterpret_cast<const f32x4*>(a.mask + yoff[it]);
         }
         __builtin_amdgcn_wave_barrier();               // staging writes of this wave precede its reads (same-wave LDS order)
+        bool bad = false;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(stage + (it * RPI + erow) * SLD + ec4 * 4);
+            if (CHECK) bad = bad || !(fabsf(v[0]) <= 3.0e38f) || !(fabsf(v[1]) <= 3.0e38f) || !(fabsf(v[2]) <= 3.0e38f) || !(fabsf(v[3]) <= 3.0e38f);
             f32x4 o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -257,6 +270,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
             }
             if (mv[it]) *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
         }
+        if (CHECK && bad) atomicOr(a.range_flag, 1);
     };
     if (full) body(std::true_type{});
     else body(std::false_type{});
@@ -537,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     for (int q = 0; q < BK / 8; ++q) foff[q] = 4 * ((2 * q + lh) ^ fswz);
 
     stage(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the LDS-DMA has landed (explicit: do not rely on the fence lowering)
     __syncthreads();
 
     for (int step = 0; step < a.nsteps; ++step) {
@@ -560,11 +575,231 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();   // emits vmcnt(0): the LDS-DMA of the next tile has landed; everyone is done with `cur`
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA of the next tile has landed
+        __syncthreads();   // everyone is done with `cur`
     }
 
     if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
     else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv_f16x3_kernel (amp_set_conv_mode(ctx, AMP_CONV_F16X3)): the same implicit GEMM on the f16 matrix pipe, fp32 in / fp32 out.
+// Every operand x is split as x = hi + lo with hi = f16(x) and lo = x - hi (exact in fp32); the low half is stored as
+// lo' = f16(lo * 2^11), which has the magnitude of hi, so it stays a normal f16 number however small x is (22 significant bits
+// down to |x| ~ 2^-25; a plain f16(lo) would go subnormal below |x| = 0.125).  a*b ~= a_hi*b_hi + (a_hi*b_lo' + a_lo'*b_hi) * 2^-11,
+// every product an exact-product v_mfma_f32_32x32x16_f16 accumulated in fp32, the cross terms in their own accumulators that
+// the epilogue folds in with one exact scaling (the dropped a_lo*b_lo term is < 2^-22 |a*b|): 3 MFMAs of 32 cycles do the work
+// of 8 fp32 MFMAs of 64 cycles (5.3x the fp32 matrix rate).
+// Weights are split once (split_weights_kernel: per K-step of 32 a row holds 64 B of hi halves then 64 B of lo' halves) and
+// staged by LDS-DMA exactly like the fp32 kernel; activations stay fp32 in HBM, are fetched with bounds-checked buffer loads
+// (zero fill outside the image) one K-step ahead into registers, split on the VALU and written to LDS in the same hi|lo' row
+// format.  Range: |operand| must stay below 65504 (fp16 max) -- checked: a violation makes an accumulator non-finite, the
+// epilogue raises ctx->d_conv_flag and the caller re-runs in fp32; the fp32 kernel has no such limit.
+// ------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr float LO_SCALE = 2048.0f;      // lo' = (x - hi) * 2^11
+
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = j < 4 ? v0[j] : v1[j - 4];
+        const _Float16 h = (_Float16)x;
+        hi[j] = h;
+        lo[j] = (_Float16)((x - (float)h) * LO_SCALE);
+    }
+}
+
+template <int BN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
+    constexpr int BM = 128;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    constexpr int GB = BN / 32;           // DMA instructions per wave per step for B: BN/4 rows per wave, 8 rows each
+    constexpr int TILE_FLOATS = (BM + BN) * BK;   // a row = 32 k = 64 B hi halves + 64 B lo halves = 32 dwords, as in the fp32 kernel
+    constexpr int SLD = WTN + 4;
+    constexpr int STAGE_FLOATS = 4 * WTM * SLD;
+    constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = tile % a.ntn;
+    const int tile_m = tile / a.ntn;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int HoWo = a.Ho * a.Wo;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+
+    // ---- A (activations): lane = 4 * (row in a 16-row group) + kg; a lane owns 8 consecutive k (32 B) of rows ra[0], ra[1] ----
+    const int arow = lane >> 2, akg = lane & 3;
+    int a_iy0[2], a_ix0[2], a_pb[2], a_row[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = p * 64 + wave * 16 + arow;
+        a_row[p] = r;
+        const int m = m0 + r;
+        if (m < a.M) {
+            const unsigned int b = fastdiv((unsigned int)m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = (unsigned int)m - b * (unsigned int)HoWo;
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            a_iy0[p] = (int)oy * a.stride - a.pad;
+            a_ix0[p] = (int)ox * a.stride - a.pad;
+            a_pb[p] = (int)b * a.H * a.W;
+        } else {
+            a_iy0[p] = -(1 << 28);
+            a_ix0[p] = 0;
+            a_pb[p] = 0;
+        }
+    }
+    // ---- B (split weights): LDS-DMA, 8 rows x 128 B per wave-instruction, source chunk XOR-swizzled ----
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned int b_voff[GB];
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * (BN / 4) + 8 * g + srow;
+        const int n = n0 + r;
+        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+
+    const int csteps = a.Cin / BK;
+    int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the K-step being FETCHED
+    unsigned int a_voff[2];
+    u32x4 ra[2][2];                             // fetched, not yet split: [row][half of the 32 B]
+
+    auto fetch = [&](int buf) {                 // A(kstep) -> registers, B(kstep) -> LDS[buf]
+        if (cs == 0) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
+                const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                a_voff[p] = v ? (unsigned int)(((a_pb[p] + iy * a.W + ix) * a.Cin + 8 * akg) * 4) : OOB_VOFF;
+            }
+        }
+        const int a_soff = cs * (BK * 4);
+        const int b_soff = kstep * (BK * 4);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ra[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p], a_soff, 0);
+            ra[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p] + 16, a_soff, 0);
+        }
+        float* Bs = lds + buf * TILE_FLOATS + BM * BK;
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK),
+                                                     16, (int)b_voff[g], b_soff, 0, 0);
+        ++kstep;
+        if (++cs == csteps) {
+            cs = 0;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+        }
+    };
+    auto commit = [&](int buf) {                // split the fetched A registers into LDS[buf]
+        float* As = lds + buf * TILE_FLOATS;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f16x8 hi, lo;
+            split8(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo);
+            const int r = a_row[p], sw = (r >> 1) & 7;
+            *reinterpret_cast<f16x8*>(As + r * BK + 4 * (akg ^ sw)) = hi;
+            *reinterpret_cast<f16x8*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
+        }
+    };
+
+    f32x16 acc[MT][NT], acx[MT][NT];       // hi*hi sums; cross-term sums (scaled by 2^11)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+
+    const int fswz = (l31 >> 1) & 7;
+
+    fetch(0);
+    commit(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // B(0) has landed (see the loop)
+    __syncthreads();
+    if (a.nsteps > 1) fetch(1);
+
+    for (int step = 0; step < a.nsteps; ++step) {
+        const int cur = step & 1;
+        const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
+        const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = 4 * ((2 * kk + lh) ^ fswz), cl = 4 * ((4 + 2 * kk + lh) ^ fswz);
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + ch);
+                al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + cl);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + ch);
+                bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + cl);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        // A(step+1) is in registers (loads issued a step ago, behind the previous barrier), B(step+1) is landing in LDS[cur^1]
+        if (step + 1 < a.nsteps) commit(cur ^ 1);
+        // The weight DMA into LDS[cur^1] must have LANDED before anyone reads it.  The compiler only counts the register loads of
+        // fetch() (it emitted vmcnt(2..3) here and no vmcnt(0) at the barrier: a race that showed up as soon as the weights were
+        // cold in L2), so the wait is explicit: vmcnt(0), other counters untouched.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();   // LDS[cur] is free, LDS[cur^1] complete
+        if (step + 2 < a.nsteps) fetch(cur);    // A(step+2) -> registers, B(step+2) -> LDS[cur]
+    }
+
+    // fold the cross terms in (their 2^-11 is exact), then the shared epilogue
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+    if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+    else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+}
+
+// w [rows][K] fp32 -> split rows: per K-step of 32, 32 f16 hi halves (64 B) then 32 f16 lo' halves (64 B)
+__global__ void split_weights_kernel(const float* __restrict__ w, size_t rows, int K, unsigned int* __restrict__ out) {
+    const size_t total = rows * (size_t)(K / 2);     // one thread per pair of consecutive k
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (K / 2);
+        const int kp = (int)(i - r * (K / 2));       // pair index in the row
+        const int step = kp / 16, j = kp % 16;       // 16 pairs per K-step
+        unsigned int hw = 0, lw = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float x = w[r * K + 2 * kp + q];
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)((x - (float)h) * LO_SCALE);
+            hw |= (unsigned int)__builtin_bit_cast(unsigned short, h) << (16 * q);
+            lw |= (unsigned int)__builtin_bit_cast(unsigned short, l) << (16 * q);
+        }
+        unsigned int* o = out + r * K + step * 32;
+        o[j] = hw;
+        o[16 + j] = lw;
+    }
 }
 
 template <int BN, bool STEM>
@@ -573,6 +808,15 @@ void launch_glds(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, un
         case 1: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
         case 2: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
         default: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    }
+}
+
+template <int BN>
+void launch_f16x3(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    switch (epi) {
+        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     }
 }
 
@@ -591,7 +835,17 @@ static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants o
 extern "C" void amp_debug_set_conv_ablate(int mode) { g_conv_ablate = mode; }
 
 static int conv_impl(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* scale,
-                     const float* shift, const float* res, const float* mask, float* y);
+                     const float* shift, const float* res, const float* mask, float* y) {
+    return amp::conv_run(ctx, d, groups, x, w, nullptr, 0, scale, shift, res, mask, y);
+}
+
+// w [rows][K] fp32 (K % 32 == 0) -> the operand layout of the AMP_CONV_F16X3 kernels, same byte size (rows * K * 4)
+extern "C" int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, int K, float* w_split) {
+    AMP_REQUIRE(ctx && w && w_split && rows > 0 && K > 0 && K % 32 == 0, "amp_split_weights: bad argument (K %% 32 != 0?)");
+    hipLaunchKernelGGL(split_weights_kernel, dim3(2048), dim3(256), 0, ctx->stream, w, (size_t)rows, K, reinterpret_cast<unsigned int*>(w_split));
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
 
 extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
                                   const float* shift, const float* res, const float* mask, float* y) {
@@ -638,8 +892,8 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
     return amp_conv2d_nhwc_ex(ctx, d, x, w, scale, shift, res, nullptr, y);
 }
 
-static int conv_impl(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* scale,
-                     const float* shift, const float* res, const float* mask, float* y) {
+int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
+                  const float* scale, const float* shift, const float* res, const float* mask, float* y) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -699,7 +953,32 @@ static int conv_impl(amp_ctx* ctx, const amp_conv_desc* d, int groups, const flo
     const bool glds = (a.Cin % BK == 0) && small;
     AMP_REQUIRE(!a.grouped || glds, "amp_conv2d_grouped_nhwc: operands must stay below 2 GiB");
     const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
-    if (stem) {
+    a.range_flag = ctx->d_conv_flag;
+    if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && glds && !a.grouped && !stem) {
+        if (!w_split) {   // per-call split into the context's scratch (stream order makes the reuse safe)
+            if (ctx->split_bytes < w_bytes) {
+                AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (ctx->split_scratch) AMP_HIP_CHECK(hipFree(ctx->split_scratch));
+                ctx->split_scratch = nullptr; ctx->split_bytes = 0;
+                AMP_HIP_CHECK(hipMalloc(&ctx->split_scratch, w_bytes));
+                ctx->split_bytes = w_bytes;
+            }
+            hipLaunchKernelGGL(split_weights_kernel, dim3(2048), dim3(256), 0, ctx->stream, w, (size_t)a.Cout, a.K,
+                               reinterpret_cast<unsigned int*>(ctx->split_scratch));
+            w_split = ctx->split_scratch;
+        }
+        a.w = w_split;
+        const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
+        if (a.Cout > 64 && nblk128 >= 512) {
+            a.ntn = amp::cdiv(a.Cout, 128);
+            a.nblk = ntm * a.ntn;
+            launch_f16x3<128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else {
+            a.ntn = amp::cdiv(a.Cout, 64);
+            a.nblk = ntm * a.ntn;
+            launch_f16x3<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        }
+    } else if (stem) {
         a.ntn = 1;
         a.nblk = ntm;
         launch_glds<64, true>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

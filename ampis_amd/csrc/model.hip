@@ -22,6 +22,8 @@ struct ConvW {
     float* scale = nullptr;  // device [Cout] or null
     float* shift = nullptr;  // device [Cout] or null
     int cout = 0, cin = 0, kh = 0, kw = 0;
+    float* w_split = nullptr; // AMP_CONV_F16X3 operand copy of w (amp_split_weights), made at finalize; null: not eligible / out of range
+    float w_absmax = 0.f;    // max |w| seen at load (range check of the split copy)
     int groups = 1;          // > 1: w is the window layout [Cout][KH][KW][64] of amp_group_expand_weights (ResNeXt conv2)
 };
 
@@ -93,6 +95,10 @@ struct amp_model {
     struct Trainable { float* p; size_t n; };
     std::vector<Trainable> trainable;
     bool grads_valid = false;
+    float* split_arena = nullptr;       // f16x3 operand copies of the weights (inference)
+    size_t split_floats = 0;
+    bool split_stale = false;
+    int f32_reruns = 0;                 // batches re-run in AMP_CONV_F32 after the range flag was raised
     std::vector<int> img_hw;            // optional per-image valid sizes for the next batches
 };
 
@@ -158,8 +164,9 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
     amp_conv_desc d;
     d.B = B; d.H = H; d.W = W; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw;
     d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
-    if (cw.groups > 1) return amp_conv2d_grouped_nhwc(m->ctx, &d, cw.groups, x, cw.w, cw.scale, cw.shift, res, y);
-    return amp_conv2d_nhwc(m->ctx, &d, x, cw.w, cw.scale, cw.shift, res, y);
+    // pre-split weights when the layer has them; a layer whose weights exceed the fp16 range of the split copy stays on fp32 MFMA
+    const bool eligible = cw.groups == 1 && cw.cin % 32 == 0;
+    return amp::conv_run(m->ctx, &d, cw.groups, x, cw.w, cw.w_split, (eligible && !cw.w_split) ? 1 : 0, cw.scale, cw.shift, res, nullptr, y);
 }
 
 void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_list<long long> shape) {
@@ -1047,6 +1054,7 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
 void amp_model_destroy(amp_model* m) {
     if (!m) return;
     (void)hipFree(m->parena);
+    (void)hipFree(m->split_arena);
     (void)hipFree(m->ws.base);
     (void)hipFree(m->d_batch_iota);
     (void)hipFree(m->d_flags);
@@ -1081,6 +1089,9 @@ int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, c
             AMP_REQUIRE(cw.w, "amp_model_load_tensor: parameter arena exhausted at %s", name_c);
         }
         cw.cout = cout; cw.cin = cin; cw.kh = kh; cw.kw = kw;
+        float mx = 0.f;
+        for (float f : v) mx = std::max(mx, std::fabs(f));
+        cw.w_absmax = mx;
         return upload(m, cw.w, v);
     };
     auto put_shift = [&](const std::string& key, const std::vector<float>& v) -> int {
@@ -1183,6 +1194,38 @@ int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, c
     return AMP_OK;
 }
 
+namespace {
+// AMP_CONV_F16X3 operand copies (hi|lo f16 halves, x 2^8): every dense layer with Cin % 32 == 0 whose weights fit the fp16 range.
+// Re-made after the weights change (amp_model_sgd_step marks them stale).
+int refresh_split_weights(amp_model* m) {
+        size_t need = 0;
+        for (auto& kv : m->conv) {
+            const ConvW& cw = kv.second;
+            if (cw.groups == 1 && cw.cin % 32 == 0 && cw.w_absmax < 60000.f) need += ((size_t)cw.cout * cw.kh * cw.kw * cw.cin + 63) & ~(size_t)63;
+        }
+        if (m->split_floats < need) {
+            if (m->split_arena) AMP_HIP_CHECK(hipFree(m->split_arena));
+            m->split_arena = nullptr; m->split_floats = 0;
+            AMP_HIP_CHECK(hipMalloc(&m->split_arena, need * sizeof(float)));
+            m->split_floats = need;
+        }
+        size_t off = 0;
+        for (auto& kv : m->conv) {
+            ConvW& cw = kv.second;
+            cw.w_split = nullptr;
+            if (!(cw.groups == 1 && cw.cin % 32 == 0 && cw.w_absmax < 60000.f)) continue;
+            const size_t n = (size_t)cw.cout * cw.kh * cw.kw * cw.cin;
+            cw.w_split = m->split_arena + off;
+            off += (n + 63) & ~(size_t)63;
+            AMP_TRY(amp_split_weights(m->ctx, cw.w, cw.cout, cw.kh * cw.kw * cw.cin, cw.w_split));
+        }
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    m->split_stale = false;
+    return AMP_OK;
+}
+
+}  // namespace
+
 int amp_model_finalize(amp_model* m) {
     AMP_REQUIRE(m, "amp_model_finalize: null");
     for (auto& e : m->expected)
@@ -1225,12 +1268,15 @@ int amp_model_finalize(amp_model* m) {
         if (!cw.w) { cw.w = palloc(m, w.size()); cw.shift = palloc(m, bias.size()); }
         AMP_REQUIRE(cw.w && cw.shift, "amp_model_finalize: parameter arena exhausted");
         cw.cout = rp; cw.cin = cols; cw.kh = cw.kw = 1;
+        cw.w_absmax = 0.f;
+        for (float f : w) cw.w_absmax = std::max(cw.w_absmax, std::fabs(f));
         AMP_TRY(upload(m, cw.w, w));
         return upload(m, cw.shift, bias);
     };
     AMP_TRY(fuse("proposal_generator.rpn_head.pred", "proposal_generator.rpn_head.objectness_logits",
                  "proposal_generator.rpn_head.anchor_deltas", 3, 12, 256));
     AMP_TRY(fuse("roi_heads.box_predictor", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred", K + 1, 4 * K, 1024));
+    AMP_TRY(refresh_split_weights(m));
     // trainable tensors: every conv / fc weight and true bias outside the frozen stem + res2 (FREEZE_AT = 2); FrozenBN has none
     m->trainable.clear();
     for (auto& kv : m->conv) {
@@ -1265,7 +1311,19 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
         AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
         imgs_d = staged;
     }
-    const int st = run(m, imgs_d, B, H, W, oh.data(), ow.data());
+    if (m->split_stale && m->ctx->conv_mode == AMP_CONV_F16X3) AMP_TRY(refresh_split_weights(m));
+    int st = run(m, imgs_d, B, H, W, oh.data(), ow.data());
+    if (m->ctx->conv_mode == AMP_CONV_F16X3) {   // an operand left the fp16 range of the split arithmetic: the whole batch again on fp32 MFMA
+        int flag = 0;
+        if (amp_conv_range_flag(m->ctx, 1, &flag) == AMP_OK && flag) {
+            if (m->f32_reruns++ == 0)
+                fprintf(stderr, "[ampis_hip] an activation exceeded the fp16 range of AMP_CONV_F16X3; re-running the batch in AMP_CONV_F32\n");
+            m->ctx->conv_mode = AMP_CONV_F32;
+            AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, 4 * sizeof(int), m->ctx->stream));
+            st = run(m, imgs_d, B, H, W, oh.data(), ow.data());
+            m->ctx->conv_mode = AMP_CONV_F16X3;
+        }
+    }
     if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     if (st != AMP_OK) return st;
     out->B = B;
@@ -1301,6 +1359,7 @@ int amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_deca
     for (auto& t : m->trainable)
         AMP_TRY(amp_sgd_update(m->ctx, t.p, m->garena + (t.p - m->parena), m->varena + (t.p - m->parena), t.n, lr, momentum, weight_decay, grad_scale));
     m->grads_valid = false;
+    m->split_stale = true;               // the f16x3 operand copies no longer match the weights
     return AMP_OK;
 }
 
@@ -1327,7 +1386,10 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
         AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
         imgs_d = staged;
     }
+    const int mode = m->ctx->conv_mode;          // the training path (forward, dgrad, wgrad) is fp32 MFMA throughout
+    m->ctx->conv_mode = AMP_CONV_F32;
     const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
+    m->ctx->conv_mode = mode;
     if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     return st;
 }

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
         fetch_rows(0);
         stage_dma(0, 0);
         if (nsteps > 1) fetch_rows(1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA has landed (explicit: do not rely on the fence lowering)
         __syncthreads();
         for (int step = 0; step < nsteps; ++step) {
             const int cur = step & 1;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's LDS-DMA has landed
             __syncthreads();
         }
     }

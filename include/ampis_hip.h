@@ -73,6 +73,23 @@ int amp_memcpy_h2d(amp_ctx* ctx, void* dst, const void* src_h, size_t bytes);
 int amp_memcpy_d2h(amp_ctx* ctx, void* dst_h, const void* src, size_t bytes);
 int amp_memset(amp_ctx* ctx, void* dst, int value, size_t bytes);
 
+/* Convolution arithmetic of this context (every conv / fc of the inference path; the training path always runs AMP_CONV_F32).
+ * AMP_CONV_F32:   v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulation.
+ * AMP_CONV_F16X3: fp32 in / fp32 out on the f16 matrix pipe: each operand is split x = hi + lo (two f16, 22 significant bits for
+ *                 2^-25 < |x| < 65504), a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with exact products and fp32 accumulation;
+ *                 error against an fp64 reference measured at or below the fp32-MFMA kernel's (tests/test_conv_modes_gpu.py).
+ *                 An operand of magnitude >= 65504 leaves a non-finite accumulator, raises the range flag below, and
+ *                 amp_model_infer re-runs the batch in AMP_CONV_F32.  Default; override with amp_set_conv_mode or AMP_CONV_MODE=f32|f16x3. */
+enum { AMP_CONV_F32 = 0, AMP_CONV_F16X3 = 1 };
+int amp_set_conv_mode(amp_ctx* ctx, int mode);
+int amp_get_conv_mode(amp_ctx* ctx);
+/* *flag_h = 1 when an AMP_CONV_F16X3 convolution since the last clear left a non-finite accumulator; synchronises the stream */
+int amp_conv_range_flag(amp_ctx* ctx, int clear, int* flag_h);
+
+/* w [rows][K] fp32 (K % 32 == 0) -> the AMP_CONV_F16X3 operand layout (same byte size); amp_conv2d_nhwc does this per call,
+ * amp_model_finalize once per layer. */
+int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, int K, float* w_split);
+
 /* Stage a9/a10/a11/a14/a16: implicit-GEMM convolution on fp32 MFMA ------------------------- */
 typedef struct amp_conv_desc {
     int B, H, W, Cin;         /* input  [B,H,W,Cin]  (Cin % 4 == 0) */

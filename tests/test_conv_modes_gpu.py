@@ -1,0 +1,91 @@
+"""The two convolution arithmetics of the C ABI (amp_set_conv_mode): AMP_CONV_F32 (fp32 MFMA) and AMP_CONV_F16X3 (operands split
+into two f16 halves, three exact-product f16 MFMAs, fp32 accumulation).  The split mode has to be an fp32-equivalent: its error
+against an fp64 reference must not exceed the fp32-MFMA kernel's, and operands outside its range must be detected, not silently
+mis-computed."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 1, 1, 0),
+    (2, 33, 29, 256, 256, 3, 1, 1),
+    (1, 14, 14, 256, 256, 3, 1, 1),
+    (2, 16, 16, 256, 128, 1, 2, 0),
+    (1, 1, 200, 12544, 1024, 1, 1, 0),
+    (3, 9, 11, 32, 16, 1, 1, 0),
+]
+
+
+def _run(ctx, mode, x, w, sc, sh, s, p, res=None):
+    from ampis_amd import ops
+    ctx.conv_mode = mode
+    try:
+        y = ops.conv2d_nhwc(ctx, x, w, sc, sh, res, stride=s, pad=p, relu=True)
+        torch.cuda.synchronize()
+    finally:
+        ctx.conv_mode = "f16x3"
+    return y.cpu().double()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("xscale", [1.0, 300.0, 1e-3])
+def test_f16x3_is_at_least_as_accurate_as_fp32_mfma(gpu_ctx, case, xscale):
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(B, H, W, Cin, generator=g) * xscale
+    w = torch.randn(Cout, k, k, Cin, generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * xscale
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=s, padding=p)
+    ref = F.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    d = "cuda:0"
+    args = (x.to(d), w.to(d), sc.to(d), sh.to(d), s, p)
+    y32, y16 = _run(gpu_ctx, "f32", *args), _run(gpu_ctx, "f16x3", *args)
+    assert not gpu_ctx.conv_range_flag()
+    mag = ref.abs().max().item()
+    e32, e16 = (y32 - ref).abs().max().item() / mag, (y16 - ref).abs().max().item() / mag
+    r32, r16 = (y32 - ref).pow(2).mean().sqrt().item() / mag, (y16 - ref).pow(2).mean().sqrt().item() / mag
+    assert e16 <= max(1.5 * e32, 3e-7), (e16, e32)
+    assert r16 <= max(1.25 * r32, 3e-8), (r16, r32)
+
+
+def test_out_of_range_operand_raises_the_flag(gpu_ctx):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 8, 8, 64, generator=g)
+    x[0, 3, 3, 5] = 1.0e5                       # beyond fp16: the split halves cannot hold it
+    w = torch.randn(64, 1, 1, 64, generator=g) * 0.1
+    d = "cuda:0"
+    gpu_ctx.conv_range_flag()
+    _run(gpu_ctx, "f16x3", x.to(d), w.to(d), None, None, 1, 0)
+    assert gpu_ctx.conv_range_flag(), "an activation above 65504 must be reported"
+    assert not gpu_ctx.conv_range_flag(), "reading with clear=True resets the flag"
+    y = _run(gpu_ctx, "f32", x.to(d), w.to(d), None, None, 1, 0)
+    assert torch.isfinite(y).all() and not gpu_ctx.conv_range_flag()
+
+
+def test_mode_switch_and_model_fallback(gpu_ctx):
+    """A model whose activations leave the fp16 range must return exactly what the fp32-MFMA mode returns (the batch is re-run)."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    assert gpu_ctx.conv_mode == gpu_ctx.CONV_F16X3
+    K, H, W = 2, 128, 160
+    imgs = np.stack([synth_image(np.random.default_rng(2), H, W)])
+    p = P.init_params(K, seed=3, style="spread")
+    p["backbone.bottom_up.stem.conv1.norm.weight"] = p["backbone.bottom_up.stem.conv1.norm.weight"] * np.float32(4000.0)   # res2 inputs ~1e5
+    m = MaskRCNN(gpu_ctx, K, max_batch=1, max_h=H, max_w=W, max_out_hw=W, detections_per_image=20)
+    m.load_params(p)
+    a = m.infer(imgs, rle="counts")
+    assert m.tap("res2").max() > 65504
+    gpu_ctx.conv_mode = "f32"
+    try:
+        b = m.infer(imgs, rle="counts")
+    finally:
+        gpu_ctx.conv_mode = "f16x3"
+    for x, y in zip(a, b):
+        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
+        assert all(np.array_equal(q["counts"], r["counts"]) for q, r in zip(x["masks"], y["masks"]))
+    m.close()
