@@ -25,6 +25,10 @@ from ampis_amd.model import MaskRCNN
 
 BATCH, SIZE, K, DETS = 8, 1024, 2, 200
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak (v_mfma_f32_32x32x16_f16)
+# AMP_CONV_F16X3 (the default conv arithmetic, include/ampis_hip.h): fp32 in / fp32 out, every product a*b evaluated as three
+# exact-product f16 MFMAs with fp32 accumulation -> its ceiling in ALGORITHMIC flops (2*M*N*K) is a third of the f16 matrix peak.
+PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 
 
 def log(msg):
@@ -160,6 +164,7 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=4, help="timed training steps of the secondary `train` object (0 = skip)")
     ap.add_argument("--x101-steps", type=int, default=5, help="timed steps of the secondary `x101_2048` object (0 = skip)")
+    ap.add_argument("--no-strict", action="store_true", help="skip the fp32-MFMA reference run of the headline workload")
     ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog for the secondary legs, seconds")
     args = ap.parse_args()
 
@@ -191,53 +196,77 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        t = time.perf_counter()
-        step()
-        log(f"warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
-    barrier()
-    ctx.prof_begin(max_launches=args.steps * 96)
-    t0 = time.perf_counter()
-    ndet = 0
-    for _ in range(args.steps):
-        d = step()
-        ndet += sum(d.n[b] for b in range(BATCH))
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    prof = ctx.prof_end()
-    log(f"timed {args.steps} steps in {elapsed:.3f} s")
-    barrier()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(mode, warmup, steps):
+        """W untimed + exactly K timed steps in one conv arithmetic, bracketed by barrier + synchronize; max over ranks."""
+        ctx.conv_mode = mode
+        for i in range(warmup):
+            t = time.perf_counter()
+            step()
+            log(f"[{mode}] warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
+        barrier()
+        ctx.prof_begin(max_launches=steps * 96)
+        t0 = time.perf_counter()
+        ndet = 0
+        for _ in range(steps):
+            d = step()
+            ndet += sum(d.n[b] for b in range(BATCH))
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        prof = ctx.prof_end()
+        log(f"[{mode}] timed {steps} steps in {el:.3f} s")
+        barrier()
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return el, prof, ndet
+
+    mode = "f32" if os.environ.get("AMP_CONV_MODE") == "f32" else "f16x3"
+    elapsed, prof, ndet = timed(mode, args.warmup, args.steps)
+    strict = None
+    if mode == "f16x3" and not args.no_strict:      # the same workload on the fp32-MFMA kernels, for reference
+        s_el, s_prof, _ = timed("f32", 2, args.steps)
+        ctx.conv_mode = "f16x3"
+        s_ach = s_prof["flops"][0] / (s_prof["ms"][0] * 1e-3) / 1e12 if s_prof["ms"][0] > 0 else 0.0
+        strict = {"what": "same workload with AMP_CONV_MODE=f32: every conv on v_mfma_f32_32x32x2_f32",
+                  "value": round(world * BATCH * args.steps / s_el, 3), "unit": "images/s", "ms_per_step": round(s_el / args.steps * 1e3, 3),
+                  "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<128>", "achieved": round(s_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(s_ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               "kernel_ms_per_step": round(s_prof["ms"][0] / args.steps, 3)}}
 
     out = None
     if rank == 0:
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")))
-            traffic = pmc["kernels"]["conv_glds_kernel<128>"]["hbm_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v3.json")))
+            traffic = pmc["kernels"]["conv_f16x3_kernel<128>" if mode == "f16x3" else "conv_glds_kernel<128>"]["hbm_bytes_per_launch"]
         except Exception:
             pass
         ms_per_step = elapsed / args.steps * 1e3
         value = world * BATCH * args.steps / elapsed
         ach = prof["flops"][0] / (prof["ms"][0] * 1e-3) / 1e12 if prof["ms"][0] > 0 else 0.0
+        peak = PEAK_F16X3_TFLOPS if mode == "f16x3" else PEAK_F32_MFMA_TFLOPS
         conv_all = (prof["flops"][0] + prof["flops"][1]) / ((prof["ms"][0] + prof["ms"][1]) * 1e-3) / 1e12
         out = {
             "metric": "images/sec Mask R-CNN R50-FPN @1024x1024 inference", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if mode == "f32" else "f32 (convs: f16x3 split-operand MFMA -- 22-bit operands, exact products, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: R50-FPN inference, batch=8 synthetic 1024x1024 micrographs per GPU, "
                                    "K=2, 1000 proposals/img, TEST.DETECTIONS_PER_IMAGE=200, seeded random-init weights, "
                                    "outputs boxes+scores+classes+COCO-RLE counts on host",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
-                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary.json)",
+            "roofline": {"bound": "mfma",
+                         "kernel": ("conv_f16x3_kernel<128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, 3 MFMAs per product, 128x128x32 tiles, "
+                                    "LDS-DMA weights, register-staged split activations)") if mode == "f16x3" else
+                                   "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
+                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
+                         "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v3.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
@@ -253,6 +282,8 @@ def main():
         if not emitted.acquire(blocking=False) or out is None:
             return
         out.update(extra)
+        if strict is not None:
+            out["f32_mfma_reference"] = strict
         if train_obj is not None:
             out["train"] = train_obj
         if world == 1 and not args.no_cpu_baseline:
