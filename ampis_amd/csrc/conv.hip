@@ -612,7 +612,9 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& 
     }
 }
 
-template <int BN, int EPI>
+// STEM = true: the 7x7 stride-2 stem on the [B,H,W,4] input with weights [64][7][8][4] (see conv_glds_kernel): a K-step is one
+// kernel row, a lane's 8 consecutive k are two taps x 4 channels, each tap bounds-checked on its own.
+template <int BN, int EPI, bool STEM = false>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -672,13 +674,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
         b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
 
-    const int csteps = a.Cin / BK;
+    const int csteps = STEM ? 1 : a.Cin / BK;
     int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the K-step being FETCHED
     unsigned int a_voff[2];
     u32x4 ra[2][2];                             // fetched, not yet split: [row][half of the 32 B]
 
     auto fetch = [&](int buf) {                 // A(kstep) -> registers, B(kstep) -> LDS[buf]
-        if (cs == 0) {
+        if (STEM) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int iy = a_iy0[p] + kstep;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ix = a_ix0[p] + 2 * akg + h;
+                    const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    const unsigned int vo = v ? (unsigned int)((a_pb[p] + iy * a.W + ix) * 16) : OOB_VOFF;
+                    ra[p][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)vo, 0, 0);
+                }
+            }
+        } else if (cs == 0) {
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
@@ -688,10 +702,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
         }
         const int a_soff = cs * (BK * 4);
         const int b_soff = kstep * (BK * 4);
+        if (!STEM) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            ra[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p], a_soff, 0);
-            ra[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p] + 16, a_soff, 0);
+            for (int p = 0; p < 2; ++p) {
+                ra[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p], a_soff, 0);
+                ra[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p] + 16, a_soff, 0);
+            }
         }
         float* Bs = lds + buf * TILE_FLOATS + BM * BK;
 #pragma unroll
@@ -809,6 +825,11 @@ void launch_glds(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, un
         case 2: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
         default: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     }
+}
+
+void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    if (epi == 1) hipLaunchKernelGGL((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    else hipLaunchKernelGGL((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
 }
 
 template <int BN>
@@ -954,7 +975,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     AMP_REQUIRE(!a.grouped || glds, "amp_conv2d_grouped_nhwc: operands must stay below 2 GiB");
     const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
     a.range_flag = ctx->d_conv_flag;
-    if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && glds && !a.grouped && !stem) {
+    if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && ((glds && !a.grouped) || stem)) {
         if (!w_split) {   // per-call split into the context's scratch (stream order makes the reuse safe)
             if (ctx->split_bytes < w_bytes) {
                 AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -969,7 +990,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         }
         a.w = w_split;
         const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
-        if (a.Cout > 64 && nblk128 >= 512) {
+        if (stem) {
+            a.ntn = 1;
+            a.nblk = ntm;
+            launch_f16x3_stem(a, epi == 2 ? 0 : epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (a.Cout > 64 && nblk128 >= 512) {
             a.ntn = amp::cdiv(a.Cout, 128);
             a.nblk = ntm * a.ntn;
             launch_f16x3<128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
