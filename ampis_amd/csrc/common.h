@@ -87,7 +87,8 @@ struct amp_ctx {
 
 namespace amp {
 // internal convolution entry (conv.hip): w_split = weights already in the f16x3 split layout (amp_split_weights) or null;
-// force_f32 = 1 runs the fp32-MFMA kernel whatever the context mode is.
+// force_f32 = 1 runs the fp32-MFMA kernel whatever the context mode is; in_shift = s: (AMP_CONV_F16X3 only) the input is multiplied
+// by 2^s before the operand split and the sum by 2^-s (data gradients: tiny values would otherwise sit in the f16 subnormals).
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-             const float* scale, const float* shift, const float* res, const float* mask, float* y);
+             const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0);
 }

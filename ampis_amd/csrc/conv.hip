@@ -39,6 +39,7 @@ struct ConvArgs {
     int M, K, nsteps;
     int relu, res_mode, out_mode;
     int ntn;  // number of N tiles
+    float in_scale, out_scale;   // f16x3 kernels: activations are multiplied by in_scale (a power of two) before the split, the sum by out_scale
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
@@ -602,10 +603,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float LO_SCALE = 2048.0f;      // lo' = (x - hi) * 2^11
 
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& hi, f16x8& lo) {
+template <bool SCALED>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& hi, f16x8& lo, float in_scale) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float x = j < 4 ? v0[j] : v1[j - 4];
+        float x = j < 4 ? v0[j] : v1[j - 4];
+        if (SCALED) x *= in_scale;
         const _Float16 h = (_Float16)x;
         hi[j] = h;
         lo[j] = (_Float16)((x - (float)h) * LO_SCALE);
@@ -614,7 +617,10 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& 
 
 // STEM = true: the 7x7 stride-2 stem on the [B,H,W,4] input with weights [64][7][8][4] (see conv_glds_kernel): a K-step is one
 // kernel row, a lane's 8 consecutive k are two taps x 4 channels, each tap bounds-checked on its own.
-template <int BN, int EPI, bool STEM = false>
+// SCALED = true: activations are multiplied by a.in_scale before the split and the result by a.out_scale (powers of two, exact).
+// The data-gradient convolutions use it: loss gradients of 1e-9..1e-4 would sit in the f16 subnormals (the hi half keeps 11 bits
+// only above 6.1e-5); scaled by 2^16 they split like activations.
+template <int BN, int EPI, bool STEM = false, bool SCALED = false>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f16x8 hi, lo;
-            split8(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo);
+            split8<SCALED>(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo, a.in_scale);
             const int r = a_row[p], sw = (r >> 1) & 7;
             *reinterpret_cast<f16x8*>(As + r * BK + 4 * (akg ^ sw)) = hi;
             *reinterpret_cast<f16x8*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
@@ -791,7 +797,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                if (SCALED) acc[i][j][e] *= a.out_scale;
+            }
     if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
     else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
@@ -833,7 +842,17 @@ void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int 
 }
 
 template <int BN>
+void launch_f16x3_scaled(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    switch (epi) {
+        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    }
+}
+
+template <int BN>
 void launch_f16x3(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    if (a.in_scale != 1.0f) { launch_f16x3_scaled<BN>(a, epi, st, xb, wb); return; }
     switch (epi) {
         case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
         case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
@@ -914,7 +933,7 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
 }
 
 int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-                  const float* scale, const float* shift, const float* res, const float* mask, float* y) {
+                  const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -975,6 +994,8 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     AMP_REQUIRE(!a.grouped || glds, "amp_conv2d_grouped_nhwc: operands must stay below 2 GiB");
     const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
     a.range_flag = ctx->d_conv_flag;
+    a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
+    a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
     if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && ((glds && !a.grouped) || stem)) {
         if (!w_split) {   // per-call split into the context's scratch (stream order makes the reuse safe)
             if (ctx->split_bytes < w_bytes) {

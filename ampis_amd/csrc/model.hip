@@ -166,7 +166,9 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
     d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
     // pre-split weights when the layer has them; a layer whose weights exceed the fp16 range of the split copy stays on fp32 MFMA
     const bool eligible = cw.groups == 1 && (cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8));   // dense layers and the padded stem
-    return amp::conv_run(m->ctx, &d, cw.groups, x, cw.w, cw.w_split, (eligible && !cw.w_split) ? 1 : 0, cw.scale, cw.shift, res, nullptr, y);
+    // (after an SGD step the split copies are stale until the next inference refreshes them: split per call then)
+    return amp::conv_run(m->ctx, &d, cw.groups, x, cw.w, m->split_stale ? nullptr : cw.w_split, (eligible && !cw.w_split) ? 1 : 0, cw.scale, cw.shift, res,
+                         nullptr, y);
 }
 
 void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_list<long long> shape) {
@@ -562,6 +564,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const int K = c.num_classes;
     auto CONV = [&](const char* key) -> const ConvW& { return m->conv.at(key); };
     Trunk T;
+    struct ModeGuard { amp_ctx* c; int mode; ~ModeGuard() { c->conv_mode = mode; } } mode_guard{m->ctx, m->ctx->conv_mode};
     m->saving = backward;
     const int trunk_status = run_trunk(m, imgs_d, B, H, W, T);
     m->saving = false;
@@ -758,7 +761,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         amp_conv_desc d;
         d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
         d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
-        return amp_conv2d_nhwc_ex(ctx, &d, dy, wt_scratch, nullptr, nullptr, res, mask, dx);
+        // data gradient on the context's arithmetic; AMP_CONV_F16X3 splits dy * 2^16 (gradients of 1e-9..1e-4 would sit in the f16
+        // subnormals); weight gradients stay on the fp32 MFMA (wgrad.hip)
+        return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16);
     };
 
     // ---- gradient buffers of the FPN outputs p2..p6 ----
@@ -794,7 +799,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
             amp_conv_desc g;
             g.B = N; g.H = 28; g.W = 28; g.Cin = 256; g.Cout = 256; g.KH = 2; g.KW = 2; g.stride = 2; g.pad = 0; g.relu = 0; g.res_mode = 0; g.out_mode = 0;
-            AMP_TRY(amp_conv2d_nhwc_ex(ctx, &g, d_mtb, wt_scratch, nullptr, nullptr, nullptr, macts[4], d_ma));
+            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16));
         }
         float* dcur = d_ma;
         float* dnext = d_mb;
@@ -1386,10 +1391,21 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
         AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
         imgs_d = staged;
     }
-    const int mode = m->ctx->conv_mode;          // the training path (forward, dgrad, wgrad) is fp32 MFMA throughout
-    m->ctx->conv_mode = AMP_CONV_F32;
-    const int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
+    // training: forward and data-gradient convolutions follow the context's mode (AMP_CONV_F16X3: weights are split per call, they
+    // change every step); weight gradients are fp32 MFMA
+    const int mode = m->ctx->conv_mode;
+    int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
     m->ctx->conv_mode = mode;
+    if (st == AMP_OK && mode == AMP_CONV_F16X3) {   // an activation beyond the fp16 range: the step again, entirely on fp32 MFMA
+        int flag = 0;
+        if (amp_conv_range_flag(m->ctx, 1, &flag) == AMP_OK && flag) {
+            if (m->f32_reruns++ == 0)
+                fprintf(stderr, "[ampis_hip] an activation exceeded the fp16 range of AMP_CONV_F16X3; re-running the step in AMP_CONV_F32\n");
+            m->ctx->conv_mode = AMP_CONV_F32;
+            st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
+            m->ctx->conv_mode = mode;
+        }
+    }
     if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     return st;
 }
