@@ -73,7 +73,8 @@ int amp_memcpy_h2d(amp_ctx* ctx, void* dst, const void* src_h, size_t bytes);
 int amp_memcpy_d2h(amp_ctx* ctx, void* dst_h, const void* src, size_t bytes);
 int amp_memset(amp_ctx* ctx, void* dst, int value, size_t bytes);
 
-/* Convolution arithmetic of this context (every conv / fc of the inference path; the training path always runs AMP_CONV_F32).
+/* Convolution arithmetic of this context (every conv / fc of the inference path and, in training, the forward and data-gradient
+ * convolutions; weight gradients always run on the fp32 MFMA).
  * AMP_CONV_F32:   v_mfma_f32_32x32x2_f32, exact fp32 products, fp32 accumulation.
  * AMP_CONV_F16X3: fp32 in / fp32 out on the f16 matrix pipe: each operand is split x = hi + lo (two f16, 22 significant bits for
  *                 2^-25 < |x| < 65504), a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with exact products and fp32 accumulation;
