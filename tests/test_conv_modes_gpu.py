@@ -89,3 +89,40 @@ def test_mode_switch_and_model_fallback(gpu_ctx):
         assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
         assert all(np.array_equal(q["counts"], r["counts"]) for q, r in zip(x["masks"], y["masks"]))
     m.close()
+
+
+def test_training_trajectories_agree_between_modes(gpu_ctx):
+    """Eight SGD steps from the same weights, batches and sampling seeds: (a) everything on the fp32 MFMA, (b) forward + data-gradient
+    convolutions in AMP_CONV_F16X3, (c) fp32 MFMA again with the stem weights perturbed by 1e-7 relative.  Detection training
+    amplifies any rounding difference (NMS / sampling decisions flip), so (b) cannot track (a) forever -- but it must not drift
+    faster than the fp32 run does under a one-ulp-sized perturbation: the split arithmetic is an fp32 equivalent in training too."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    K, B, S, steps = 2, 2, 256, 8
+    imgs, gts = synth.batch(B, S, S, first_index=300)
+    p0 = P.init_params(K, seed=2, style="spread")
+    traj = {}
+    for tag, mode, eps in (("f32", "f32", 0.0), ("f16x3", "f16x3", 0.0), ("f32_perturbed", "f32", 1e-7)):
+        gpu_ctx.conv_mode = mode
+        try:
+            p = dict(p0)
+            if eps:
+                p["backbone.bottom_up.stem.conv1.weight"] = p0["backbone.bottom_up.stem.conv1.weight"] * np.float32(1 + eps)
+            m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 700, max_poly_doubles=B * 700 * 64)
+            m.load_params(p)
+            losses = []
+            for i in range(steps):
+                L = m.forward_losses(imgs, gts, seed=100 + i, backward=True)
+                m.sgd_step(0.002)
+                losses.append([L[k] for k in sorted(L)])
+            traj[tag] = np.array(losses)
+            m.close()
+        finally:
+            gpu_ctx.conv_mode = "f16x3"
+    a = traj["f32"]
+    assert all(np.isfinite(t).all() for t in traj.values())
+    drift = lambda t: (np.abs(a - t) / np.maximum(np.abs(a), 1e-3)).max(axis=1)
+    d16, dper = drift(traj["f16x3"]), drift(traj["f32_perturbed"])
+    assert d16[0] < 1e-5, d16[0]                                   # same forward to fp32 rounding
+    assert np.all(d16[:6] <= 10 * dper[:6] + 1e-4), (d16, dper)     # measured: 2e-7 1e-5 4e-5 2e-4 1e-3 4e-3 vs 3e-7 5e-6 7e-6 4e-5 2e-4 5e-3
+    assert abs(traj["f16x3"][-1].sum() - a[-1].sum()) < 0.05 * a[-1].sum()
