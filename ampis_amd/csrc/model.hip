@@ -99,6 +99,8 @@ struct amp_model {
     size_t split_floats = 0;
     bool split_stale = false;
     int f32_reruns = 0;                 // batches re-run in AMP_CONV_F32 after the range flag was raised
+    uint8_t* img_stage = nullptr;       // device copy of host images (amp_model_infer / forward_losses with imgs_on_host), grown on demand
+    size_t img_stage_bytes = 0;
     std::vector<int> img_hw;            // optional per-image valid sizes for the next batches
 };
 
@@ -1060,6 +1062,7 @@ void amp_model_destroy(amp_model* m) {
     if (!m) return;
     (void)hipFree(m->parena);
     (void)hipFree(m->split_arena);
+    (void)hipFree(m->img_stage);
     (void)hipFree(m->ws.base);
     (void)hipFree(m->d_batch_iota);
     (void)hipFree(m->d_flags);
@@ -1296,6 +1299,18 @@ int amp_model_finalize(amp_model* m) {
     return AMP_OK;
 }
 
+static int stage_images(amp_model* m, const uint8_t* host, size_t bytes) {
+    if (m->img_stage_bytes < bytes) {
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        if (m->img_stage) AMP_HIP_CHECK(hipFree(m->img_stage));
+        m->img_stage = nullptr; m->img_stage_bytes = 0;
+        AMP_HIP_CHECK(hipMalloc(&m->img_stage, bytes));
+        m->img_stage_bytes = bytes;
+    }
+    AMP_HIP_CHECK(hipMemcpyAsync(m->img_stage, host, bytes, hipMemcpyHostToDevice, m->ctx->stream));
+    return AMP_OK;
+}
+
 int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const int* out_h_h,
                     const int* out_w_h, amp_dets* out) {
     AMP_REQUIRE(m && imgs_bgr && out, "amp_model_infer: null argument");
@@ -1310,11 +1325,9 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
     AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
     AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, 4 * sizeof(int), m->ctx->stream));
     const uint8_t* imgs_d = imgs_bgr;
-    uint8_t* staged = nullptr;
     if (imgs_on_host) {
-        AMP_HIP_CHECK(hipMalloc(&staged, (size_t)B * H * W * 3));
-        AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
-        imgs_d = staged;
+        AMP_TRY(stage_images(m, imgs_bgr, (size_t)B * H * W * 3));
+        imgs_d = m->img_stage;
     }
     if (m->split_stale && m->ctx->conv_mode == AMP_CONV_F16X3) AMP_TRY(refresh_split_weights(m));
     int st = run(m, imgs_d, B, H, W, oh.data(), ow.data());
@@ -1329,7 +1342,6 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
             m->ctx->conv_mode = AMP_CONV_F16X3;
         }
     }
-    if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     if (st != AMP_OK) return st;
     out->B = B;
     out->D = m->cfg.detections_per_image;
@@ -1385,11 +1397,9 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
     AMP_REQUIRE(B >= 1 && B <= m->cfg.max_batch && Hp <= m->cfg.max_h && Wp <= m->cfg.max_w, "amp_model_forward_losses: batch exceeds the model capacity");
     AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
     const uint8_t* imgs_d = imgs_bgr;
-    uint8_t* staged = nullptr;
     if (imgs_on_host) {
-        AMP_HIP_CHECK(hipMalloc(&staged, (size_t)B * H * W * 3));
-        AMP_HIP_CHECK(hipMemcpyAsync(staged, imgs_bgr, (size_t)B * H * W * 3, hipMemcpyHostToDevice, m->ctx->stream));
-        imgs_d = staged;
+        AMP_TRY(stage_images(m, imgs_bgr, (size_t)B * H * W * 3));
+        imgs_d = m->img_stage;
     }
     // training: forward and data-gradient convolutions follow the context's mode (AMP_CONV_F16X3: weights are split per call, they
     // change every step); weight gradients are fp32 MFMA
@@ -1406,7 +1416,6 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
             m->ctx->conv_mode = mode;
         }
     }
-    if (staged) { (void)hipStreamSynchronize(m->ctx->stream); (void)hipFree(staged); }
     return st;
 }
 
