@@ -43,6 +43,40 @@ def resize_shortest_edge(img, min_size, max_size):
     return np.asarray(Image.fromarray(img).resize((neww, newh), Image.BILINEAR))
 
 
+def shortest_edge_size(h, w, min_size, max_size):
+    """Output size of detectron2 ResizeShortestEdge.get_transform (same rounding)."""
+    if min_size == 0:
+        return h, w
+    scale = min_size * 1.0 / min(h, w)
+    newh, neww = (min_size, scale * w) if h < w else (scale * h, min_size)
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def device_resize_shortest_edge(ctx, img, min_size, max_size, bufs):
+    """Upload `img` (uint8 HxWx3) and resize it on the device with the PIL-exact kernel.  Returns (device pointer of the network
+    input, (h, w), bufs); `bufs` caches the device buffers between calls."""
+    import ctypes as C
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape[:2]
+    h, w = shortest_edge_size(H, W, min_size, max_size)
+    need = {"src": img.nbytes, "dst": h * w * 3, "tmp": int(_lib.lib().amp_resize_scratch_bytes(H, W, h, w))}
+    for k, n in need.items():
+        if bufs.get(k + "_n", 0) < n:
+            if bufs.get(k):
+                _lib.check(_lib.lib().amp_free(ctx.handle, C.c_void_p(bufs[k])), "amp_free")
+            bufs[k] = ctx.malloc(n)
+            bufs[k + "_n"] = n
+    ctx.h2d(bufs["src"], img)
+    if (h, w) == (H, W):
+        return bufs["src"], (h, w), bufs
+    _lib.check(_lib.lib().amp_resize_bilinear_u8(ctx.handle, C.c_void_p(bufs["src"]), H, W, C.c_void_p(bufs["dst"]), h, w, C.c_void_p(bufs["tmp"])),
+               "amp_resize_bilinear_u8")
+    return bufs["dst"], (h, w), bufs
+
+
 def _device_index(dev):
     dev = str(dev)
     if dev.startswith("cpu"):
@@ -94,11 +128,11 @@ class DefaultPredictor:
         if self.input_format == "RGB":
             original_image = original_image[:, :, ::-1]
         height, width = original_image.shape[:2]
-        image = resize_shortest_edge(np.ascontiguousarray(original_image), int(self.cfg.INPUT.MIN_SIZE_TEST),
-                                     int(self.cfg.INPUT.MAX_SIZE_TEST))
-        h, w = image.shape[:2]
+        # ResizeShortestEdge on the device (PIL-exact bilinear, amp_resize_bilinear_u8): the image goes up once, as uint8
+        dptr, (h, w), self._bufs = device_resize_shortest_edge(self.ctx, original_image, int(self.cfg.INPUT.MIN_SIZE_TEST),
+                                                               int(self.cfg.INPUT.MAX_SIZE_TEST), getattr(self, "_bufs", {}))
         model = self._ensure(h, w, max(height, width))
-        r = model.infer(np.ascontiguousarray(image)[None], out_sizes=[(height, width)])[0]
+        r = model.infer(device_ptr=dptr, shape=(1, h, w), out_sizes=[(height, width)])[0]
         inst = Instances((height, width))
         inst.pred_boxes = Boxes(torch.from_numpy(r["boxes"]))
         inst.scores = torch.from_numpy(r["scores"])

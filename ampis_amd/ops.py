@@ -66,6 +66,20 @@ def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, str
     return y
 
 
+def resize_bilinear_u8(ctx, img, h, w):
+    """img uint8 ndarray [H,W,3] (host) -> resized uint8 ndarray [h,w,3]; PIL-exact bilinear on the device (amp_resize_bilinear_u8)."""
+    import numpy as np
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W, _ = img.shape
+    src = torch.from_numpy(img).to("cuda:%d" % ctx.device)
+    dst = torch.empty((h, w, 3), dtype=torch.uint8, device=src.device)
+    tmp = torch.empty(int(lib().amp_resize_scratch_bytes(H, W, h, w)), dtype=torch.uint8, device=src.device)
+    torch.cuda.synchronize()
+    check(lib().amp_resize_bilinear_u8(ctx.handle, ptr(src), H, W, ptr(dst), h, w, ptr(tmp)), "amp_resize_bilinear_u8")
+    check(lib().amp_sync(ctx.handle), "amp_sync")
+    return dst.cpu().numpy()
+
+
 def conv2d_wgrad(ctx, x, dy, w_shape, stride=1, pad=0, scale=None, grad=None):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dW [Cout,KH,KW,Cin] (accumulated into `grad` when given)."""
     _f32c(x), _f32c(dy)

@@ -91,6 +91,12 @@ int amp_conv_range_flag(amp_ctx* ctx, int clear, int* flag_h);
  * amp_model_finalize once per layer. */
 int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, int K, float* w_split);
 
+/* Stage a7 (DefaultPredictor.__call__: ResizeShortestEdge): uint8 bilinear resize, bit-exact with PIL's Image.resize(BILINEAR)
+ * (antialiased triangle filter, 22-bit fixed-point coefficients, horizontal then vertical pass).  src [H,W,3], dst [h,w,3] and
+ * tmp (amp_resize_scratch_bytes) are device pointers. */
+size_t amp_resize_scratch_bytes(int H, int W, int h, int w);
+int amp_resize_bilinear_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int h, int w, void* tmp);
+
 /* Stage a9/a10/a11/a14/a16: implicit-GEMM convolution on fp32 MFMA ------------------------- */
 typedef struct amp_conv_desc {
     int B, H, W, Cin;         /* input  [B,H,W,Cin]  (Cin % 4 == 0) */
