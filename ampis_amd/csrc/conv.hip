@@ -620,22 +620,27 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& 
 // SCALED = true: activations are multiplied by a.in_scale before the split and the result by a.out_scale (powers of two, exact).
 // The data-gradient convolutions use it: loss gradients of 1e-9..1e-4 would sit in the f16 subnormals (the hi half keeps 11 bits
 // only above 6.1e-5); scaled by 2^16 they split like activations.
+// BN = 256 runs 8 waves (2 x 4, one workgroup per CU): the activation tile is fetched and split once for 256 output channels, so a
+// wave carries half the split work and half the activation loads per MFMA of the 4-wave tiles.
 template <int BN, int EPI, bool STEM = false, bool SCALED = false>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
+__global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv_f16x3_kernel(const ConvArgs a, const unsigned int x_bytes,
+                                                                                                const unsigned int w_bytes) {
     constexpr int BM = 128;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int WTM = BM / 2, WTN = (BN == 64) ? 32 : 64;
+    constexpr int NWN = BN / WTN, NW = 2 * NWN;   // waves across N, waves per workgroup
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int GB = BN / 32;           // DMA instructions per wave per step for B: BN/4 rows per wave, 8 rows each
+    constexpr int RPT = 512 / (64 * NW);  // activation rows per lane (128 rows x 4 lanes per row over the workgroup)
+    constexpr int GB = BN / NW / 8;       // DMA instructions per wave per step for B: BN/NW rows per wave, 8 rows each
     constexpr int TILE_FLOATS = (BM + BN) * BK;   // a row = 32 k = 64 B hi halves + 64 B lo halves = 32 dwords, as in the fp32 kernel
     constexpr int SLD = WTN + 4;
-    constexpr int STAGE_FLOATS = 4 * WTM * SLD;
+    constexpr int STAGE_FLOATS = NW * WTM * SLD;
     constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
@@ -650,9 +655,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
 
     // ---- A (activations): lane = 4 * (row in a 16-row group) + kg; a lane owns 8 consecutive k (32 B) of rows ra[0], ra[1] ----
     const int arow = lane >> 2, akg = lane & 3;
-    int a_iy0[2], a_ix0[2], a_pb[2], a_row[2];
+    int a_iy0[RPT], a_ix0[RPT], a_pb[RPT], a_row[RPT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < RPT; ++p) {
         const int r = p * 64 + wave * 16 + arow;
         a_row[p] = r;
         const int m = m0 + r;
@@ -675,20 +680,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
     unsigned int b_voff[GB];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-        const int r = wave * (BN / 4) + 8 * g + srow;
+        const int r = wave * (BN / NW) + 8 * g + srow;
         const int n = n0 + r;
         b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
 
     const int csteps = STEM ? 1 : a.Cin / BK;
     int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the K-step being FETCHED
-    unsigned int a_voff[2];
-    u32x4 ra[2][2];                             // fetched, not yet split: [row][half of the 32 B]
+    unsigned int a_voff[RPT];
+    u32x4 ra[RPT][2];                             // fetched, not yet split: [row][half of the 32 B]
 
     auto fetch = [&](int buf) {                 // A(kstep) -> registers, B(kstep) -> LDS[buf]
         if (STEM) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < RPT; ++p) {
                 const int iy = a_iy0[p] + kstep;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
             }
         } else if (cs == 0) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < RPT; ++p) {
                 const int iy = a_iy0[p] + ky, ix = a_ix0[p] + kx;
                 const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 a_voff[p] = v ? (unsigned int)(((a_pb[p] + iy * a.W + ix) * a.Cin + 8 * akg) * 4) : OOB_VOFF;
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
         const int b_soff = kstep * (BK * 4);
         if (!STEM) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < RPT; ++p) {
                 ra[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p], a_soff, 0);
                 ra[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff[p] + 16, a_soff, 0);
             }
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
         float* Bs = lds + buf * TILE_FLOATS + BM * BK;
 #pragma unroll
         for (int g = 0; g < GB; ++g)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK),
                                                      16, (int)b_voff[g], b_soff, 0, 0);
         ++kstep;
         if (++cs == csteps) {
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(const ConvArgs a, co
     auto commit = [&](int buf) {                // split the fetched A registers into LDS[buf]
         float* As = lds + buf * TILE_FLOATS;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < RPT; ++p) {
             f16x8 hi, lo;
             split8<SCALED>(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo, a.in_scale);
             const int r = a_row[p], sw = (r >> 1) & 7;
@@ -843,20 +848,22 @@ void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int 
 
 template <int BN>
 void launch_f16x3_scaled(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    constexpr int NT_ = (BN == 256) ? 512 : 256;
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0, false, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     }
 }
 
 template <int BN>
 void launch_f16x3(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (a.in_scale != 1.0f) { launch_f16x3_scaled<BN>(a, epi, st, xb, wb); return; }
+    constexpr int NT_ = (BN == 256) ? 512 : 256;
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     }
 }
 
@@ -869,6 +876,8 @@ void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
 
 }  // namespace
 
+static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles where Cout % 256 == 0
+extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
 extern "C" void amp_debug_set_conv_generic_epilogue(int on) { g_conv_generic_epi = on; }
 static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
@@ -1015,6 +1024,10 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             a.ntn = 1;
             a.nblk = ntm;
             launch_f16x3_stem(a, epi == 2 ? 0 : epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (g_f16x3_bn256 && a.Cout % 256 == 0 && ntm * (a.Cout / 256) >= 512) {
+            a.ntn = a.Cout / 256;
+            a.nblk = ntm * a.ntn;
+            launch_f16x3<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (a.Cout > 64 && nblk128 >= 512) {
             a.ntn = amp::cdiv(a.Cout, 128);
             a.nblk = ntm * a.ntn;

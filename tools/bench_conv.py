@@ -33,6 +33,9 @@ SHAPES = [
 def main():
     ctx = ops.torch_context(0)
     only = os.environ.get("AMP_ONLY")
+    if os.environ.get("AMP_BN256"):
+        from ampis_amd import _lib
+        _lib.lib().amp_debug_set_f16x3_bn256(int(os.environ["AMP_BN256"]))
     d = "cuda:0"
     out = []
     for shp in SHAPES:
