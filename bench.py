@@ -240,8 +240,10 @@ def main():
     if rank == 0:
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v4.json")))
-            traffic = pmc["kernels"]["conv_f16x3_kernel<128>" if mode == "f16x3" else "conv_glds_kernel<128>"]["hbm_bytes_per_launch"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v5.json")))
+            key = ("conv_f16x3_kernel<256>" if "conv_f16x3_kernel<256>" in pmc["kernels"] else "conv_f16x3_kernel<128>") if mode == "f16x3" \
+                else "conv_glds_kernel<128>"
+            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
         except Exception:
             pass
         ms_per_step = elapsed / args.steps * 1e3
@@ -262,13 +264,13 @@ def main():
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_f16x3_kernel<128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, 3 MFMAs per product, 128x128x32 tiles, "
-                                    "LDS-DMA weights, register-staged split activations)") if mode == "f16x3" else
+                         "kernel": ("conv_f16x3_kernel<256|128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, 3 MFMAs per product, 128x256x32 "
+                                    "8-wave / 128x128x32 4-wave tiles, LDS-DMA weights, register-staged split activations)") if mode == "f16x3" else
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
                          "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v4.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v5.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
