@@ -685,7 +685,8 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
         b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
 
-    const int csteps = STEM ? 1 : a.Cin / BK;
+    const int csteps = STEM ? 1 : a.cin_win / BK;
+    const int a_win = a.grouped ? n0 * 4 : 0;   // bytes: first input channel of this N tile's window (grouped conv, BN = 64 only)
     int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the K-step being FETCHED
     unsigned int a_voff[RPT];
     u32x4 ra[RPT][2];                             // fetched, not yet split: [row][half of the 32 B]
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
                 a_voff[p] = v ? (unsigned int)(((a_pb[p] + iy * a.W + ix) * a.Cin + 8 * akg) * 4) : OOB_VOFF;
             }
         }
-        const int a_soff = cs * (BK * 4);
+        const int a_soff = cs * (BK * 4) + a_win;
         const int b_soff = kstep * (BK * 4);
         if (!STEM) {
 #pragma unroll
@@ -1005,7 +1006,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     a.range_flag = ctx->d_conv_flag;
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
     a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
-    if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && ((glds && !a.grouped) || stem)) {
+    if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && (glds || stem)) {
         if (!w_split) {   // per-call split into the context's scratch (stream order makes the reuse safe)
             if (ctx->split_bytes < w_bytes) {
                 AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1024,6 +1025,10 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             a.ntn = 1;
             a.nblk = ntm;
             launch_f16x3_stem(a, epi == 2 ? 0 : epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (a.grouped) {     // the window of a 64-wide N tile is the tile's own 64 input channels
+            a.ntn = a.Cout / 64;
+            a.nblk = ntm * a.ntn;
+            launch_f16x3<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (g_f16x3_bn256 && a.Cout % 256 == 0 && ntm * (a.Cout / 256) >= 512) {
             a.ntn = a.Cout / 256;
             a.nblk = ntm * a.ntn;

@@ -167,7 +167,7 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
     d.B = B; d.H = H; d.W = W; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw;
     d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
     // pre-split weights when the layer has them; a layer whose weights exceed the fp16 range of the split copy stays on fp32 MFMA
-    const bool eligible = cw.groups == 1 && (cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8));   // dense layers and the padded stem
+    const bool eligible = cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8);   // dense and grouped layers, the padded stem
     // (after an SGD step the split copies are stale until the next inference refreshes them: split per call then)
     return amp::conv_run(m->ctx, &d, cw.groups, x, cw.w, m->split_stale ? nullptr : cw.w_split, (eligible && !cw.w_split) ? 1 : 0, cw.scale, cw.shift, res,
                          nullptr, y);
@@ -1209,7 +1209,7 @@ int refresh_split_weights(amp_model* m) {
         size_t need = 0;
         for (auto& kv : m->conv) {
             const ConvW& cw = kv.second;
-            if (cw.groups == 1 && (cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f) need += ((size_t)cw.cout * cw.kh * cw.kw * cw.cin + 63) & ~(size_t)63;
+            if ((cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f) need += ((size_t)cw.cout * cw.kh * cw.kw * (cw.groups > 1 ? 64 : cw.cin) + 63) & ~(size_t)63;
         }
         if (m->split_floats < need) {
             if (m->split_arena) AMP_HIP_CHECK(hipFree(m->split_arena));
@@ -1221,11 +1221,12 @@ int refresh_split_weights(amp_model* m) {
         for (auto& kv : m->conv) {
             ConvW& cw = kv.second;
             cw.w_split = nullptr;
-            if (!(cw.groups == 1 && (cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f)) continue;
-            const size_t n = (size_t)cw.cout * cw.kh * cw.kw * cw.cin;
+            if (!((cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f)) continue;
+            const int kin = cw.groups > 1 ? 64 : cw.cin;     // grouped 3x3: window layout [Cout][KH][KW][64]
+            const size_t n = (size_t)cw.cout * cw.kh * cw.kw * kin;
             cw.w_split = m->split_arena + off;
             off += (n + 63) & ~(size_t)63;
-            AMP_TRY(amp_split_weights(m->ctx, cw.w, cw.cout, cw.kh * cw.kw * cw.cin, cw.w_split));
+            AMP_TRY(amp_split_weights(m->ctx, cw.w, cw.cout, cw.kh * cw.kw * kin, cw.w_split));
         }
         AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     m->split_stale = false;
