@@ -84,9 +84,38 @@ __global__ void gather_dets_kernel(int B, int cap, int D, const float* sboxes, c
     }
 }
 
+// compact list of the detections of a batch: row off[b] + i <- (image b, detection i), off = exclusive prefix of min(count, D)
+__global__ void compact_dets_kernel(int B, int D, const int* __restrict__ det_count, const float* __restrict__ det_boxes,
+                                    const float* __restrict__ det_scores, const int* __restrict__ det_classes, float* __restrict__ boxes,
+                                    float* __restrict__ scores, int* __restrict__ classes, int* __restrict__ batch) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const int b = t / D, i = t - b * D;
+    if (i >= min(det_count[b], D)) return;
+    int off = 0;
+    for (int q = 0; q < b; ++q) off += min(det_count[q], D);
+    const int o = off + i;
+    const float4 v = reinterpret_cast<const float4*>(det_boxes)[t];
+    reinterpret_cast<float4*>(boxes)[o] = v;
+    scores[o] = det_scores[t];
+    classes[o] = det_classes[t];
+    batch[o] = b;
+}
+
 }  // namespace
 
 extern "C" {
+
+int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
+                     float* boxes, float* scores, int* classes, int* batch) {
+    AMP_REQUIRE(ctx && det_count && det_boxes && det_scores && det_classes && boxes && scores && classes && batch && B >= 1 && D >= 1,
+                "amp_compact_dets: bad argument");
+    hipLaunchKernelGGL(compact_dets_kernel, dim3(amp::cdiv(B * D, 256)), dim3(256), 0, ctx->stream, B, D, det_count, det_boxes, det_scores,
+                       det_classes, boxes, scores, classes, batch);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
 
 int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
                        int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,

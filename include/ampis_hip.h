@@ -192,6 +192,9 @@ int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* pro
 int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
                     const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes,
                     const int* payload_in /* [B,cap] or NULL */, int* payload_out /* [B,D] or NULL */);
+/* [B][D] detections with device-side counts -> compact rows in image order (+ the image index of every row) for the mask branch */
+int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
+                     float* boxes, float* scores, int* classes, int* batch);
 
 /* Stages a16 / a17 / a3: mask probability, paste + threshold + RLE counts ----------------------- */
 int amp_mask_prob(amp_ctx* ctx, const float* logits, const int* classes, int N, int K, float* prob);
