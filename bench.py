@@ -175,11 +175,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU fallback for the hot path"
+    if os.environ.get("AMP_BENCH_REHEARSAL"):    # rehearsal of the N>1 code path on a one-GPU box: every rank on device 0, gloo collectives
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if os.environ.get("AMP_BENCH_REHEARSAL"):
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     log(f"rank {rank}/{world}: creating model")
     ctx = _lib.Context(local_rank)
