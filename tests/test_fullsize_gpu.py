@@ -82,3 +82,38 @@ def test_bitwise_deterministic(run):
         assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
         assert np.array_equal(x["classes"], y["classes"])
         assert all(np.array_equal(p["counts"], q["counts"]) for p, q in zip(x["masks"], y["masks"]))
+
+
+def test_fullsize_image_against_the_oracle(gpu_ctx):
+    """One benchmark-sized image (1024x1024, 1000 proposals, 200 detections) through the oracle too: the end-to-end gate of
+    tests/test_e2e_gpu.py at BASELINE configs[1] scale (the oracle needs a few seconds per image on the host cores)."""
+    import torch
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O
+    from test_e2e_gpu import _decode
+    S, K, D = 1024, 2, 200
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    imgs, _ = synth.batch(1, S, S, first_index=7)
+    p = P.init_params(K, seed=0, style="spread")
+    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D))[0]
+    m = MaskRCNN(gpu_ctx, K, max_batch=1, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+    m.load_params(p)
+    o = m.infer(imgs)[0]
+    m.close()
+    rb, rs, rc, rm = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy(), ref["masks"].numpy()
+    assert len(rb) == D and abs(len(o["boxes"]) - D) <= 2
+    good, worst = 0, []
+    for i in range(len(rb)):
+        d = np.abs(o["boxes"] - rb[i]).max(axis=1)
+        j = int(np.argmin(d))
+        assert d[j] < 1e-3 and o["classes"][j] == rc[i] and abs(o["scores"][j] - rs[i]) < 1e-4, (i, float(d[j]))
+        gm = _decode(o["masks"][j]["counts"], S, S)
+        flips, area = int((gm ^ rm[i]).sum()), int(rm[i].sum())
+        worst.append((flips, area))
+        # threshold flips scale with the outline: masks here reach 10^5 px (outline ~10^3 px), the small-image gate of 2 px does not
+        assert flips <= max(2, 2e-4 * area), (i, flips, area)
+        u = (gm | rm[i]).sum()
+        good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
+    print("flips/area of the 5 worst masks:", sorted(worst, reverse=True)[:5], "masks at IoU>=0.999:", good)
+    assert good >= 0.97 * len(rb), good
