@@ -90,5 +90,9 @@ namespace amp {
 // force_f32 = 1 runs the fp32-MFMA kernel whatever the context mode is; in_shift = s: (AMP_CONV_F16X3 only) the input is multiplied
 // by 2^s before the operand split and the sum by 2^-s (data gradients: tiny values would otherwise sit in the f16 subnormals).
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-             const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0);
+             const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0);
+int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
+                  float* out, int* level_out, int out_split);   // out_split = 1: the pooled tensor in the split operand format
+// fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
+// only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)
 }

@@ -21,6 +21,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr float LO_SCALE = 2048.0f;      // AMP_CONV_F16X3: lo' = (x - hi) * 2^11 (see conv_f16x3_kernel)
 
 constexpr int BK = 32;      // K-slice per step (floats)
 constexpr int LDS_LD = 36;  // padded row length in LDS (floats): 144 B rows -> conflict-free ds_read_b128
@@ -40,6 +44,7 @@ struct ConvArgs {
     int relu, res_mode, out_mode;
     int ntn;  // number of N tiles
     float in_scale, out_scale;   // f16x3 kernels: activations are multiplied by in_scale (a power of two) before the split, the sum by out_scale
+    int y_split;            // 1: y is written in the split hi|lo' row format (out_mode 0, Cout % 32 == 0): the next conv's operand
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
@@ -269,7 +274,24 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
                 if (has_mask) t = mk[it][q] > 0.f ? t : 0.f;
                 o[q] = t;
             }
-            if (mv[it]) *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
+            if (a.y_split) {
+                // row-relative: 32 channels = 64 B of hi halves + 64 B of lo' halves; this lane's 4 channels -> 8 B in each
+                if (mv[it]) {
+                    f16x4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const _Float16 h = (_Float16)o[q];
+                        hi[q] = h;
+                        lo[q] = (_Float16)((o[q] - (float)h) * LO_SCALE);
+                    }
+                    const size_t row = yoff[it] - (size_t)n;                     // float index of the row start
+                    char* base = reinterpret_cast<char*>(a.y + row) + (n >> 5) * 128 + (n & 31) * 2;
+                    *reinterpret_cast<f16x4*>(base) = hi;
+                    *reinterpret_cast<f16x4*>(base + 64) = lo;
+                }
+            } else if (mv[it]) {
+                *reinterpret_cast<f32x4*>(a.y + yoff[it]) = o;
+            }
         }
         if (CHECK && bad) atomicOr(a.range_flag, 1);
     };
@@ -441,23 +463,28 @@ constexpr unsigned int OOB_VOFF = 0x80000000u;   // >= num_records of every buff
 // STEM = true: the 7x7 stride-2 stem on the [B,H,W,4] input with weights [64][7][8][4]: a K-step is one kernel row ky, whose
 // 8 taps x 4 channels are 128 contiguous bytes; the 16-B chunk index IS the tap kx, so validity is per chunk.
 // EPI: 0 = generic epilogue (any Cout), 1 = fast (Cout % 4 == 0, out_mode 0, res_mode 0/1), 2 = fast with per-row (b,oy,ox).
-template <int BN, bool STEM = false, int EPI = 0>
-__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
+// F16 = true: AMP_CONV_F16X3 with BOTH operands already in the split hi|lo' row format -- the input tensor was written that way by
+// its producer (conv epilogue / RoIAlign with split output; byte offsets equal the fp32 tensor's) -- so activations and weights
+// are staged by LDS-DMA with no per-step VALU, and the compute loop is conv_f16x3_kernel's.  BN = 256 runs 8 waves (2 x 4).
+template <int BN, bool STEM = false, int EPI = 0, bool F16 = false>
+__global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv_glds_kernel(const ConvArgs a, const unsigned int x_bytes,
+                                                                                               const unsigned int w_bytes) {
     constexpr int BM = 128;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int WTM = BM / 2, WTN = (BN == 64) ? 32 : 64;
+    constexpr int NWN = BN / WTN, NW = 2 * NWN;   // waves across N, waves per workgroup
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int GA = 4;                 // DMA instructions per wave per step for A: 32 rows per wave, 8 rows each
-    constexpr int GB = BN / 32;           // ... for B: BN/4 rows per wave
+    constexpr int GA = BM / NW / 8;       // DMA instructions per wave per step for A: BM/NW rows per wave, 8 rows each
+    constexpr int GB = BN / NW / 8;       // ... for B: BN/NW rows per wave
     constexpr int TILE_FLOATS = (BM + BN) * BK;
     constexpr int SLD = WTN + 4;
-    constexpr int STAGE_FLOATS = 4 * WTM * SLD;
+    constexpr int STAGE_FLOATS = NW * WTM * SLD;
     constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
@@ -475,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     int a_iy0[GA], a_ix0[GA], a_pb[GA], a_chunk[GA];
 #pragma unroll
     for (int g = 0; g < GA; ++g) {
-        const int r = wave * 32 + 8 * g + srow;
+        const int r = wave * (BM / NW) + 8 * g + srow;
         a_chunk[g] = 4 * (spos ^ ((r >> 1) & 7));      // source chunk (floats) = 4 * (pos ^ swz(row))
         const int m = m0 + r;
         if (m < a.M) {
@@ -495,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     unsigned int b_voff[GB];              // byte offset of the weight row (+ swizzled chunk); the K offset rides in soffset
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-        const int r = wave * (BN / 4) + 8 * g + srow;
+        const int r = wave * (BN / NW) + 8 * g + srow;
         const int n = n0 + r;
         b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
@@ -524,11 +551,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
         const int b_soff = kstep * (BK * 4);
 #pragma unroll
         for (int g = 0; g < GA; ++g)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * 32 + 8 * g) * BK),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK),
                                                      16, (int)a_voff[g], a_soff, 0, 0);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / 4) + 8 * g) * BK),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK),
                                                      16, (int)b_voff[g], b_soff, 0, 0);
         ++kstep;
         if (++cs == csteps) {
@@ -538,12 +565,16 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
     };
 
     f32x16 acc[MT][NT];
+    f32x16 acx[F16 ? MT : 1][F16 ? NT : 1];      // F16: cross-term sums (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                acc[i][j][e] = 0.f;
+                if (F16) acx[F16 ? i : 0][F16 ? j : 0][e] = 0.f;
+            }
 
     // fragment read offsets (floats): row*32 + 4*((2q+lh) ^ swz(row)), swz(row) = (l31>>1)&7 for every 32-row fragment
     const int fswz = (l31 >> 1) & 7;
@@ -561,27 +592,62 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
 
         const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
         const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
+        if (F16) {
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 af[MT], bf[NT];
+            for (int kk = 0; kk < 2; ++kk) {       // chunk 2kk+lh = hi halves of k 16kk+8lh.., chunk 4+2kk+lh = their lo' halves
+                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + foff[q]);
+                for (int i = 0; i < MT; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + foff[kk]);
+                    al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + foff[2 + kk]);
+                }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + foff[q]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int j = 0; j < NT; ++j) {
+                    bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + foff[kk]);
+                    bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + foff[2 + kk]);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        f32x16& cx = acx[F16 ? i : 0][F16 ? j : 0];
+                        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cx, 0, 0, 0);
+                        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cx, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BK + foff[q]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BK + foff[q]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA of the next tile has landed
         __syncthreads();   // everyone is done with `cur`
     }
 
-    if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
-    else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+    if (F16) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[F16 ? i : 0][F16 ? j : 0][e], 1.0f / LO_SCALE));
+    }
+    if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, F16>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+    else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, F16>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 
@@ -599,9 +665,6 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const ConvArgs a, con
 // format.  Range: |operand| must stay below 65504 (fp16 max) -- checked: a violation makes an accumulator non-finite, the
 // epilogue raises ctx->d_conv_flag and the caller re-runs in fp32; the fp32 kernel has no such limit.
 // ------------------------------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr float LO_SCALE = 2048.0f;      // lo' = (x - hi) * 2^11
 
 template <bool SCALED>
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f16x8& hi, f16x8& lo, float in_scale) {
@@ -842,6 +905,16 @@ void launch_glds(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, un
     }
 }
 
+template <int BN>
+void launch_f16x3s(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    constexpr int NT_ = (BN == 256) ? 512 : 256;
+    switch (epi) {
+        case 1: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 1, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 2, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 0, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+    }
+}
+
 void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (epi == 1) hipLaunchKernelGGL((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     else hipLaunchKernelGGL((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
@@ -943,7 +1016,7 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
 }
 
 int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-                  const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift) {
+                  const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift, int fmt) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -1004,6 +1077,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     AMP_REQUIRE(!a.grouped || glds, "amp_conv2d_grouped_nhwc: operands must stay below 2 GiB");
     const bool stem = a.Cin == 4 && a.KW == 8 && a.Cout <= 64 && small;   // the padded 7x7 stem
     a.range_flag = ctx->d_conv_flag;
+    const bool x_is_split = (fmt & 1) != 0;
+    a.y_split = (fmt & 2) ? 1 : 0;
+    AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
+    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && w_split && a.Cin % 32 == 0 && !a.grouped && in_shift == 0),
+                "conv: a split-format input needs AMP_CONV_F16X3 with pre-split weights");
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
     a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
     if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && (glds || stem)) {
@@ -1021,7 +1099,18 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         }
         a.w = w_split;
         const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
-        if (stem) {
+        if (x_is_split) {      // both operands by LDS-DMA
+            if (g_f16x3_bn256 && a.Cout % 256 == 0 && ntm * (a.Cout / 256) >= 512) {
+                a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
+                launch_f16x3s<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+            } else if (a.Cout > 64 && nblk128 >= 512) {
+                a.ntn = amp::cdiv(a.Cout, 128); a.nblk = ntm * a.ntn;
+                launch_f16x3s<128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+            } else {
+                a.ntn = amp::cdiv(a.Cout, 64); a.nblk = ntm * a.ntn;
+                launch_f16x3s<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+            }
+        } else if (stem) {
             a.ntn = 1;
             a.nblk = ntm;
             launch_f16x3_stem(a, epi == 2 ? 0 : epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -164,7 +164,7 @@ std::vector<float> oihw_to_ohwi(const float* w, int O, int I, int KH, int KW, in
 }
 
 int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int W, int stride, int pad, bool relu,
-                int res_mode, const float* res, int out_mode, float* y) {
+                int res_mode, const float* res, int out_mode, float* y, int fmt = 0) {
     amp_conv_desc d;
     d.B = B; d.H = H; d.W = W; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw;
     d.stride = stride; d.pad = pad; d.relu = relu ? 1 : 0; d.res_mode = res_mode; d.out_mode = out_mode;
@@ -172,7 +172,19 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
     const bool eligible = cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8);   // dense and grouped layers, the padded stem
     // (after an SGD step the split copies are stale until the next inference refreshes them: split per call then)
     return amp::conv_run(m->ctx, &d, cw.groups, x, cw.w, m->split_stale ? nullptr : cw.w_split, (eligible && !cw.w_split) ? 1 : 0, cw.scale, cw.shift, res,
-                         nullptr, y);
+                         nullptr, y, 0, fmt);
+}
+
+// Inference in AMP_CONV_F16X3: tensors that only feed convolutions travel in the split operand format (written by the producer's
+// epilogue / by RoIAlign, same bytes as fp32), so their consumers stage both operands by LDS-DMA and split nothing.
+bool split_chain(amp_model* m, std::initializer_list<const char*> keys) {
+    static const bool off = getenv("AMP_NO_SPLIT_CHAIN") != nullptr;
+    if (off || m->ws.dry || m->ctx->conv_mode != AMP_CONV_F16X3 || m->split_stale) return false;
+    for (const char* k : keys) {
+        auto it = m->conv.find(k);
+        if (it == m->conv.end() || !it->second.w_split) return false;
+    }
+    return true;
 }
 
 void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_list<long long> shape) {
@@ -432,16 +444,17 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(det_scores, float, (size_t)B * D);
     AMP_ALLOC(det_classes, int, (size_t)B * D);
     if (!dry) {
-        AMP_TRY(amp_roi_align(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2));
+        const bool bchain = split_chain(m, {"roi_heads.box_head.fc1", "roi_heads.box_head.fc2"});
+        AMP_TRY(amp::roi_align_run(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr, bchain ? 1 : 0));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1, bchain ? 3 : 0));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2, bchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
         AMP_TRY(amp_box_candidates(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
                                    H, W, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
         AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
         AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
         AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr));
-        tap(m, "box_pooled", pooled, 0, {R, 7, 7, 256});
+        tap(m, "box_pooled", pooled, bchain ? 5 : 0, {R, 7, 7, 256});
         tap(m, "box_pred", box_pred, 0, {R, ld_box});
         tap(m, "det_boxes", det_boxes, 0, {B, D, 4});
         tap(m, "det_scores", det_scores, 0, {B, D});
@@ -497,12 +510,15 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     if (N > 0) {
         AMP_TRY(amp_compact_dets(ctx, B, D, det_count, det_boxes, det_scores, det_classes, m_boxes, m_scores, m_classes, m_batch));
         // ---------------- mask head ----------------
-        AMP_TRY(amp_roi_align(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
+        const bool mchain = split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2", "roi_heads.mask_head.mask_fcn3",
+                                            "roi_heads.mask_head.mask_fcn4", "roi_heads.mask_head.deconv"});
+        const int io = mchain ? 3 : 0;      // split in, split out
+        AMP_TRY(amp::roi_align_run(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr, mchain ? 1 : 0));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, mchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
         AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
         AMP_TRY(amp_paste_rle(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, c.mask_threshold, o_boxes,

@@ -24,6 +24,7 @@ struct RoiArgs {
     float* out;             // [R,P,P,C]
     int* level_out;         // [R] (may be null)
     int R, P, C;
+    int out_split;          // 1: write the AMP_CONV_F16X3 operand format (per 32 channels 64 B of f16 hi halves + 64 B of lo' halves)
 };
 
 __device__ __forceinline__ int assign_level(float x1, float y1, float x2, float y2) {
@@ -95,16 +96,41 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = __fdiv_rn(acc[e], count);
-            o4[c] = acc;
+            if (a.out_split) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)acc[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)((acc[e] - (float)h) * 2048.0f);
+                }
+                const int ch = 4 * c;
+                char* base = reinterpret_cast<char*>(o4) + (ch >> 5) * 128 + (ch & 31) * 2;
+                *reinterpret_cast<f16x4*>(base) = hi;
+                *reinterpret_cast<f16x4*>(base + 64) = lo;
+            } else {
+                o4[c] = acc;
+            }
         }
     }
 }
 
 }  // namespace
 
+namespace amp {
+int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
+                  float* out, int* level_out, int out_split);
+}
 extern "C" int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx,
                              const int* roi_count, int R, int P, float* out, int* level_out) {
+    return amp::roi_align_run(ctx, f, rois, batch_idx, roi_count, R, P, out, level_out, 0);
+}
+
+int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
+                       float* out, int* level_out, int out_split) {
     AMP_REQUIRE(ctx && f && rois && out, "amp_roi_align: null argument");
+    AMP_REQUIRE(!out_split || f->C % 32 == 0, "amp_roi_align: split output needs C %% 32 == 0");
     AMP_REQUIRE(R >= 0 && P > 0 && f->C % 4 == 0, "amp_roi_align: bad shape");
     if (R == 0) return AMP_OK;
     RoiArgs a;
@@ -116,7 +142,7 @@ extern "C" int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* 
         a.scale[l] = 1.0f / (float)f->stride[l];
     }
     a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
-    a.R = R; a.P = P; a.C = f->C;
+    a.R = R; a.P = P; a.C = f->C; a.out_split = out_split;
     const long long nbins = (long long)R * P * P;
     long long g = (nbins + 3) / 4;
     if (g > 65536) g = 65536;

@@ -185,6 +185,12 @@ class MaskRCNN:
         shape = (C.c_longlong * 5)()
         check(lib().amp_model_get_tap(self._h, name.encode(), C.byref(ptr), C.byref(dt), C.byref(nd), shape), "amp_model_get_tap")
         shp = tuple(int(shape[i]) for i in range(nd.value))
+        if dt.value == 5:    # split operand format of AMP_CONV_F16X3: per 32 channels 32 f16 hi halves, then 32 f16 halves of lo * 2^11
+            raw = np.empty(shp[:-1] + (shp[-1] // 32, 2, 32), dtype=np.float16)
+            if raw.size:
+                check(lib().amp_memcpy_d2h(self.ctx.handle, raw.ctypes.data_as(C.c_void_p), ptr, raw.nbytes), "amp_memcpy_d2h")
+            r = raw.astype(np.float64)
+            return (r[..., 0, :] + r[..., 1, :] / 2048.0).reshape(shp).astype(np.float32)
         a = np.empty(shp, dtype=_TAP_DTYPES[dt.value])
         if a.size:
             check(lib().amp_memcpy_d2h(self.ctx.handle, a.ctypes.data_as(C.c_void_p), ptr, a.nbytes), "amp_memcpy_d2h")
