@@ -10,10 +10,16 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    m = re.search(r"(conv_\w+_kernel)<(\d+),?\s*(true|false)?,?\s*(\d+)?", name)
+    m = re.search(r"(conv_\w+_kernel)<([^>]*)>", name)
     if m:
-        base = f"{m.group(1)}<{m.group(2)}>"
-        return base + ("[stem]" if m.group(3) == "true" else "")
+        args = [t.strip() for t in m.group(2).split(",")]
+        if m.group(1) == "conv_glds_kernel":      # <BN, STEM, EPI, F16>
+            tag = ("[stem]" if len(args) > 1 and args[1] == "true" else "") + ("[f16x3, both operands pre-split]" if len(args) > 3 and args[3] == "true" else "")
+        elif m.group(1) == "conv_f16x3_kernel":   # <BN, EPI, STEM, SCALED>
+            tag = ("[stem]" if len(args) > 2 and args[2] == "true" else "") + ("[scaled input]" if len(args) > 3 and args[3] == "true" else "")
+        else:
+            tag = ""
+        return f"{m.group(1)}<{args[0]}>{tag}"
     m = re.search(r"::(\w+_kernel)", name)
     return m.group(1) if m else name.split("(")[0][-40:]
 
