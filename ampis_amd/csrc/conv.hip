@@ -1099,8 +1099,12 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         }
         a.w = w_split;
         const int nblk128 = ntm * amp::cdiv(a.Cout, 128);
+        // 256-wide tiles (8 waves, one workgroup per CU) when they fill the chip twice -- or once, if the K loop is long enough to
+        // amortise a single round (fc1: M = 8000, K = 12544: 64-wide tiles re-read the 400 MB activation matrix from HBM)
+        const int nblk256 = (a.Cout % 256 == 0) ? ntm * (a.Cout / 256) : 0;
+        const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= 64));
         if (x_is_split) {      // both operands by LDS-DMA
-            if (g_f16x3_bn256 && a.Cout % 256 == 0 && ntm * (a.Cout / 256) >= 512) {
+            if (wide256) {
                 a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
                 launch_f16x3s<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
             } else if (a.Cout > 64 && nblk128 >= 512) {
@@ -1118,7 +1122,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             a.ntn = a.Cout / 64;
             a.nblk = ntm * a.ntn;
             launch_f16x3<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-        } else if (g_f16x3_bn256 && a.Cout % 256 == 0 && ntm * (a.Cout / 256) >= 512) {
+        } else if (wide256) {
             a.ntn = a.Cout / 256;
             a.nblk = ntm * a.ntn;
             launch_f16x3<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
