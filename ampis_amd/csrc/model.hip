@@ -106,6 +106,9 @@ struct amp_model {
     std::vector<int> img_hw;            // optional per-image valid sizes for the next batches
 };
 
+static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
+extern "C" void amp_debug_set_split_chain(int on) { g_split_chain = on; }
+
 namespace {
 
 float* palloc(amp_model* m, size_t n) {
@@ -178,7 +181,8 @@ int launch_conv(amp_model* m, const ConvW& cw, const float* x, int B, int H, int
 // Inference in AMP_CONV_F16X3: tensors that only feed convolutions travel in the split operand format (written by the producer's
 // epilogue / by RoIAlign, same bytes as fp32), so their consumers stage both operands by LDS-DMA and split nothing.
 bool split_chain(amp_model* m, std::initializer_list<const char*> keys) {
-    static const bool off = getenv("AMP_NO_SPLIT_CHAIN") != nullptr;
+    static const bool env_off = getenv("AMP_NO_SPLIT_CHAIN") != nullptr;
+    const bool off = g_split_chain < 0 ? env_off : g_split_chain == 0;
     if (off || m->ws.dry || m->ctx->conv_mode != AMP_CONV_F16X3 || m->split_stale) return false;
     for (const char* k : keys) {
         auto it = m->conv.find(k);

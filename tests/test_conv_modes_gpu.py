@@ -129,3 +129,32 @@ def test_training_trajectories_agree_between_modes(gpu_ctx):
     assert d16[1] < 2e-4 and d16[2] < 5e-4 and d16[3] < 3e-3, d16
     assert d16[:5].max() <= 100 * max(dper[:5].max(), 1e-5), (d16, dper)
     assert abs(traj["f16x3"][-1].sum() - a[-1].sum()) < 0.05 * a[-1].sum()
+
+
+def test_split_format_chains_change_no_bit(gpu_ctx):
+    """In AMP_CONV_F16X3 inference the box / mask head tensors travel in the split operand format and their convs stage both
+    operands by LDS-DMA.  That is a change of data path, not of arithmetic: results must be bit-identical to splitting in the kernel."""
+    from ampis_amd import params as P
+    from ampis_amd._lib import lib
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    K, B, H, W = 2, 2, 224, 288
+    rng = np.random.default_rng(9)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=W, detections_per_image=80)
+    m.load_params(P.init_params(K, seed=3, style="spread"))
+    outs, pooled = [], []
+    try:
+        for on in (1, 0):
+            lib().amp_debug_set_split_chain(on)
+            outs.append(m.infer(imgs, rle="counts"))
+            pooled.append(m.tap("box_pooled"))
+    finally:
+        lib().amp_debug_set_split_chain(-1)
+    m.close()
+    # the pooled features read back from the split format (hi + lo' / 2^11) equal the fp32 ones to 2^-22
+    assert np.abs(pooled[0] - pooled[1]).max() <= 2.0 ** -21 * np.abs(pooled[1]).max()
+    for x, y in zip(*outs):
+        assert len(x["boxes"]) > 10
+        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"]) and np.array_equal(x["classes"], y["classes"])
+        assert all(np.array_equal(p["counts"], q["counts"]) for p, q in zip(x["masks"], y["masks"]))
