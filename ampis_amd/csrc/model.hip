@@ -269,8 +269,11 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             AMP_ALLOC(t1, float, (size_t)B * h1 * w1 * m->mid[s]);
             AMP_ALLOC(t2, float, (size_t)B * oh * ow * m->mid[s]);
             if (!dry) {
-                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2));
+                // t1 feeds only the 3x3: in AMP_CONV_F16X3 inference it travels in the split operand format (see split_chain)
+                const bool tchain = !m->saving && CONV((p + ".conv2").c_str()).groups == 1 && split_chain(m, {(p + ".conv2").c_str()}) &&
+                                    CONV((p + ".conv1").c_str()).w_split != nullptr;
+                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1, tchain ? 2 : 0));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2, tchain ? 1 : 0));
                 AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out));
             }
             (void)mark;
@@ -301,8 +304,11 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         AMP_ALLOC(lat, float, (size_t)B * res_h[s] * res_w[s] * 256);
         AMP_ALLOC(outp, float, (size_t)B * res_h[s] * res_w[s] * 256);
         if (!dry) {
-            AMP_TRY(launch_conv(m, CONV(ln.c_str()), res_out[s], B, res_h[s], res_w[s], 1, 0, false, prev_lat ? 2 : 0, prev_lat, 0, lat));
-            AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp));
+            // the finest lateral sum (l = 2) is read by its output conv only (the coarser ones are also the top-down residual of
+            // the next level and stay fp32): split operand format in AMP_CONV_F16X3 inference
+            const bool lchain = l == 2 && !m->saving && split_chain(m, {ln.c_str(), on.c_str()});
+            AMP_TRY(launch_conv(m, CONV(ln.c_str()), res_out[s], B, res_h[s], res_w[s], 1, 0, false, prev_lat ? 2 : 0, prev_lat, 0, lat, lchain ? 2 : 0));
+            AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp, lchain ? 1 : 0));
         }
         prev_lat = lat;
         m->lat[s] = lat;
