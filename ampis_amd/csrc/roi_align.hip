@@ -24,7 +24,6 @@ struct RoiArgs {
     float* out;             // [R,P,P,C]
     int* level_out;         // [R] (may be null)
     int R, P, C;
-    int bins_per_block;
     int out_split;          // 1: write the AMP_CONV_F16X3 operand format (per 32 channels 64 B of f16 hi halves + 64 B of lo' halves)
 };
 
@@ -42,12 +41,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
     const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
     const long long nbins = (long long)nvalid * a.P * a.P;
     const int C4 = a.C >> 2;
-    // A workgroup owns a run of `a.bins_per_block` consecutive bins (= one RoI at P = 7, a quarter RoI at P = 14): neighbouring
-    // bins share a row / column of taps, and with 4 bins per workgroup the 49 bins of a RoI were spread over all 8 XCDs, each
-    // pulling the shared pixels into its own L2 (PMC: 3.5 GB fetched per launch for 0.54 GB of features).
-    const long long bin_begin = (long long)blockIdx.x * a.bins_per_block;
-    const long long bin_end = bin_begin + a.bins_per_block < nbins ? bin_begin + a.bins_per_block : nbins;
-    for (long long bin = bin_begin + wave; bin < bin_end; bin += 4) {
+    for (long long bin = (long long)blockIdx.x * 4 + wave; bin < nbins; bin += (long long)gridDim.x * 4) {
         const int pw = (int)(bin % a.P);
         const int ph = (int)((bin / a.P) % a.P);
         const int r = (int)(bin / (a.P * a.P));
@@ -150,9 +144,8 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
     a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
     a.R = R; a.P = P; a.C = f->C; a.out_split = out_split;
     const long long nbins = (long long)R * P * P;
-    a.bins_per_block = 49;
-    const long long g = (nbins + a.bins_per_block - 1) / a.bins_per_block;
-    AMP_REQUIRE(g < (1ll << 31), "amp_roi_align: too many RoIs");
+    long long g = (nbins + 3) / 4;
+    if (g > 65536) g = 65536;
     hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;

@@ -30,10 +30,7 @@ __device__ __forceinline__ int assign_level_b(float x1, float y1, float x2, floa
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiBwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long nbins = (long long)a.R * a.P * a.P;
-    // a workgroup owns 49 consecutive bins (one RoI at P = 7): their atomics hit the same few feature rows through one L2
-    const long long bin_begin = (long long)blockIdx.x * 49;
-    const long long bin_end = bin_begin + 49 < nbins ? bin_begin + 49 : nbins;
-    for (long long bin = bin_begin + wave; bin < bin_end; bin += 4) {
+    for (long long bin = (long long)blockIdx.x * 4 + wave; bin < nbins; bin += (long long)gridDim.x * 4) {
         const int pw = (int)(bin % a.P), ph = (int)((bin / a.P) % a.P), r = (int)(bin / (a.P * a.P));
         const float x1 = a.rois[4 * r], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
         const int lv = assign_level_b(x1, y1, x2, y2);
@@ -241,7 +238,7 @@ int amp_roi_align_bwd(amp_ctx* ctx, float* const dfeat[4], const int fh[4], cons
     for (int l = 0; l < 4; ++l) { a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l]; }
     a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.C = C;
     const long long nbins = (long long)R * P * P;
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((unsigned)((nbins + 48) / 49)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((unsigned)std::min<long long>((nbins + 3) / 4, 65536)), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }
