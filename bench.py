@@ -245,7 +245,7 @@ def main():
     if rank == 0:
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v6.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v7.json")))
             key = ("conv_f16x3_kernel<256>" if "conv_f16x3_kernel<256>" in pmc["kernels"] else "conv_f16x3_kernel<128>") if mode == "f16x3" \
                 else "conv_glds_kernel<128>"
             traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
@@ -275,7 +275,7 @@ def main():
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
                          "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v6.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v7.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
