@@ -160,8 +160,8 @@ def x101_leg(ctx, dev, rank, world, steps, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=4, help="timed training steps of the secondary `train` object (0 = skip)")
