@@ -182,3 +182,56 @@ int amp_memset(amp_ctx* ctx, void* dst, int value, size_t bytes) {
 }
 
 }  // extern "C"
+
+// ---- matrix-pipe ceiling as this chip sustains it (tools/mfma_peak.py): back-to-back MFMAs on registers, no memory ----
+namespace {
+typedef float pk_f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
+template <int KIND>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+    pk_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    const float a32 = 1.0f + threadIdx.x * 1e-3f, b32 = 1.0f - threadIdx.x * 1e-3f;
+    pk_f16x8 a16, b16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a16[e] = (_Float16)(1.0f + e * 0.01f); b16[e] = (_Float16)(1.0f - e * 0.01f); }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32, b32, acc[t], 0, 0, 0);
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, b16, acc[t], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[t][e];
+    if (s == 1.2345e-30f) out[0] = s;
+}
+}  // namespace
+
+extern "C" int amp_debug_mfma_peak(amp_ctx* ctx, int kind, int iters, int waves_per_simd, float* tflops_h) {
+    AMP_REQUIRE(ctx && tflops_h && iters > 0 && (kind == 0 || kind == 1) && waves_per_simd >= 1 && waves_per_simd <= 2, "amp_debug_mfma_peak: bad argument");
+    hipDeviceProp_t p;
+    AMP_HIP_CHECK(hipGetDeviceProperties(&p, ctx->device));
+    const int blocks = p.multiProcessorCount * waves_per_simd;
+    float* d = nullptr;
+    AMP_HIP_CHECK(hipMalloc(&d, 64));
+    for (int rep = 0; rep < 2; ++rep) {
+        AMP_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
+        if (kind == 0) hipLaunchKernelGGL((mfma_peak_kernel<0>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        else hipLaunchKernelGGL((mfma_peak_kernel<1>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        AMP_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
+        AMP_HIP_CHECK(hipEventSynchronize(ctx->ev1));
+    }
+    float ms = 0.f;
+    AMP_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    const double flop_per_mfma = (kind == 0) ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
+    *tflops_h = (float)((double)blocks * 4 * iters * 4 * flop_per_mfma / (ms * 1e-3) / 1e12);
+    (void)hipFree(d);
+    return AMP_OK;
+}
