@@ -54,3 +54,47 @@ def test_grouped_backbone_refuses_training(gpu_ctx):
     from ampis_amd.model import MaskRCNN
     with pytest.raises(_lib.AmpError):
         MaskRCNN(gpu_ctx, 2, max_batch=1, max_h=64, max_w=64, arch="X101", train=True, max_gt=16, max_poly_doubles=1024)
+
+
+def test_r101_inference_and_training_step(gpu_ctx):
+    """R101-FPN (blocks 3-4-23-3, dense 3x3, stride in the 1x1): inference against the oracle and one training step (losses vs oracle)."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O, train as T
+    from test_e2e_gpu import synth_image
+    K, B, H, W, D = 2, 2, 192, 256, 60
+    rng = np.random.default_rng(21)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    p = P.init_params(K, seed=6, style="spread", arch="R101")
+    for k in p:     # 33 residual blocks amplify rounding noise into different NMS decisions with the 16-block damping of "spread"
+        if ".conv3.norm.weight" in k:
+            p[k] = p[k] * np.float32(0.5)
+    cfg = O.Cfg(num_classes=K, detections_per_image=D, resnet_blocks=(3, 4, 23, 3))
+    ref = O.infer(imgs, O.to_torch_params(p), cfg)
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D, arch="R101", train=True,
+                 max_gt=B * 700, max_poly_doubles=B * 700 * 64)
+    m.load_params(p)
+    out = m.infer(imgs)
+    from test_e2e_gpu import _decode
+    total = good = 0
+    for o, r in zip(out, ref):
+        rb, rs, rc, rm = r["boxes"].numpy(), r["scores"].numpy(), r["classes"].numpy(), r["masks"].numpy()
+        assert abs(len(rb) - len(o["boxes"])) <= 1
+        for i in range(len(rb)):
+            d = np.abs(o["boxes"] - rb[i]).max(axis=1)
+            j = int(np.argmin(d))
+            assert d[j] < 1e-3 and o["classes"][j] == rc[i] and abs(o["scores"][j] - rs[i]) < 1e-4, (i, float(d[j]))
+            gm = _decode(o["masks"][j]["counts"], H, W)
+            flips, area = int((gm ^ rm[i]).sum()), int(rm[i].sum())
+            assert flips <= max(2, 3e-4 * area), (i, flips, area)      # threshold flips scale with the outline (33 blocks deep)
+            u = (gm | rm[i]).sum()
+            good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
+            total += 1
+    assert total > 60 and good >= 0.9 * total, (good, total)
+    # one training step runs and produces finite, sensible losses and gradients for a res4.22 weight
+    timgs, gts = synth.batch(B, H, W, first_index=40)
+    L = m.forward_losses(timgs, gts, seed=1, backward=True)
+    assert all(np.isfinite(v) and v > 0 for v in L.values()), L
+    g = m.get_tensor("backbone.bottom_up.res4.22.conv2.weight", grad=True)
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    m.close()
