@@ -107,6 +107,7 @@ def _declare(L):
         "amp_conv2d_grouped_nhwc": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, vp], i),
         "amp_conv_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
         "amp_conv2d_wgrad": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i], i),
+        "amp_conv2d_wgrad_scaled": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i, i, i], i),
         "amp_colsum": ([vp, vp, i, i, vp, vp, i], i),
         "amp_dgrad_weights": ([vp, vp, vp, i, i, i, i, vp], i),
         "amp_preprocess": ([vp, vp, i, i, i, i, i, C.POINTER(f), C.POINTER(f), vp, vp], i),

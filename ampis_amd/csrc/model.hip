@@ -774,7 +774,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         d.B = B_; d.H = H_; d.W = W_; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw; d.stride = stride; d.pad = pad;
         d.relu = 0; d.res_mode = 0; d.out_mode = 0;
         AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
-        return amp_conv2d_wgrad(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0);
+        // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
+        return amp_conv2d_wgrad_scaled(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0);
     };
     auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
         return amp_colsum(ctx, dy, (int)M_, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0);
@@ -787,7 +788,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
         d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
         // data gradient on the context's arithmetic; AMP_CONV_F16X3 splits dy * 2^16 (gradients of 1e-9..1e-4 would sit in the f16
-        // subnormals); weight gradients stay on the fp32 MFMA (wgrad.hip)
+        // subnormals)
         return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16);
     };
 
@@ -816,7 +817,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             amp_conv_desc d;
             d.B = N; d.H = 28; d.W = 28; d.Cin = 256; d.Cout = 256; d.KH = 2; d.KW = 2; d.stride = 2; d.pad = 0; d.relu = 0; d.res_mode = 0; d.out_mode = 0;
             AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
-            AMP_TRY(amp_conv2d_wgrad(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0));
+            AMP_TRY(amp_conv2d_wgrad_scaled(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0, 0, 16));   // here the gradient is the 'x' operand
             AMP_TRY(amp_deconv_grad_transpose(ctx, dwd_t, GW(cd), 256, 4, 256, 0));
             AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
             for (int q = 0; q < 4; ++q) AMP_HIP_CHECK(hipMemcpyAsync(GB(cd) + q * 256, dbd_t, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));

@@ -172,6 +172,160 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs a) {
         }
 }
 
+// wgrad_f16x3_kernel (conv mode AMP_CONV_F16X3): the same GEMM on the f16 matrix pipe with the 3-MFMA operand split of
+// conv_f16x3_kernel (conv.hip): x = hi + lo'*2^-11, dW ~= sum hi*hi + (hi*lo' + lo'*hi) * 2^-11, fp32 accumulation.
+// v_mfma_f32_32x32x16_f16 wants 8 CONSECUTIVE reduction indices (pixels) per lane, but in memory the pixel is the slow index of
+// both operands.  The transposition happens in the register stage that has to exist anyway for the split: wave w of a step owns
+// pixels 8w..8w+7, a lane two adjacent columns; it loads its 8 x 2 block of each operand (8 coalesced 512-B row loads), splits it
+// and writes per column the 8 hi halves and the 8 lo' halves as two 16-byte LDS stores into a column-major tile
+// [128 columns][32 pixels] (144-byte column pitch: 64 B hi | 64 B lo' | pad; the pitch makes the ds_read_b128 fragment reads
+// conflict-free).  X rows come from the same [tap][pixel] offset table as the fp32 kernel, read through the scalar unit (a wave's
+// 8 rows are wave-uniform).  scale_p / scale_q (powers of two) lift a small operand (loss gradients) out of the f16 subnormals
+// before the split; out_scale undoes it.  |operand * scale| must stay below 65504: a violation makes an accumulator non-finite,
+// which raises *range_flag (the caller redoes the step on the fp32 MFMA).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr float LO_SCALE = 2048.0f;
+constexpr int WPITCH = 144;                 // bytes per tile column
+constexpr int WOP = 128 * WPITCH;           // bytes per operand tile
+
+template <int SC>   // 0: no operand scaling, 1: dY * scale, 2: X * scale
+__global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, const float scale, const float out_scale, int* range_flag) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * WOP];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int bid = amp::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = bid % a.ntc; bid /= a.ntc;
+    const int tile_n = bid % a.ntn; bid /= a.ntn;
+    const int split = bid;
+    const int n0 = tile_n * TN;
+    const int kp0 = tile_c * TC;
+    const int tap = kp0 / a.Cin;
+    const int c0 = kp0 - tap * a.Cin;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BKW - 1) / BKW : 0;
+
+    const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+
+    const unsigned int p_voff = (n0 + 2 * lane < a.N) ? (unsigned int)((n0 + 2 * lane) * 4) : OOB;   // N even: a pair is all-in or all-out
+    const unsigned int q_lane = (unsigned int)((c0 + 2 * lane) * 4);
+    const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * wave;   // wave-uniform: scalar loads
+
+    unsigned int qt[8];                 // X-row byte offsets of the step fetched next
+    u32x2 rp[8], rq[8];                 // fetched, not yet split
+    auto load_tab = [&](int step) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) qt[r] = tab[step * BKW + r];
+    };
+    auto fetch = [&](int step) {
+        const int row0 = m_begin + step * BKW + 8 * wave;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            rp[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);   // past the tensor: zero fill
+            rq[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (int)(qt[r] + q_lane), 0, 0);             // 0x80000000 + lane part: zero fill
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned char* P = lds + buf * (2 * WOP) + (2 * lane) * WPITCH + wave * 16;
+        unsigned char* Q = P + WOP;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f16x8 ph, pl, qh, ql;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned int pu = rp[r][q], qu = rq[r][q];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                float x = __builtin_bit_cast(float, pu);
+                if (SC == 1) x *= scale;
+                _Float16 h = (_Float16)x;
+                ph[r] = h;
+                pl[r] = (_Float16)((x - (float)h) * LO_SCALE);
+                float y = __builtin_bit_cast(float, qu);
+                if (SC == 2) y *= scale;
+                h = (_Float16)y;
+                qh[r] = h;
+                ql[r] = (_Float16)((y - (float)h) * LO_SCALE);
+            }
+            *reinterpret_cast<f16x8*>(P + q * WPITCH) = ph;
+            *reinterpret_cast<f16x8*>(P + q * WPITCH + 64) = pl;
+            *reinterpret_cast<f16x8*>(Q + q * WPITCH) = qh;
+            *reinterpret_cast<f16x8*>(Q + q * WPITCH + 64) = ql;
+        }
+    };
+
+    f32x16 acc[2][2], acx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+
+    if (nsteps > 0) {
+        load_tab(0);
+        fetch(0);
+        if (nsteps > 1) load_tab(1);
+        commit(0);
+        __syncthreads();
+        if (nsteps > 1) {
+            fetch(1);
+            if (nsteps > 2) load_tab(2);
+        }
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            const unsigned char* P = lds + cur * (2 * WOP) + (wm * 64 + l31) * WPITCH + lh * 16;
+            const unsigned char* Q = lds + cur * (2 * WOP) + WOP + (wn * 64 + l31) * WPITCH + lh * 16;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(P + i * 32 * WPITCH + kk * 32);
+                    al[i] = *reinterpret_cast<const f16x8*>(P + i * 32 * WPITCH + kk * 32 + 64);
+                    bh[i] = *reinterpret_cast<const f16x8*>(Q + i * 32 * WPITCH + kk * 32);
+                    bl[i] = *reinterpret_cast<const f16x8*>(Q + i * 32 * WPITCH + kk * 32 + 64);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+                        acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (step + 1 < nsteps) commit(cur ^ 1);     // operands of step+1: loads issued a step ago
+            __syncthreads();                             // LDS[cur] is free, LDS[cur^1] complete
+            if (step + 2 < nsteps) {
+                fetch(step + 2);
+                if (step + 3 < nsteps) load_tab(step + 3);
+            }
+        }
+    }
+    float* out = a.partial + (size_t)split * a.N * a.Kp;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kp = kp0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = n0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float v = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                bad |= !(fabsf(v) <= 3.0e38f);
+                if (SC != 0) v *= out_scale;
+                if (n < a.N && kp < a.Kp) out[(size_t)n * a.Kp + kp] = v;
+            }
+        }
+    if (bad && range_flag) *range_flag = 1;
+}
+
 // rowtab[tap][m] = byte offset of the input pixel that output pixel m sees through tap (ky,kx), or 0x80000000 (outside the image, or
 // m >= M): the operand staging of wgrad_mfma_kernel reads it instead of redoing the index arithmetic every step.
 __global__ void wgrad_rowtab_kernel(const WgradArgs a, unsigned int* __restrict__ tab) {
@@ -299,7 +453,14 @@ size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d) {
 
 int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                      float* grad, int accumulate) {
+    return amp_conv2d_wgrad_scaled(ctx, d, x, dy, scale, scratch, grad, accumulate, 0, 0);
+}
+
+int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
+                            float* grad, int accumulate, int dy_shift, int x_shift) {
     AMP_REQUIRE(ctx && d && x && dy && scratch && grad, "amp_conv2d_wgrad: null argument");
+    AMP_REQUIRE(dy_shift >= 0 && dy_shift <= 24 && x_shift >= 0 && x_shift <= 24 && (dy_shift == 0 || x_shift == 0),
+                "amp_conv2d_wgrad: shifts must be in [0, 24] and at most one of them non-zero");
     AMP_REQUIRE(d->Cin % TC == 0, "amp_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, TC);
     AMP_REQUIRE(d->Cout % 4 == 0, "amp_conv2d_wgrad: Cout=%d must be a multiple of 4", d->Cout);
     WgradArgs a;
@@ -327,7 +488,16 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
     a.rowtab = rowtab;
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
-    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
+    if (ctx->conv_mode == AMP_CONV_F16X3) {
+        // shifts are exact powers of two; the fp32 kernel needs none
+        const int sh = dy_shift ? dy_shift : x_shift;
+        const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);
+        if (dy_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<1>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
+        else if (x_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
+        else hipLaunchKernelGGL(wgrad_f16x3_kernel<0>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
+    } else {
+        hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
+    }
     const size_t nk = (size_t)a.N * a.Kp;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, ctx->stream, scratch,
                        a.nsplit, nk, a.Kp, scale, grad, accumulate);

@@ -109,7 +109,7 @@ def train_leg(ctx, infer_model, dev, rank, world, steps, barrier):
     return {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
             "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
             "steps": steps, "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
-            "dtype": "f32 (forward + data-gradient convs: f16x3 split-operand MFMA; weight gradients: fp32 MFMA)"
+            "dtype": "f32 (forward, data-gradient and weight-gradient convs: f16x3 split-operand MFMA, fp32 accumulate)"
                      if ctx.conv_mode == ctx.CONV_F16X3 else "f32",
             "workload": "BASELINE configs[2] (N=1) / configs[3] (N=8): K=2, ~480 GT instances/image (polygons), 256 anchors + 512 RoIs "
                         "sampled per image, seeded random-init weights, images passed as host uint8 each step",

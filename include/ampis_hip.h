@@ -125,6 +125,11 @@ int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, con
 size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d);
 int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                      float* grad, int accumulate);
+/* same; in AMP_CONV_F16X3 mode dy (or x) is multiplied by 2^dy_shift (2^x_shift) before the f16 split and the result by the inverse
+ * (exact): loss gradients of 1e-9..1e-4 need it to keep fp32-equivalent accuracy. At most one shift non-zero; ignored in AMP_CONV_F32.
+ * |operand * 2^shift| >= 65504 raises amp_conv_range_flag(). amp_conv2d_wgrad == shifts 0. */
+int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
+                            float* grad, int accumulate, int dy_shift, int x_shift);
 /* out[n] (= or +=) sum_m dy[m][n]; N % 4 == 0; scratch >= ceil(M/512)*N floats */
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */

@@ -66,6 +66,67 @@ def test_out_of_range_operand_raises_the_flag(gpu_ctx):
     assert torch.isfinite(y).all() and not gpu_ctx.conv_range_flag()
 
 
+WGRAD_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dy magnitude, dy_shift
+    (2, 20, 24, 128, 128, 3, 1, 1, 1.0, 0),
+    (2, 16, 16, 256, 128, 1, 2, 0, 1.0, 0),
+    (3, 14, 14, 256, 256, 3, 1, 1, 1e-6, 16),     # loss-gradient magnitudes: need the shift
+    (1, 1, 300, 1024, 12, 1, 1, 0, 1e-4, 16),
+    (2, 37, 41, 256, 64, 3, 1, 1, 1e-8, 16),      # ragged pixel count, N tile half empty
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_f16x3_is_at_least_as_accurate_as_fp32_mfma(gpu_ctx, case):
+    from ampis_amd import ops
+    B, H, W, Cin, Cout, k, s, p, mag, shift = case
+    g = torch.Generator().manual_seed(Cin + 7 * k + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).clamp_(min=0)          # post-ReLU activations
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = torch.randn(B, Ho, Wo, Cout, generator=g) * mag
+    xt = x.double().permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(xt, (Cout, Cin, k, k), dy.double().permute(0, 3, 1, 2), stride=s, padding=p).permute(0, 2, 3, 1)
+    d = "cuda:0"
+    out = {}
+    for mode in ("f32", "f16x3"):
+        gpu_ctx.conv_mode = mode
+        try:
+            out[mode] = ops.conv2d_wgrad(gpu_ctx, x.to(d), dy.to(d), (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift)
+            torch.cuda.synchronize()
+            again = ops.conv2d_wgrad(gpu_ctx, x.to(d), dy.to(d), (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift)
+            torch.cuda.synchronize()
+            assert torch.equal(again, out[mode]), "weight gradients are bitwise reproducible in both modes"
+        finally:
+            gpu_ctx.conv_mode = "f16x3"
+        out[mode] = out[mode].cpu().double()
+    assert not gpu_ctx.conv_range_flag()
+    m = ref.abs().max().item()
+    e32, e16 = (out["f32"] - ref).abs().max().item() / m, (out["f16x3"] - ref).abs().max().item() / m
+    r32, r16 = (out["f32"] - ref).pow(2).mean().sqrt().item() / m, (out["f16x3"] - ref).pow(2).mean().sqrt().item() / m
+    assert e16 <= max(1.5 * e32, 3e-7), (e16, e32)
+    assert r16 <= max(1.25 * r32, 3e-8), (r16, r32)
+
+
+def test_wgrad_x_shift_and_range_flag(gpu_ctx):
+    """The deconv weight gradient has the loss gradient as its 'x' operand (x_shift); an operand that leaves fp16 after the
+    shift must raise the flag."""
+    from ampis_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Cin, Cout = 2, 28, 28, 256, 256
+    x = torch.randn(B, H, W, Cin, generator=g) * 1e-6
+    dy = torch.randn(B, 14, 14, Cout, generator=g).clamp_(min=0)
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, 2, 2), dy.double().permute(0, 3, 1, 2), stride=2).permute(0, 2, 3, 1)
+    d = "cuda:0"
+    gpu_ctx.conv_range_flag()
+    got = ops.conv2d_wgrad(gpu_ctx, x.to(d), dy.to(d), (Cout, 2, 2, Cin), stride=2, pad=0, x_shift=16).cpu().double()
+    assert not gpu_ctx.conv_range_flag()
+    assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    dy_big = torch.randn(B, 14, 14, Cout, generator=g) * 4.0
+    ops.conv2d_wgrad(gpu_ctx, x.to(d), dy_big.to(d), (Cout, 2, 2, Cin), stride=2, pad=0, dy_shift=16)
+    torch.cuda.synchronize()
+    assert gpu_ctx.conv_range_flag(), "dy * 2^16 beyond 65504 must be reported"
+
+
 def test_mode_switch_and_model_fallback(gpu_ctx):
     """A model whose activations leave the fp16 range must return exactly what the fp32-MFMA mode returns (the batch is re-run)."""
     from ampis_amd import params as P

@@ -21,6 +21,9 @@ SHAPES = [
 
 def main():
     ctx = ops.torch_context(0)
+    if os.environ.get("AMP_CONV_MODE"):
+        ctx.conv_mode = os.environ["AMP_CONV_MODE"]
+    print("conv mode:", ctx.conv_mode, flush=True)
     d = "cuda:0"
     only = os.environ.get("AMP_ONLY")
     tot = 0.0
