@@ -187,16 +187,24 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr float LO_SCALE = 2048.0f;
 constexpr int WPITCH = 144;                 // bytes per tile column
-constexpr int WOP = 128 * WPITCH;           // bytes per operand tile
+// A tile of C columns is two regions, even columns then odd columns, each C/2 columns of WPITCH bytes plus 128 B: a lane's two
+// columns go to the same slot of the two regions, so the 8 lanes of a ds_write_b128 group hit 8 consecutive slots (pitch 9 x 16 B:
+// all 32 banks once), and the 128-B skew puts the odd lanes of a ds_read_b128 group on the 32 banks its even lanes leave free.
+constexpr int wreg(int cols) { return cols / 2 * WPITCH + 128; }
+constexpr int WOP = 2 * wreg(128);          // bytes of a 128-column operand tile
 
-template <int SC>   // 0: no operand scaling, 1: dY * scale, 2: X * scale
+// (An 8-wave variant with a 256-channel dY tile -- 24 instead of 32 split values per lane and step -- ran at the same speed.)
+template <int SC>   // SC 0: no operand scaling, 1: dY * scale, 2: X * scale
 __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, const float scale, const float out_scale, int* range_flag) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * WOP];
+    constexpr int REG = wreg(128);
+    constexpr int STAGE = 2 * WOP;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;       // wave tile 64 (n) x 64 (c')
     const int l31 = lane & 31, lh = lane >> 5;
+    const int mg = wave;                           // staging: this wave's 8-pixel group
 
     int bid = amp::xcd_remap(blockIdx.x, gridDim.x);
     const int tile_c = bid % a.ntc; bid /= a.ntc;
@@ -213,48 +221,55 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
 
-    const unsigned int p_voff = (n0 + 2 * lane < a.N) ? (unsigned int)((n0 + 2 * lane) * 4) : OOB;   // N even: a pair is all-in or all-out
+    const int pcol = 2 * lane;                     // tile column pair of this lane
+    const unsigned int p_voff = (n0 + pcol < a.N) ? (unsigned int)((n0 + pcol) * 4) : OOB;   // N even: a pair is all-in or all-out
     const unsigned int q_lane = (unsigned int)((c0 + 2 * lane) * 4);
-    const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * wave;   // wave-uniform: scalar loads
+    const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * mg;   // wave-uniform: scalar loads
 
-    unsigned int qt[8];                 // X-row byte offsets of the step fetched next
-    u32x2 rp[8], rq[8];                 // fetched, not yet split
+    unsigned int qt[8];                // X-row byte offsets of the step fetched next
+    u32x2 rp[8], rq[8];                // fetched, not yet split
     auto load_tab = [&](int step) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) qt[r] = tab[step * BKW + r];
     };
     auto fetch = [&](int step) {
-        const int row0 = m_begin + step * BKW + 8 * wave;
+        const int row0 = m_begin + step * BKW + 8 * mg;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 8; ++r)
             rp[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);   // past the tensor: zero fill
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
             rq[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (int)(qt[r] + q_lane), 0, 0);             // 0x80000000 + lane part: zero fill
-        }
     };
     auto commit = [&](int buf) {
-        unsigned char* P = lds + buf * (2 * WOP) + (2 * lane) * WPITCH + wave * 16;
+        unsigned char* P = lds + buf * STAGE + lane * WPITCH + mg * 16;
         unsigned char* Q = P + WOP;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            f16x8 ph, pl, qh, ql;
+            f16x8 ph, pl;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const unsigned int pu = rp[r][q], qu = rq[r][q];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                const unsigned int pu = rp[r][q];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
                 float x = __builtin_bit_cast(float, pu);
                 if (SC == 1) x *= scale;
-                _Float16 h = (_Float16)x;
+                const _Float16 h = (_Float16)x;
                 ph[r] = h;
                 pl[r] = (_Float16)((x - (float)h) * LO_SCALE);
+            }
+            *reinterpret_cast<f16x8*>(P + q * REG) = ph;
+            *reinterpret_cast<f16x8*>(P + q * REG + 64) = pl;
+            f16x8 qh, ql;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned int qu = rq[r][q];
                 float y = __builtin_bit_cast(float, qu);
                 if (SC == 2) y *= scale;
-                h = (_Float16)y;
+                const _Float16 h = (_Float16)y;
                 qh[r] = h;
                 ql[r] = (_Float16)((y - (float)h) * LO_SCALE);
             }
-            *reinterpret_cast<f16x8*>(P + q * WPITCH) = ph;
-            *reinterpret_cast<f16x8*>(P + q * WPITCH + 64) = pl;
-            *reinterpret_cast<f16x8*>(Q + q * WPITCH) = qh;
-            *reinterpret_cast<f16x8*>(Q + q * WPITCH + 64) = ql;
+            *reinterpret_cast<f16x8*>(Q + q * REG) = qh;
+            *reinterpret_cast<f16x8*>(Q + q * REG + 64) = ql;
         }
     };
 
@@ -278,17 +293,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
         }
         for (int step = 0; step < nsteps; ++step) {
             const int cur = step & 1;
-            const unsigned char* P = lds + cur * (2 * WOP) + (wm * 64 + l31) * WPITCH + lh * 16;
-            const unsigned char* Q = lds + cur * (2 * WOP) + WOP + (wn * 64 + l31) * WPITCH + lh * 16;
+            const unsigned char* P = lds + cur * STAGE + (l31 & 1) * REG + (wm * 32 + (l31 >> 1)) * WPITCH + lh * 16;
+            const unsigned char* Q = lds + cur * STAGE + WOP + (l31 & 1) * REG + (wn * 32 + (l31 >> 1)) * WPITCH + lh * 16;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 f16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(P + i * 32 * WPITCH + kk * 32);
-                    al[i] = *reinterpret_cast<const f16x8*>(P + i * 32 * WPITCH + kk * 32 + 64);
-                    bh[i] = *reinterpret_cast<const f16x8*>(Q + i * 32 * WPITCH + kk * 32);
-                    bl[i] = *reinterpret_cast<const f16x8*>(Q + i * 32 * WPITCH + kk * 32 + 64);
+                    ah[i] = *reinterpret_cast<const f16x8*>(P + i * 16 * WPITCH + kk * 32);
+                    al[i] = *reinterpret_cast<const f16x8*>(P + i * 16 * WPITCH + kk * 32 + 64);
+                    bh[i] = *reinterpret_cast<const f16x8*>(Q + i * 16 * WPITCH + kk * 32);
+                    bl[i] = *reinterpret_cast<const f16x8*>(Q + i * 16 * WPITCH + kk * 32 + 64);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -299,7 +314,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
-            if (step + 1 < nsteps) commit(cur ^ 1);     // operands of step+1: loads issued a step ago
+            commit(cur ^ 1);     // operands of step+1 (loads issued a step ago).  Unconditional, so that the split arithmetic shares
+                                 // a basic block with the MFMAs and fills their issue gaps; after the last step it rewrites stale
+                                 // registers into the buffer nobody reads again
             __syncthreads();                             // LDS[cur] is free, LDS[cur^1] complete
             if (step + 2 < nsteps) {
                 fetch(step + 2);
@@ -324,6 +341,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
             }
         }
     if (bad && range_flag) *range_flag = 1;
+}
+
+void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag) {
+    const int sh = dy_shift ? dy_shift : x_shift;
+    const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);     // exact powers of two
+    if (dy_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<1>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else if (x_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else hipLaunchKernelGGL(wgrad_f16x3_kernel<0>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
 }
 
 // rowtab[tap][m] = byte offset of the input pixel that output pixel m sees through tap (ky,kx), or 0x80000000 (outside the image, or
@@ -489,12 +514,7 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
     if (ctx->conv_mode == AMP_CONV_F16X3) {
-        // shifts are exact powers of two; the fp32 kernel needs none
-        const int sh = dy_shift ? dy_shift : x_shift;
-        const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);
-        if (dy_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<1>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
-        else if (x_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
-        else hipLaunchKernelGGL(wgrad_f16x3_kernel<0>, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a, sc, osc, ctx->d_conv_flag);
+        launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag);   // the fp32 kernel needs no shift
     } else {
         hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
     }
