@@ -462,6 +462,24 @@ __global__ void dgrad_weight_kernel(const float* __restrict__ w, const float* __
 
 }  // namespace
 
+namespace {
+// Pixel slices (split-K): the grid runs in rounds of 512 workgroups (2 per CU x 256 CUs), and a round costs its slice's steps plus a
+// fixed prologue / epilogue (~12 steps: first loads, the 64 KiB partial tile).  Take the slice count with the cheapest
+// rounds x (steps + 12): e.g. 36 tiles x 14 slices = 504 workgroups in ONE round instead of 36 x 57 = 2052 in four and a 4-workgroup
+// fifth.  Fewer slices also mean fewer slabs for wgrad_reduce_kernel to add.
+int pick_nsplit(long long M, int tiles) {
+    const int smax = (int)std::max(1LL, std::min(256LL, M / 256));
+    long long best = -1;
+    int best_s = 1;
+    for (int s = 1; s <= smax; ++s) {
+        const long long steps = amp::cdiv((int)((M + s - 1) / s), BKW);
+        const long long cost = (long long)amp::cdiv(tiles * s, 512) * (steps + 12);
+        if (best < 0 || cost < best) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
+}  // namespace
+
 extern "C" {
 
 /* dW = conv-wgrad(dy, x). scratch: >= nsplit*N*Kp floats (see amp_conv_wgrad_scratch_floats). grad is [N][KH][KW][Cin]. */
@@ -471,7 +489,7 @@ size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d) {
     const long long M = (long long)d->B * Ho * Wo;
     const int Kp = d->KH * d->KW * d->Cin;
     const int tiles = amp::cdiv(d->Cout, TN) * amp::cdiv(Kp, TC);
-    int nsplit = (int)std::max(1LL, std::min((long long)amp::cdiv(2048, tiles), (M + 1023) / 1024));
+    const int nsplit = pick_nsplit(M, tiles);
     const long long Mpad = (M + BKW - 1) / BKW * BKW;
     return (size_t)nsplit * d->Cout * Kp + (size_t)d->KH * d->KW * Mpad;   // partial slabs + the row table (4-byte entries)
 }
@@ -500,7 +518,7 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
     a.ntn = amp::cdiv(a.N, TN);
     a.ntc = amp::cdiv(a.Kp, TC);
     const int tiles = a.ntn * a.ntc;
-    a.nsplit = (int)std::max(1LL, std::min((long long)amp::cdiv(2048, tiles), (M + 1023) / 1024));
+    a.nsplit = pick_nsplit(M, tiles);
     a.rows_per_split = amp::cdiv(amp::cdiv(a.M, a.nsplit), BKW) * BKW;
     const size_t dyb = (size_t)M * a.N * 4, xb = (size_t)a.B * a.H * a.W * a.Cin * 4;
     AMP_REQUIRE(dyb < (size_t)OOB && xb < (size_t)OOB, "amp_conv2d_wgrad: operand larger than 2 GiB (split the batch)");
