@@ -913,6 +913,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
 
     // ---- ResNet res5 .. res3 (reverse block order) ----
     float* dcur = nullptr;
+    bool dcur_masked = false;
     const int nblk = dry ? 0 : (int)m->blocks.size();
     // dry run: reserve the worst-case gradient buffers of every trainable block
     if (dry) {
@@ -935,9 +936,12 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         if (last_of_stage) {
             // gradient from the FPN lateral; the next stage's first block (if any) has already added its share into d_res
             dcur = d_res[ba.stage];
+            dcur_masked = false;
         }
         const size_t out_elems = (size_t)B * ba.oh * ba.ow * ba.cout;
-        AMP_TRY(amp_relu_mask(ctx, dcur, ba.out, out_elems));  // d(pre-activation) = d(out) * (out > 0)
+        // d(pre-activation) = d(out) * (out > 0); inside a stage the previous iteration's input-gradient conv has applied it already
+        if (!dcur_masked) AMP_TRY(amp_relu_mask(ctx, dcur, ba.out, out_elems));
+        dcur_masked = false;
         const ConvW& c3 = CONV((ba.key + ".conv3").c_str());
         const ConvW& c2 = CONV((ba.key + ".conv2").c_str());
         const ConvW& c1 = CONV((ba.key + ".conv1").c_str());
@@ -963,8 +967,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             }
         } else {
             AMP_ALLOC(d_in, float, out_elems);
-            AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, nullptr, d_in));   // + identity shortcut
+            // + identity shortcut, times the ReLU mask of the block below (its output IS this block's input)
+            const bool fuse = bi > 0 && m->blocks[bi - 1].out == ba.x_in;
+            AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in));
             dcur = d_in;
+            dcur_masked = fuse;
         }
     }
     if (!dry) m->grads_valid = true;
