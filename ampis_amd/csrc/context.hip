@@ -184,26 +184,44 @@ int amp_memset(amp_ctx* ctx, void* dst, int value, size_t bytes) {
 }  // extern "C"
 
 // ---- matrix-pipe ceiling as this chip sustains it (tools/mfma_peak.py): back-to-back MFMAs on registers, no memory ----
+// RANDOM = false: every lane multiplies the same two constants for ever (the multiplier inputs never toggle: the chip holds its
+// full clock).  RANDOM = true: per-lane pseudo-random operands, a different pair for each of the 4 accumulators, so consecutive MFMAs
+// see different inputs like a real GEMM's do -- the clock the chip holds under THAT load sets the practical ceiling.
 namespace {
 typedef float pk_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 pk_f16x8 __attribute__((ext_vector_type(8)));
-template <int KIND>
+__device__ __forceinline__ float pk_rand(unsigned int h) {
+    h *= 2654435761u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    return (float)(h & 0xffff) / 32768.0f - 1.0f;      // [-1, 1)
+}
+template <int KIND, bool RANDOM>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
     pk_f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    const float a32 = 1.0f + threadIdx.x * 1e-3f, b32 = 1.0f - threadIdx.x * 1e-3f;
-    pk_f16x8 a16, b16;
+    float a32[4], b32[4];
+    pk_f16x8 a16[4], b16[4];
+    const unsigned int id = blockIdx.x * 256 + threadIdx.x;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a16[e] = (_Float16)(1.0f + e * 0.01f); b16[e] = (_Float16)(1.0f - e * 0.01f); }
-    for (int i = 0; i < iters; ++i) {
+    for (int t = 0; t < 4; ++t) {
+        a32[t] = RANDOM ? pk_rand(id * 8 + t) : 1.0f + threadIdx.x * 1e-3f;
+        b32[t] = RANDOM ? pk_rand(id * 8 + 4 + t) : 1.0f - threadIdx.x * 1e-3f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32, b32, acc[t], 0, 0, 0);
-            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16, b16, acc[t], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+            a16[t][e] = (_Float16)(RANDOM ? pk_rand(id * 64 + t * 8 + e) : 1.0f + e * 0.01f);
+            b16[t][e] = (_Float16)(RANDOM ? pk_rand(id * 64 + 32 + t * 8 + e) : 1.0f - e * 0.01f);
         }
+    }
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)        // static register indices: the operand pairing rotates every round
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (KIND == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[t], b32[(t + u) & 3], acc[t], 0, 0, 0);
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a16[t], b16[(t + u) & 3], acc[t], 0, 0, 0);
+            }
     }
     float s = 0.f;
 #pragma unroll
@@ -214,8 +232,9 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
 }
 }  // namespace
 
+/* kind: 0 fp32 MFMA, 1 f16 MFMA, constant operands; 2 / 3: the same on pseudo-random operands */
 extern "C" int amp_debug_mfma_peak(amp_ctx* ctx, int kind, int iters, int waves_per_simd, float* tflops_h) {
-    AMP_REQUIRE(ctx && tflops_h && iters > 0 && (kind == 0 || kind == 1) && waves_per_simd >= 1 && waves_per_simd <= 2, "amp_debug_mfma_peak: bad argument");
+    AMP_REQUIRE(ctx && tflops_h && iters > 0 && kind >= 0 && kind <= 3 && waves_per_simd >= 1 && waves_per_simd <= 2, "amp_debug_mfma_peak: bad argument");
     hipDeviceProp_t p;
     AMP_HIP_CHECK(hipGetDeviceProperties(&p, ctx->device));
     const int blocks = p.multiProcessorCount * waves_per_simd;
@@ -223,14 +242,16 @@ extern "C" int amp_debug_mfma_peak(amp_ctx* ctx, int kind, int iters, int waves_
     AMP_HIP_CHECK(hipMalloc(&d, 64));
     for (int rep = 0; rep < 2; ++rep) {
         AMP_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));
-        if (kind == 0) hipLaunchKernelGGL((mfma_peak_kernel<0>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
-        else hipLaunchKernelGGL((mfma_peak_kernel<1>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        if (kind == 0) hipLaunchKernelGGL((mfma_peak_kernel<0, false>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        else if (kind == 1) hipLaunchKernelGGL((mfma_peak_kernel<1, false>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        else if (kind == 2) hipLaunchKernelGGL((mfma_peak_kernel<0, true>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
+        else hipLaunchKernelGGL((mfma_peak_kernel<1, true>), dim3(blocks), dim3(256), 0, ctx->stream, d, iters);
         AMP_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->stream));
         AMP_HIP_CHECK(hipEventSynchronize(ctx->ev1));
     }
     float ms = 0.f;
     AMP_HIP_CHECK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    const double flop_per_mfma = (kind == 0) ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
+    const double flop_per_mfma = (kind % 2 == 0) ? 2.0 * 32 * 32 * 2 : 2.0 * 32 * 32 * 16;
     *tflops_h = (float)((double)blocks * 4 * iters * 4 * flop_per_mfma / (ms * 1e-3) / 1e12);
     (void)hipFree(d);
     return AMP_OK;

@@ -29,6 +29,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 matrix pe
 # AMP_CONV_F16X3 (the default conv arithmetic, include/ampis_hip.h): fp32 in / fp32 out, every product a*b evaluated as three
 # exact-product f16 MFMAs with fp32 accumulation -> its ceiling in ALGORITHMIC flops (2*M*N*K) is a third of the f16 matrix peak.
 PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
+# What the f16 matrix pipe SUSTAINS on this chip when its operands toggle like a GEMM's (tools/mfma_peak.py, profiles/r01/mfma_peak.json:
+# register-only back-to-back v_mfma_f32_32x32x16_f16 on random operands 1655 TFLOP/s, on constant operands 2475; the fp32 MFMA holds
+# 155 either way).  Reported beside `peak`, never instead of it.
+SUSTAINED_F16_MFMA_RANDOM_TFLOPS = 1655.0
 
 
 def log(msg):
@@ -274,7 +278,12 @@ def main():
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
-                         "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
+                         "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
+                         **({"sustained_peak_random_operands": round(SUSTAINED_F16_MFMA_RANDOM_TFLOPS / 3.0, 1),
+                             "frac_of_sustained": round(ach / (SUSTAINED_F16_MFMA_RANDOM_TFLOPS / 3.0), 4),
+                             "sustained_is": "measured on this chip: MFMA-only loop on random f16 operands 1655 TFLOP/s (clock drops under "
+                                             "toggling inputs; 2475 on constants), / 3 (profiles/r01/mfma_peak.json)"} if mode == "f16x3" else {}),
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v7.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
