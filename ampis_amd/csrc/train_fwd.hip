@@ -56,7 +56,6 @@ __global__ __launch_bounds__(256) void anchor_match_kernel(const AnchorGeom g, c
                                                            const int* __restrict__ gt_off, float* match_val, int* match_idx,
                                                            unsigned int* gt_best /* [sum G] float bits, zeroed */) {
     __shared__ float sg[MAXG_TILE][5];
-    __shared__ float wmax[4];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
@@ -79,17 +78,15 @@ __global__ __launch_bounds__(256) void anchor_match_kernel(const AnchorGeom g, c
         for (int j = 0; j < tn; ++j) {
             const float v = av ? iou_gt_box(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area) : 0.f;
             if (v > best) { best = v; besti = t0 + j; }        // first maximum, like torch.max(dim=0)
-            // workgroup max of this GT's IoU over the 256 anchors -> one atomicMax per (workgroup, GT)
-            float m = v;
+            // this GT's best IoU over all anchors: wave maximum -> one atomicMax per (wave, GT), and only for the few GTs the wave's
+            // 64 neighbouring anchors touch at all (a max is order-independent: deterministic).  A workgroup-level reduction here
+            // cost two barriers per GT and 2/3 of the kernel.
+            if (__builtin_amdgcn_ballot_w64(v > 0.f)) {
+                float m = v;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const float mm = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-                if (mm > 0.f) atomicMax(&gt_best[g0 + t0 + j], __float_as_uint(mm));   // IoU >= 0: uint order == float order
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                if ((threadIdx.x & 63) == 0) atomicMax(&gt_best[g0 + t0 + j], __float_as_uint(m));   // IoU >= 0: uint order == float order
             }
-            __syncthreads();
         }
     }
     if (av) {
