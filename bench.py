@@ -249,7 +249,7 @@ def main():
     if rank == 0:
         traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v7.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v8.json")))
             key = ("conv_f16x3_kernel<256>" if "conv_f16x3_kernel<256>" in pmc["kernels"] else "conv_f16x3_kernel<128>") if mode == "f16x3" \
                 else "conv_glds_kernel<128>"
             traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
@@ -284,7 +284,7 @@ def main():
                              "sustained_is": "measured on this chip: MFMA-only loop on random f16 operands 1655 TFLOP/s (clock drops under "
                                              "toggling inputs; 2475 on constants), / 3 (profiles/r01/mfma_peak.json)"} if mode == "f16x3" else {}),
                          "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v7.json)",
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v8.json)",
                          "launches_per_step": prof["launches"][0] / args.steps,
                          "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
                          "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
