@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --train-steps 0 --x101-steps 0"
+BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --train-steps 0 --x101-steps 0 --no-two-pipelines"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats_bench.log 2>&1 || { echo "stats run failed"; tail -5 $OUT/stats_bench.log; exit 1; }
 grep '^{' $OUT/stats_bench.log > $OUT/bench_line_under_rocprof.json
 echo "stats done"
