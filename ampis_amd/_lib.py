@@ -116,13 +116,16 @@ def _declare(L):
         "amp_subsample2": ([vp, vp, i, i, i, i, vp], i),
         "amp_rpn_topk": ([vp, C.POINTER(RpnLevels), i, i, vp, i, vp, vp, vp], i),
         "amp_rpn_decode": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, i, vp, vp, vp], i),
+        "amp_rpn_decode_sized": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, vp, i, vp, vp, vp], i),
         "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_nms": ([vp, i, i, vp, vp, vp, f, i, vp, vp, vp], i),
         "amp_roi_align": ([vp, C.POINTER(FpnFeats), vp, vp, vp, i, i, vp, vp], i),
         "amp_box_candidates": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, i, vp, vp], i),
+        "amp_box_candidates_sized": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, vp, i, vp, vp], i),
         "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_mask_prob": ([vp, vp, vp, i, i, vp], i),
         "amp_paste_rle": ([vp, vp, vp, vp, i, vp, vp, i, i, i, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp], i),
+        "amp_paste_rle_sized": ([vp, vp, vp, vp, i, vp, vp, i, i, i, vp, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp], i),
         "amp_rle_to_string": ([vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)], i),
         "amp_rle_from_string": ([vp, C.c_size_t, vp, i, C.POINTER(i)], i),
         "amp_rle_encode": ([vp, i, i, vp, i, C.POINTER(i)], i),

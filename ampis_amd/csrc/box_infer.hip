@@ -12,6 +12,7 @@ struct CandArgs {
     const int* prop_count;    // [B]
     int B, Rcap, K, ld;
     float wx, wy, ww, wh, scale_clamp, score_thresh, img_h, img_w;
+    const int* img_hw;        // optional device [B][2]: per-image (h, w) to clip to
     float* dense_boxes;       // [B][Rcap*K][4] decoded + clipped boxes
     unsigned long long* keys; // [B][ccap] compacted candidate keys (zeroed by the caller)
     int* cand_count;          // [B] (zeroed by the caller)
@@ -44,8 +45,9 @@ __global__ void box_candidates_kernel(const CandArgs a) {
             float x1 = __fsub_rn(pcx, __fmul_rn(0.5f, pw)), y1 = __fsub_rn(pcy, __fmul_rn(0.5f, ph));
             float x2 = __fadd_rn(pcx, __fmul_rn(0.5f, pw)), y2 = __fadd_rn(pcy, __fmul_rn(0.5f, ph));
             all_finite = all_finite && isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
-            x1 = fminf(fmaxf(x1, 0.f), a.img_w); x2 = fminf(fmaxf(x2, 0.f), a.img_w);
-            y1 = fminf(fmaxf(y1, 0.f), a.img_h); y2 = fminf(fmaxf(y2, 0.f), a.img_h);
+            const float ch = a.img_hw ? (float)a.img_hw[2 * b] : a.img_h, cw = a.img_hw ? (float)a.img_hw[2 * b + 1] : a.img_w;
+            x1 = fminf(fmaxf(x1, 0.f), cw); x2 = fminf(fmaxf(x2, 0.f), cw);
+            y1 = fminf(fmaxf(y1, 0.f), ch); y2 = fminf(fmaxf(y2, 0.f), ch);
             ob[4 * k + 0] = x1; ob[4 * k + 1] = y1; ob[4 * k + 2] = x2; ob[4 * k + 3] = y2;
         }
         if (!all_finite) continue;
@@ -120,6 +122,13 @@ int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const flo
 int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
                        int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,
                        float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow) {
+    return amp_box_candidates_sized(ctx, pred, ld, proposals, prop_count, B, Rcap, K, reg_weights, score_thresh, img_h, img_w, nullptr,
+                                    dense_boxes, keys, ccap, cand_count, overflow);
+}
+
+int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
+                             int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w, const int* img_hw,
+                             float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow) {
     AMP_REQUIRE(ctx && pred && proposals && prop_count && reg_weights && dense_boxes && keys && cand_count && overflow,
                 "amp_box_candidates: null argument");
     AMP_REQUIRE(B >= 1 && Rcap >= 1 && K >= 1 && K <= 255 && ld >= 5 * K + 1, "amp_box_candidates: bad shape");
@@ -129,7 +138,7 @@ int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* pro
     a.B = B; a.Rcap = Rcap; a.K = K; a.ld = ld;
     a.wx = reg_weights[0]; a.wy = reg_weights[1]; a.ww = reg_weights[2]; a.wh = reg_weights[3];
     a.scale_clamp = (float)log(1000.0 / 16.0);
-    a.score_thresh = score_thresh; a.img_h = (float)img_h; a.img_w = (float)img_w;
+    a.score_thresh = score_thresh; a.img_h = (float)img_h; a.img_w = (float)img_w; a.img_hw = img_hw;
     a.dense_boxes = dense_boxes; a.keys = keys; a.cand_count = cand_count; a.ccap = ccap; a.overflow = overflow;
     AMP_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)B * ccap * sizeof(unsigned long long), ctx->stream));
     AMP_HIP_CHECK(hipMemsetAsync(cand_count, 0, (size_t)B * sizeof(int), ctx->stream));

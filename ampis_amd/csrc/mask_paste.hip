@@ -32,6 +32,7 @@ struct PasteArgs {
     const int* out_h;         // [B] output (original image) height / width
     const int* out_w;
     int N, in_h, in_w;
+    const int* in_hw;     // optional device [B][2]: per-image network-input (h, w) instead of in_h / in_w
     float threshold;
     float* out_boxes;         // [N][4] rescaled + clipped
     int* valid;               // [N] 1 when the rescaled box is non-empty
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(PT) void paste_rle_kernel(const PasteArgs a) {
     const int tid = threadIdx.x;
     const int b = a.det_batch[n];
     const int H = a.out_h[b], W = a.out_w[b];
-    const float sx = (float)((double)W / (double)a.in_w), sy = (float)((double)H / (double)a.in_h);
+    const int in_h = a.in_hw ? a.in_hw[2 * b] : a.in_h, in_w = a.in_hw ? a.in_hw[2 * b + 1] : a.in_w;
+    const float sx = (float)((double)W / (double)in_w), sy = (float)((double)H / (double)in_h);
     const float* db = a.det_boxes + (size_t)n * 4;
     float x0 = __fmul_rn(db[0], sx), y0 = __fmul_rn(db[1], sy), x1 = __fmul_rn(db[2], sx), y1 = __fmul_rn(db[3], sy);
     x0 = fminf(fmaxf(x0, 0.f), (float)W); x1 = fminf(fmaxf(x1, 0.f), (float)W);
@@ -227,13 +229,21 @@ int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const
                   const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
                   int* rle_len, int* overflow) {
+    return amp_paste_rle_sized(ctx, prob, det_boxes, det_batch, N, out_h, out_w, max_out_hw, in_h, in_w, nullptr, threshold, out_boxes,
+                               valid, pool, pool_cap, pool_used, rle_off, rle_len, overflow);
+}
+
+int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
+                        const int* out_w, int max_out_hw, int in_h, int in_w, const int* in_hw, float threshold, float* out_boxes,
+                        int* valid, unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used,
+                        unsigned long long* rle_off, int* rle_len, int* overflow) {
     AMP_REQUIRE(ctx && prob && det_boxes && det_batch && out_h && out_w && out_boxes && valid && pool && pool_used && rle_off &&
                 rle_len && overflow, "amp_paste_rle: null argument");
     AMP_REQUIRE(max_out_hw >= 1 && max_out_hw <= 8192, "amp_paste_rle: max_out_hw=%d out of range [1,8192]", max_out_hw);
     if (N == 0) return AMP_OK;
     PasteArgs a;
     a.prob = prob; a.det_boxes = det_boxes; a.det_batch = det_batch; a.out_h = out_h; a.out_w = out_w;
-    a.N = N; a.in_h = in_h; a.in_w = in_w; a.threshold = threshold;
+    a.N = N; a.in_h = in_h; a.in_w = in_w; a.in_hw = in_hw; a.threshold = threshold;
     a.out_boxes = out_boxes; a.valid = valid; a.pool = pool; a.pool_cap = pool_cap; a.pool_used = pool_used;
     a.rle_off = rle_off; a.rle_len = rle_len; a.overflow = overflow;
     a.max_rows = max_out_hw + 2;

@@ -211,6 +211,7 @@ struct Trunk {
     amp_rpn_levels lv;
     amp_fpn_feats ff;
     int max_n;
+    const int* img_hw;    // device [B][2] per-image sizes (amp_model_set_image_sizes) or null: clip / rescale with these, not the frame
 };
 
 // Shared by inference and training: preprocess -> ResNet-50 -> FPN -> RPN head. With ws.dry nothing is launched.
@@ -235,6 +236,9 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         }
         AMP_TRY(amp_preprocess(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0));
+        T.img_hw = sized ? d_img_hw : nullptr;
+    } else {
+        T.img_hw = nullptr;
     }
     int h = Hp / 2, w = Wp / 2;
     AMP_ALLOC(stem, float, (size_t)B * h * w * 64);
@@ -396,7 +400,7 @@ int run_proposals(amp_model* m, const Trunk& T, int B, int H, int W, int k, int 
     AMP_ALLOC(prop_anchor, int, (size_t)B * Rcap);
     if (!dry) {
         AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
-        AMP_TRY(amp_rpn_decode(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, cap, cand_boxes, cand_keys, cand_anchor));
+        AMP_TRY(amp_rpn_decode_sized(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, T.img_hw, cap, cand_boxes, cand_keys, cand_anchor));
         AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr, cand_anchor, s_anchor));
         AMP_TRY(amp_nms(ctx, B, cap, s_boxes, s_cats, s_count, c.rpn_nms_thresh, Rcap, nms_mask, keep_idx, prop_count));
         AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl, s_anchor, prop_anchor));
@@ -459,8 +463,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1, bchain ? 3 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2, bchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
-        AMP_TRY(amp_box_candidates(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
-                                   H, W, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
+        AMP_TRY(amp_box_candidates_sized(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
+                                         H, W, T.img_hw, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
         AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
         AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
         AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr));
@@ -531,7 +535,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, mchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
         AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
-        AMP_TRY(amp_paste_rle(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, c.mask_threshold, o_boxes,
+        AMP_TRY(amp_paste_rle_sized(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, T.img_hw, c.mask_threshold, o_boxes,
                               o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1));
         tap(m, "mask_prob", mprob, 0, {N, 28, 28});
         tap(m, "mask_rois", m_boxes, 0, {N, 4});
@@ -1356,6 +1360,8 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
                 "amp_model_infer: batch %dx%dx%d exceeds the capacity the model was created with (%dx%dx%d)", B, H, W,
                 m->cfg.max_batch, m->cfg.max_h, m->cfg.max_w);
     std::vector<int> oh(B, H), ow(B, W);
+    if ((int)m->img_hw.size() == 2 * B)      // differently sized images in one frame: the default output size is each image's own
+        for (int b = 0; b < B; ++b) { oh[b] = m->img_hw[2 * b]; ow[b] = m->img_hw[2 * b + 1]; }
     if (out_h_h && out_w_h) { oh.assign(out_h_h, out_h_h + B); ow.assign(out_w_h, out_w_h + B); }
     AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
     AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, 4 * sizeof(int), m->ctx->stream));

@@ -65,6 +65,7 @@ struct DecodeArgs {
     const float* sel_logit;
     const int* sel_count;
     float img_h, img_w;
+    const int* img_hw;               // optional device [B][2]: per-image (h, w) to clip to instead of img_h / img_w
     float scale_clamp;
     int cap;                         // capacity per image of the outputs (>= nlevels*k)
     float* boxes;                    // [B][cap][4] clipped boxes
@@ -107,8 +108,9 @@ __global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
                 x2 = __fadd_rn(pcx, __fmul_rn(0.5f, pw));
                 y2 = __fadd_rn(pcy, __fmul_rn(0.5f, ph));
                 const bool finite = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2) && isfinite(logit);
-                x1 = fminf(fmaxf(x1, 0.f), a.img_w); x2 = fminf(fmaxf(x2, 0.f), a.img_w);
-                y1 = fminf(fmaxf(y1, 0.f), a.img_h); y2 = fminf(fmaxf(y2, 0.f), a.img_h);
+                const float ch = a.img_hw ? (float)a.img_hw[2 * b] : a.img_h, cw = a.img_hw ? (float)a.img_hw[2 * b + 1] : a.img_w;
+                x1 = fminf(fmaxf(x1, 0.f), cw); x2 = fminf(fmaxf(x2, 0.f), cw);
+                y1 = fminf(fmaxf(y1, 0.f), ch); y2 = fminf(fmaxf(y2, 0.f), ch);
                 const bool nonempty = (__fsub_rn(x2, x1) > 0.f) && (__fsub_rn(y2, y1) > 0.f);
                 if (finite && nonempty) {
                     key = amp::make_sortkey(f2ord(logit), pos, lvl);
@@ -189,6 +191,12 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
 
 int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
                    const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey, int* anchor_id) {
+    return amp_rpn_decode_sized(ctx, lv, B, k, sel_idx, sel_logit, sel_count, img_h, img_w, nullptr, cap, boxes, sortkey, anchor_id);
+}
+
+int amp_rpn_decode_sized(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
+                         const int* sel_count, int img_h, int img_w, const int* img_hw, int cap, float* boxes,
+                         unsigned long long* sortkey, int* anchor_id) {
     AMP_REQUIRE(ctx && lv && sel_idx && sel_logit && sel_count && boxes && sortkey, "amp_rpn_decode: null argument");
     AMP_REQUIRE(lv->nlevels >= 1 && lv->nlevels <= MAX_LEVELS && lv->A == 3, "amp_rpn_decode: need 1..5 levels, A == 3");
     AMP_REQUIRE(cap >= lv->nlevels * k, "amp_rpn_decode: cap=%d < nlevels*k", cap);
@@ -209,7 +217,7 @@ int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const i
     }
     a.nlevels = lv->nlevels; a.A = lv->A; a.ld = lv->ld; a.k = k;
     a.sel_idx = sel_idx; a.sel_logit = sel_logit; a.sel_count = sel_count;
-    a.img_h = (float)img_h; a.img_w = (float)img_w;
+    a.img_h = (float)img_h; a.img_w = (float)img_w; a.img_hw = img_hw;
     a.scale_clamp = (float)log(1000.0 / 16.0);
     a.cap = cap; a.boxes = boxes; a.sortkey = sortkey; a.anchor_id = anchor_id;
     a.lvl_off[0] = 0;

@@ -169,6 +169,11 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
 int amp_rpn_decode(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
                    const int* sel_count, int img_h, int img_w, int cap, float* boxes, unsigned long long* sortkey,
                    int* anchor_id /* [B,cap] global anchor index of each candidate, or NULL */);
+/* same with per-image sizes: img_hw = device int [B][2] (h, w) of each image inside the common frame (a batch of differently sized
+ * images, detectron2 ImageList): every image's proposals are clipped to ITS size (find_top_rpn_proposals); NULL = img_h / img_w. */
+int amp_rpn_decode_sized(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, const int* sel_idx, const float* sel_logit,
+                         const int* sel_count, int img_h, int img_w, const int* img_hw, int cap, float* boxes,
+                         unsigned long long* sortkey, int* anchor_id);
 /* per image: order `cap` (<= 16384) 64-bit sort words descending; gather boxes_in[b][pos] (box_stride entries per image);
  * outputs sorted boxes/scores/categories [B,cap], the number of valid entries [B], optionally the source positions. */
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
@@ -194,6 +199,10 @@ int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const
 int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
                        int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,
                        float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
+int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
+                             int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w,
+                             const int* img_hw /* device [B][2] or NULL, as in amp_rpn_decode_sized */,
+                             float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
 int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
                     const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes,
                     const int* payload_in /* [B,cap] or NULL */, int* payload_out /* [B,D] or NULL */);
@@ -207,6 +216,11 @@ int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const
                   const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
                   int* rle_len, int* overflow);
+/* same; in_hw = device int [B][2]: the network-input size of each image (detector_postprocess scales by output / image size) or NULL */
+int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
+                        const int* out_w, int max_out_hw, int in_h, int in_w, const int* in_hw, float threshold, float* out_boxes,
+                        int* valid, unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used,
+                        unsigned long long* rle_off, int* rle_len, int* overflow);
 
 /* Stage a18: training-mode label assignment, seeded sampling and losses (+ their gradients w.r.t. the network outputs) ---- */
 int amp_anchor_labels(amp_ctx* ctx, const amp_rpn_levels* lv, int B, const float* gt_boxes, const int* gt_off, int total_gt,

@@ -459,19 +459,27 @@ def detector_postprocess(boxes, scores, classes, mask_probs, image_size, out_h, 
 
 
 # ---------------------------------------------------------------------------------------------- end to end
-def infer(images_u8, params, cfg, out_sizes=None, stages=None):
-    """GeneralizedRCNN.inference on a batch of equally sized BGR uint8 images [B,H,W,3].
+def infer(images_u8, params, cfg, out_sizes=None, stages=None, image_sizes=None):
+    """GeneralizedRCNN.inference on a batch of BGR uint8 images [B,H,W,3].
     Returns per image dict(boxes [N,4] f32, scores [N] f32, classes [N] i64, masks [N,H,W] bool).
-    `stages`, if a dict, receives intermediate tensors for stage-wise parity tests."""
+    `stages`, if a dict, receives intermediate tensors for stage-wise parity tests.
+    image_sizes: per image (h, w) of the valid top-left part of the common frame (ImageList.from_tensors: the normalised image is
+    padded with 0; proposals and detections are clipped to, and results rescaled from, each image's OWN size); None = the frame."""
     B, H, W, _ = images_u8.shape
+    sizes = [(H, W)] * B if image_sizes is None else [tuple(int(v) for v in s) for s in image_sizes]
     with torch.no_grad():
         x = preprocess(images_u8, cfg)
+        if image_sizes is not None:
+            x = x.clone()
+            for b, (h_b, w_b) in enumerate(sizes):
+                x[b, :, h_b:, :] = 0.0
+                x[b, :, :, w_b:] = 0.0
         res = resnet50(x, params, cfg)
         feats = fpn(res, params)
         rpn_outs = rpn_head(feats, params)
         shapes = [(f.shape[2], f.shape[3]) for f in feats]
         cands = rpn_select_candidates(rpn_outs, shapes, cfg)
-        props = [rpn_proposals_from_candidates(c, (H, W), cfg) for c in cands]
+        props = [rpn_proposals_from_candidates(c, sizes[n], cfg) for n, c in enumerate(cands)]
         prop_boxes = [pb for pb, _ in props]
         pooled, _, _ = roi_pool(feats[:4], prop_boxes, 7)
         scores, deltas = box_head(pooled, params)
@@ -482,7 +490,7 @@ def infer(images_u8, params, cfg, out_sizes=None, stages=None):
         o = 0
         for n in range(B):
             r = len(prop_boxes[n])
-            dets.append(box_inference_single(scores[o:o + r], deltas[o:o + r], prop_boxes[n], (H, W), cfg))
+            dets.append(box_inference_single(scores[o:o + r], deltas[o:o + r], prop_boxes[n], sizes[n], cfg))
             o += r
         mpooled, _, _ = roi_pool(feats[:4], [d[0] for d in dets], 14)
         mprob = mask_head(mpooled, torch.cat([d[2] for d in dets]), params)
@@ -492,8 +500,8 @@ def infer(images_u8, params, cfg, out_sizes=None, stages=None):
         o = 0
         for n in range(B):
             nd = len(dets[n][0])
-            oh, ow = (H, W) if out_sizes is None else out_sizes[n]
-            b, s, c, m = detector_postprocess(dets[n][0], dets[n][1], dets[n][2], mprob[o:o + nd], (H, W), oh, ow, cfg)
+            oh, ow = sizes[n] if out_sizes is None else out_sizes[n]
+            b, s, c, m = detector_postprocess(dets[n][0], dets[n][1], dets[n][2], mprob[o:o + nd], sizes[n], oh, ow, cfg)
             o += nd
             results.append(dict(boxes=b, scores=s, classes=c, masks=m))
     return results

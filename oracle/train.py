@@ -248,12 +248,20 @@ class TrainCfg(M.Cfg):
             setattr(self, k, v)
 
 
-def forward_losses(images_u8, gt, params, cfg, stages=None):
+def forward_losses(images_u8, gt, params, cfg, stages=None, image_sizes=None):
     """GeneralizedRCNN.forward in training mode.  gt: per image dict(boxes f32 [G,4], classes i64 [G], polygons list[G] of
-    flat xy float64 arrays).  Returns dict of the 5 loss tensors (differentiable w.r.t. `params`)."""
+    flat xy float64 arrays).  Returns dict of the 5 loss tensors (differentiable w.r.t. `params`).
+    image_sizes: per image (h, w) of the valid top-left part of the common frame (a batch of differently sized images as
+    ImageList.from_tensors stacks it: the NORMALISED image is padded with 0, and find_top_rpn_proposals clips each image's proposals
+    to its own size); None = every image fills the frame."""
     B, H, W, _ = images_u8.shape
     K = cfg.num_classes
     x = M.preprocess(images_u8, cfg)
+    if image_sizes is not None:
+        x = x.clone()
+        for b, (h_b, w_b) in enumerate(image_sizes):
+            x[b, :, h_b:, :] = 0.0
+            x[b, :, :, w_b:] = 0.0
     res = M.resnet50(x, params)
     feats = M.fpn(res, params)
     rpn_outs = M.rpn_head(feats, params)
@@ -297,7 +305,7 @@ def forward_losses(images_u8, gt, params, cfg, stages=None):
             aid = torch.as_tensor(lvl_off[:-1])[lvl] + idx
             valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(lg)
             boxes, lg, lvl, aid = boxes[valid], lg[valid], lvl[valid], aid[valid]
-            boxes = M.clip_boxes(boxes, H, W)
+            boxes = M.clip_boxes(boxes, *((H, W) if image_sizes is None else image_sizes[len(props)]))
             keep = ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
             boxes, lg, lvl, aid = boxes[keep], lg[keep], lvl[keep], aid[keep]
             order = M.sort_desc_stable(lg)

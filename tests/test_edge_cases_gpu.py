@@ -1,0 +1,144 @@
+"""Edge cases of the inference path through the C ABI (amp_model_infer): images whose size is not a multiple of the FPN stride
+(size_divisibility padding), images without any detection (alone and beside an image that has some), an output size different
+from the network input (detector_postprocess rescale), and independence of an image's result from the batch it rides in."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BOX_TOL = 1e-3
+
+
+def _img(rng, h, w, blobs=10):
+    img = rng.normal(70, 10, (h, w))
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(blobs):
+        cy, cx, r = rng.uniform(0, h), rng.uniform(0, w), rng.uniform(6, 30)
+        d = (yy - cy) ** 2 + (xx - cx) ** 2
+        img = np.where(d < r * r, rng.normal(185, 12) - 35 * d / (r * r), img)
+    return np.repeat(np.clip(img, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
+
+
+def _decode(m, h, w):
+    from ampis_amd import rle
+    return rle.decode({"size": [h, w], "counts": m["counts"]}).astype(bool)
+
+
+def _match(out, ref, h, w, min_good=0.95):
+    rb, rs, rc, rm = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy(), ref["masks"].numpy()
+    assert abs(len(rb) - len(out["boxes"])) <= max(1, len(rb) // 50)
+    good = 0
+    for i in range(len(rb)):
+        d = np.abs(out["boxes"] - rb[i]).max(axis=1)
+        j = int(np.argmin(d))
+        if d[j] < BOX_TOL and out["classes"][j] == rc[i] and abs(out["scores"][j] - rs[i]) < 1e-4:
+            gm = _decode(out["masks"][j], h, w)
+            assert gm.shape == rm[i].shape
+            assert int((gm ^ rm[i]).sum()) <= max(2, int(rm[i].sum()) // 500)
+            good += 1
+    assert len(rb) > 5 and good >= min_good * len(rb), (good, len(rb))
+
+
+def test_size_not_a_multiple_of_32_and_rescaled_output(gpu_ctx):
+    """200 x 273 input (padded to 224 x 288 inside), results rescaled to a 300 x 410 output frame as detector_postprocess does."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O
+    K, H, W, D = 2, 200, 273, 40
+    oh, ow = 300, 410
+    rng = np.random.default_rng(11)
+    imgs = np.stack([_img(rng, H, W)])
+    p = P.init_params(K, seed=3, style="spread")
+    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D), out_sizes=[(oh, ow)])
+    model = MaskRCNN(gpu_ctx, K, max_batch=1, max_h=H, max_w=W, max_out_hw=max(oh, ow), detections_per_image=D)
+    model.load_params(p)
+    out = model.infer(imgs, out_sizes=[(oh, ow)])
+    assert out[0]["image_size"] == (oh, ow)
+    _match(out[0], ref[0], oh, ow)
+    model.close()
+
+
+def test_images_without_detections(gpu_ctx):
+    """No candidate above SCORE_THRESH_TEST: the mask branch is skipped for that image (for all of them: not launched at all);
+    the images that do have detections are unaffected.  A higher threshold keeps exactly the higher-scored detections (greedy NMS
+    decides about a box from the boxes above it only)."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    K, H, W, D = 2, 160, 192, 50
+    rng = np.random.default_rng(4)
+    imgs = np.stack([_img(rng, H, W), _img(rng, H, W, blobs=0), _img(rng, H, W, blobs=14)])
+    p = P.init_params(K, seed=3, style="spread")
+
+    def run(thresh, batch):
+        m = MaskRCNN(gpu_ctx, K, max_batch=len(batch), max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D, score_thresh=thresh)
+        m.load_params(p)
+        o = m.infer(batch)
+        m.close()
+        return o
+
+    base = run(0.05, imgs)
+    tops = sorted(float(o["scores"].max()) if len(o["scores"]) else 0.0 for o in base)
+    assert tops[-1] > tops[0]
+    thr = 0.5 * (tops[0] + tops[1]) if tops[1] > tops[0] else 0.5 * (tops[1] + tops[2])     # at least one image drops out entirely
+    cut = run(thr, imgs)
+    assert any(len(o["scores"]) == 0 for o in cut) and any(len(o["scores"]) > 0 for o in cut)
+    for o, b in zip(cut, base):
+        keep = b["scores"] > thr
+        if int(keep.sum()) < D and len(b["scores"]) < D:        # no cap in play: exactly the prefix above the threshold
+            assert len(o["scores"]) == int(keep.sum())
+            assert np.array_equal(o["boxes"], b["boxes"][keep]) and np.array_equal(o["classes"], b["classes"][keep])
+            assert [m["counts"] for m in o["masks"]] == [m["counts"] for m, k in zip(b["masks"], keep) if k]
+        assert len(o["masks"]) == len(o["scores"]) == len(o["boxes"])
+    none = run(1.5, imgs)                                         # nothing anywhere
+    assert all(len(o["scores"]) == 0 and o["boxes"].shape == (0, 4) and o["masks"] == [] for o in none)
+
+
+def test_result_does_not_depend_on_the_batch(gpu_ctx):
+    """An image gives bitwise the same boxes, scores and RLE bytes alone, first or last in a batch of three."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    K, H, W, D = 2, 160, 224, 30
+    rng = np.random.default_rng(9)
+    a, b, c = (_img(rng, H, W) for _ in range(3))
+    p = P.init_params(K, seed=3, style="spread")
+    m = MaskRCNN(gpu_ctx, K, max_batch=3, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D)
+    m.load_params(p)
+    alone = m.infer(np.stack([a]))[0]
+    first = m.infer(np.stack([a, b, c]))[0]
+    last = m.infer(np.stack([c, b, a]))[2]
+    m.close()
+    assert len(alone["scores"]) > 3
+    for o in (first, last):
+        assert np.array_equal(o["boxes"], alone["boxes"]) and np.array_equal(o["scores"], alone["scores"])
+        assert np.array_equal(o["classes"], alone["classes"])
+        assert [x["counts"] for x in o["masks"]] == [x["counts"] for x in alone["masks"]]
+
+
+def test_differently_sized_images_in_one_batch(gpu_ctx):
+    """detectron2's ImageList semantics for a batch of differently sized images (amp_model_set_image_sizes): the smaller image sits
+    top-left in the common frame, its padding is zero after normalisation whatever bytes are there, proposals and detections are
+    clipped to, and masks pasted into, the image's own size."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O
+    K, H, W, D = 2, 192, 256, 40
+    sizes = [(192, 256), (150, 201)]
+    rng = np.random.default_rng(21)
+    imgs = np.stack([_img(rng, H, W), _img(rng, H, W)])
+    imgs[1, 150:, :, :] = 250          # garbage in the padding
+    imgs[1, :, 201:, :] = 3
+    p = P.init_params(K, seed=3, style="spread")
+    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D), image_sizes=sizes)
+    model = MaskRCNN(gpu_ctx, K, max_batch=2, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D)
+    model.load_params(p)
+    model.set_image_sizes(sizes)
+    out = model.infer(imgs)
+    model.set_image_sizes(None)
+    full = model.infer(imgs)
+    model.close()
+    for b in range(2):
+        assert out[b]["image_size"] == sizes[b]
+        _match(out[b], ref[b], *sizes[b])
+        assert out[b]["boxes"][:, 2].max() <= sizes[b][1] and out[b]["boxes"][:, 3].max() <= sizes[b][0]
+    # without the sizes the second image is a different problem (its garbage padding is image content)
+    assert len(full[1]["boxes"]) != len(out[1]["boxes"]) or not np.allclose(full[1]["boxes"], out[1]["boxes"], atol=1e-2)

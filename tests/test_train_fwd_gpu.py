@@ -107,3 +107,37 @@ def test_polygon_rasteriser_exact_on_identical_boxes(gpu_ctx):
     lg = logits.cpu()[..., 0]
     ref_l = torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.from_numpy(got.astype(np.float32)), reduction="none").flatten(1).sum(1)
     assert torch.allclose(part.cpu(), ref_l, rtol=1e-5, atol=1e-4)
+
+
+def test_ragged_batch_losses_match_oracle(gpu_ctx):
+    """Two images of different size in one batch (what the trainer's ResizeShortestEdge batches look like): the smaller one sits
+    top-left in the common frame, its padding is zero AFTER normalisation whatever bytes the frame holds there, and its proposals are
+    clipped to its own size.  One of the images has a single GT instance."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    K, B, H, W = 2, 2, 256, 320
+    sizes = [(256, 320), (200, 250)]
+    imgs, gts = synth.batch(B, H, W, seed=9)
+    imgs = imgs.copy()
+    imgs[1, 200:, :, :] = 255          # garbage in the padding of the smaller image: must not matter
+    imgs[1, :, 250:, :] = 17
+    def inside(g, h, w, n):
+        keep = [i for i in range(len(g["boxes"])) if g["boxes"][i][2] <= w - 1 and g["boxes"][i][3] <= h - 1][:n]
+        return dict(boxes=np.asarray(g["boxes"])[keep], classes=np.asarray(g["classes"])[keep], polygons=[g["polygons"][i] for i in keep])
+    gts = [inside(gts[0], 256, 320, 1), inside(gts[1], 200, 250, 40)]
+    assert len(gts[0]["boxes"]) == 1 and len(gts[1]["boxes"]) >= 5
+    npp = P.init_params(K, seed=1, style="spread")
+    cfg = T.TrainCfg(num_classes=K, seed=3)
+    ref = T.forward_losses(imgs, gts, M.to_torch_params(npp), cfg, image_sizes=sizes)
+    ref_full = T.forward_losses(imgs, gts, M.to_torch_params(npp), cfg)
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=4096, max_poly_doubles=4096 * 64)
+    model.load_params(npp)
+    model.set_image_sizes(sizes)
+    got = model.forward_losses(imgs, gts, seed=3)
+    model.set_image_sizes(None)
+    model.close()
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
+        assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
+    # the sizes matter: treating the frame as one full image gives different losses (the test would pass vacuously otherwise)
+    assert any(abs(float(ref[k]) - float(ref_full[k])) > 1e-3 * abs(float(ref[k])) for k in ref)
