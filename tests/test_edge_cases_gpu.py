@@ -142,3 +142,24 @@ def test_differently_sized_images_in_one_batch(gpu_ctx):
         assert out[b]["boxes"][:, 2].max() <= sizes[b][1] and out[b]["boxes"][:, 3].max() <= sizes[b][0]
     # without the sizes the second image is a different problem (its garbage padding is image content)
     assert len(full[1]["boxes"]) != len(out[1]["boxes"]) or not np.allclose(full[1]["boxes"], out[1]["boxes"], atol=1e-2)
+
+
+def test_coco_class_count_512(gpu_ctx):
+    """BASELINE configs[0]'s shape: one 512 x 512 micrograph through the 80-class COCO head layout (box predictor 81 + 320 outputs,
+    mask predictor 80 channels) -- the class-specific box deltas and per-class NMS with many classes in play."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O
+    K, S, D = 80, 512, 100
+    rng = np.random.default_rng(33)
+    imgs = np.stack([_img(rng, S, S, blobs=25)])
+    p = P.init_params(K, seed=5, style="spread")
+    # a random 81-way softmax rarely clears the default 0.05: lower SCORE_THRESH_TEST on both sides to get a population
+    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D, score_thresh=0.02))
+    model = MaskRCNN(gpu_ctx, K, max_batch=1, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D, score_thresh=0.02)
+    model.load_params(p)
+    out = model.infer(imgs)
+    model.close()
+    cls = set(int(c) for c in ref[0]["classes"])
+    assert len(cls) >= 2 and max(cls) > 8, "the random head should pick classes deep inside the 80-class layout"
+    _match(out[0], ref[0], S, S)

@@ -141,3 +141,25 @@ def test_ragged_batch_losses_match_oracle(gpu_ctx):
         assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
     # the sizes matter: treating the frame as one full image gives different losses (the test would pass vacuously otherwise)
     assert any(abs(float(ref[k]) - float(ref_full[k])) > 1e-3 * abs(float(ref[k])) for k in ref)
+
+
+@pytest.mark.parametrize("K", [1, 5])
+def test_losses_other_class_counts(gpu_ctx, K):
+    """The tutorial trains NUM_CLASSES = 1 (particles); 5 exercises an odd predictor width (6 + 20 outputs, 5 mask channels).  One
+    image of the batch has no annotation at all (detectron2 would filter it out of a dataset, but the path must not depend on that)."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    B, H, W = 2, 224, 288
+    imgs, gts = synth.batch(B, H, W, seed=12)
+    gts = [dict(boxes=np.asarray(g["boxes"])[:30], classes=np.asarray(g["classes"])[:30] % K, polygons=g["polygons"][:30]) for g in gts]
+    gts[1] = dict(boxes=np.zeros((0, 4), np.float32), classes=np.zeros(0, np.int64), polygons=[])
+    npp = P.init_params(K, seed=2, style="spread")
+    cfg = T.TrainCfg(num_classes=K, seed=11)
+    ref = T.forward_losses(imgs, gts, M.to_torch_params(npp), cfg)
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=4096, max_poly_doubles=4096 * 64)
+    model.load_params(npp)
+    got = model.forward_losses(imgs, gts, seed=11, backward=True)
+    model.close()
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
+        assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
