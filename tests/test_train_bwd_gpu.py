@@ -81,3 +81,41 @@ def test_grad_arena_torch_view_is_zero_copy(setup, gpu_ctx):
     after = m.get_tensor("backbone.fpn_output3.weight", grad=True)
     assert np.allclose(after, 2.0 * before)
     assert comm.all_reduce_gradients(m, gpu_ctx) == 1.0      # single process: no-op, scale 1
+
+
+def test_gradients_single_class_ragged_batch(gpu_ctx):
+    """The tutorial's training configuration in miniature: NUM_CLASSES = 1 and two differently sized images in one batch
+    (amp_model_set_image_sizes).  Every trainable tensor's gradient against autograd of the oracle."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    K, B, H, W = 1, 2, 160, 224
+    sizes = [(160, 224), (128, 171)]
+    imgs, gts = synth.batch(B, H, W, seed=15)
+    def inside(g, h, w, n):
+        keep = [i for i in range(len(g["boxes"])) if g["boxes"][i][2] <= w - 1 and g["boxes"][i][3] <= h - 1][:n]
+        return dict(boxes=np.asarray(g["boxes"])[keep], classes=np.zeros(len(keep), np.int64), polygons=[g["polygons"][i] for i in keep])
+    gts = [inside(gts[b], *sizes[b], 25) for b in range(B)]
+    assert all(len(g["boxes"]) >= 3 for g in gts)
+    npp = P.init_params(K, seed=4, style="spread")
+    tp = M.to_torch_params(npp)
+    names = [k for k in tp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    for k in names:
+        tp[k].requires_grad_(True)
+    ref = T.forward_losses(imgs, gts, tp, T.TrainCfg(num_classes=K, seed=5), image_sizes=sizes)
+    sum(ref.values()).backward()
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=2048, max_poly_doubles=2048 * 64)
+    model.load_params(npp)
+    model.set_image_sizes(sizes)
+    got = model.forward_losses(imgs, gts, seed=5, backward=True)
+    for k, v in ref.items():
+        assert got[k] == pytest.approx(float(v.detach()), rel=2e-4, abs=1e-6), k
+    bad = []
+    for name in names:
+        g, r = model.get_tensor(name, grad=True), tp[name].grad.detach().numpy()
+        assert g.shape == r.shape, name
+        err = float(np.abs(g - r).max()) / max(float(np.abs(r).max()), 1e-8)
+        if err > 2e-3:
+            bad.append((err, name))
+    model.close()
+    assert not bad, f"{len(bad)} tensors off: {sorted(bad, reverse=True)[:8]}"
