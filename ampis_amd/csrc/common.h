@@ -82,6 +82,8 @@ struct amp_ctx {
     int conv_mode = 1;
     int* d_conv_flag = nullptr;            // device int: an f16x3 convolution produced a non-finite accumulator (operand beyond fp16 range)
     float* split_scratch = nullptr;        // split copy of the weights of a per-call f16x3 convolution
+    void* topk_scratch = nullptr;          // chunk candidates of amp_rpn_topk (levels cut into several workgroups)
+    size_t topk_bytes = 0;
     size_t split_bytes = 0;
 };
 

@@ -136,6 +136,7 @@ void amp_destroy(amp_ctx* ctx) {
     (void)hipFree(ctx->zero_page);
     (void)hipFree(ctx->d_conv_flag);
     (void)hipFree(ctx->split_scratch);
+    (void)hipFree(ctx->topk_scratch);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -28,28 +28,77 @@ struct TopkArgs {
     int* sel_idx;                    // [B][nlevels][k] anchor index within the level, sorted
     float* sel_logit;                // [B][nlevels][k]
     int* sel_count;                  // [B][nlevels]
+    // A level with more than TOPK_CHUNK anchors is cut into nch[l] chunks of len[l] anchors, one workgroup each: the top-k of the
+    // level is contained in the union of the chunks' top-k lists, which topk_merge_kernel orders exactly (64-bit words
+    // (key << 32) | ~anchor index: logit descending, ties by ascending anchor index, as in the one-workgroup path).
+    int nch[MAX_LEVELS], len[MAX_LEVELS], seg0[MAX_LEVELS];   // seg0[l]: first chunk-segment of level l inside an image
+    int segs_per_img;
+    unsigned long long* cand;        // [B][segs_per_img][k] sorted words of the chunk segments (levels with nch > 1)
+    int* cand_count;                 // [B][segs_per_img]
 };
 
 }  // namespace
 #include "select.h"
 namespace {
 
+constexpr int TOPK_CHUNK = 49152;    // anchors per workgroup: the 196 608 anchors of p2 of a 1024 x 1024 image become 4 chunks (8 chunks of 24 576 were
+                                     // slower: the select has ~100 us of fixed cost and the merge sorts twice as many words)
+
 __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a) {
     __shared__ amp::SelectSmem sm;
-    const int seg = blockIdx.x;
-    const int b = seg / a.nlevels, lvl = seg % a.nlevels;
-    const int n = a.hw[lvl] * a.A;
+    const int b = blockIdx.x / a.segs_per_img, s_in = blockIdx.x % a.segs_per_img;
+    int lvl = 0;
+    while (lvl + 1 < a.nlevels && s_in >= a.seg0[lvl + 1]) ++lvl;
+    const int c = s_in - a.seg0[lvl];
+    const int seg = b * a.nlevels + lvl;
+    const int n_lvl = a.hw[lvl] * a.A;
+    const int i0 = c * a.len[lvl];
+    const int n = min(a.len[lvl], n_lvl - i0);
     const float* pred = a.pred[lvl] + (size_t)b * a.hw[lvl] * a.ld;
-    uint32_t* keys = a.keys_scratch + (size_t)seg * a.max_n;
+    uint32_t* keys = a.keys_scratch + (size_t)seg * a.max_n + i0;
     const int A = a.A, ld = a.ld;
     // key = order-preserving image of the logit; (logit desc, index asc) == (key desc, index asc)
     const int k = amp::select_topk(sm, n, a.k, keys, [&](int i) {
-        const int pix = i / A, an = i - pix * A;
+        const int g = i0 + i, pix = g / A, an = g - pix * A;
         uint32_t key = f2ord(pred[(size_t)pix * ld + an]);
         return key ? key : 1u;   // 0 is the "not a candidate" marker of select_topk (only a negative NaN maps there)
     });
+    if (a.nch[lvl] == 1) {
+        for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
+            const unsigned long long wv = sm.sorted[i];
+            a.sel_idx[(size_t)seg * a.k + i] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
+            a.sel_logit[(size_t)seg * a.k + i] = ord2f((uint32_t)(wv >> 32));
+        }
+        if (threadIdx.x == 0) a.sel_count[seg] = k;
+    } else {
+        // chunk-local index -> anchor index of the level: ~(i0 + i) = ~i - i0 in the low word
+        unsigned long long* out = a.cand + (size_t)blockIdx.x * a.k;
+        for (int i = threadIdx.x; i < k; i += TOPK_THREADS) out[i] = sm.sorted[i] - (unsigned long long)(uint32_t)i0;
+        if (threadIdx.x == 0) a.cand_count[blockIdx.x] = k;
+    }
+}
+
+// one workgroup per (image, level with chunks): exact order of the chunks' candidates, first k out
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkArgs a, int lvl, int N) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];
+    const int b = blockIdx.x;
+    const int nch = a.nch[lvl];
+    int total = 0;
+    for (int c = 0; c < nch; ++c) total += a.cand_count[b * a.segs_per_img + a.seg0[lvl] + c];
+    for (int i = threadIdx.x; i < N; i += TOPK_THREADS) {
+        const int c = i / a.k, j = i - c * a.k;
+        unsigned long long w = 0ull;
+        if (c < nch) {
+            const int sg = b * a.segs_per_img + a.seg0[lvl] + c;
+            if (j < a.cand_count[sg]) w = a.cand[(size_t)sg * a.k + j];
+        }
+        mkeys[i] = w;
+    }
+    amp::bitonic_desc<TOPK_THREADS>(mkeys, N);
+    const int k = min(a.k, total);
+    const int seg = b * a.nlevels + lvl;
     for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
-        const unsigned long long wv = sm.sorted[i];
+        const unsigned long long wv = mkeys[i];
         a.sel_idx[(size_t)seg * a.k + i] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
         a.sel_logit[(size_t)seg * a.k + i] = ord2f((uint32_t)(wv >> 32));
     }
@@ -184,7 +233,42 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
     a.nlevels = lv->nlevels; a.A = lv->A; a.ld = lv->ld; a.k = k;
     a.keys_scratch = keys_scratch; a.max_n = max_n;
     a.sel_idx = sel_idx; a.sel_logit = sel_logit; a.sel_count = sel_count;
-    hipLaunchKernelGGL(rpn_topk_kernel, dim3(B * lv->nlevels), dim3(TOPK_THREADS), 0, ctx->stream, a);
+    int segs = 0;
+    bool chunked = false;
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        a.seg0[l] = segs;
+        if (l >= lv->nlevels) { a.nch[l] = 1; a.len[l] = 0; continue; }
+        const int n = a.hw[l] * a.A;
+        a.nch[l] = std::min(8, std::max(1, amp::cdiv(n, TOPK_CHUNK)));
+        if ((long long)a.nch[l] * k > 8192) a.nch[l] = std::max(1, 8192 / k);     // the merge sorts nch * k words in LDS
+        a.len[l] = amp::cdiv(amp::cdiv(n, a.nch[l]), 64) * 64;
+        a.nch[l] = amp::cdiv(n, a.len[l]);
+        chunked = chunked || a.nch[l] > 1;
+        segs += a.nch[l];
+    }
+    a.segs_per_img = segs;
+    a.cand = nullptr; a.cand_count = nullptr;
+    if (chunked) {
+        const size_t need = (size_t)B * segs * ((size_t)k * sizeof(unsigned long long) + sizeof(int));
+        if (ctx->topk_bytes < need) {      // grown on demand, once per shape class
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (ctx->topk_scratch) AMP_HIP_CHECK(hipFree(ctx->topk_scratch));
+            ctx->topk_scratch = nullptr; ctx->topk_bytes = 0;
+            AMP_HIP_CHECK(hipMalloc(&ctx->topk_scratch, need));
+            ctx->topk_bytes = need;
+        }
+        a.cand = reinterpret_cast<unsigned long long*>(ctx->topk_scratch);
+        a.cand_count = reinterpret_cast<int*>(a.cand + (size_t)B * segs * k);
+    }
+    hipLaunchKernelGGL(rpn_topk_kernel, dim3(B * segs), dim3(TOPK_THREADS), 0, ctx->stream, a);
+    for (int l = 0; l < lv->nlevels; ++l)
+        if (a.nch[l] > 1) {
+            int N = 64;
+            while (N < a.nch[l] * k) N <<= 1;
+            AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)(N * sizeof(unsigned long long))));
+            hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_THREADS), (size_t)N * sizeof(unsigned long long), ctx->stream, a, l, N);
+        }
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -45,6 +45,30 @@ def test_rpn_topk_exact(gpu_ctx, ties):
             assert np.array_equal(sl[b, l, :kk], logits.numpy()[order])
 
 
+@pytest.mark.parametrize("ties", [False, True])
+def test_rpn_topk_exact_on_chunked_levels(gpu_ctx, ties):
+    """Levels with more than 49 152 anchors are selected by several workgroups and merged: same exact order (logit descending,
+    ties by ascending anchor index), also when a chunk holds fewer candidates than k and when ties straddle chunk borders."""
+    from ampis_amd import ops
+    from oracle import maskrcnn as O
+    rng = np.random.default_rng(7 + ties)
+    B, k = 2, 1000
+    shapes = [(256, 200), (130, 127), (64, 50), (32, 25), (16, 13)]      # 153 600 / 49 530 / 9 600 ... anchors: 4 and 2 chunks, then 1
+    preds = _levels(B, rng, shapes, ties)
+    preds[0][1, 40000:, :3] = -50.0 - torch.arange(preds[0].shape[1] - 40000)[:, None] * 1e-3    # image 1: three of four chunks nearly empty of good logits
+    si, sl, sc = ops.rpn_topk(gpu_ctx, [p.to(DEV) for p in preds], shapes, B, k)
+    torch.cuda.synchronize()
+    si, sl, sc = si.cpu().numpy(), sl.cpu().numpy(), sc.cpu().numpy()
+    for b in range(B):
+        for l, p in enumerate(preds):
+            logits = p[b, :, :3].reshape(-1)
+            kk = min(k, logits.numel())
+            assert sc[b, l] == kk
+            order = O.sort_desc_stable(logits)[:kk].numpy()
+            assert np.array_equal(si[b, l, :kk], order), (b, l)
+            assert np.array_equal(sl[b, l, :kk], logits.numpy()[order])
+
+
 def test_rpn_decode_and_sort(gpu_ctx):
     from ampis_amd import ops
     from oracle import maskrcnn as O
