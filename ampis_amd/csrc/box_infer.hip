@@ -53,10 +53,25 @@ __global__ void box_candidates_kernel(const CandArgs a) {
         if (!all_finite) continue;
         for (int k = 0; k < a.K; ++k) {
             const float p = __fdiv_rn(expf(__fsub_rn(row[k], mx)), sum);
-            if (p > a.score_thresh) {
-                const int slot = atomicAdd(&a.cand_count[b], 1);
-                if (slot < a.ccap) a.keys[(size_t)b * a.ccap + slot] = amp::make_sortkey(amp::f2ord(p), r * a.K + k, k);
-                else *a.overflow = 1;
+            bool take = p > a.score_thresh;
+            // one atomic per (wave, image) instead of one per candidate: thousands of adds to the same 8 counters were 4/5 of the
+            // kernel.  Slot order is arbitrary either way (the candidates are sorted by key afterwards).
+            while (true) {
+                const unsigned long long pending = __ballot(take);
+                if (!pending) break;
+                const int leader = __ffsll((long long)pending) - 1;
+                const int bsel = __shfl(b, leader, 64);
+                const unsigned long long mine = __ballot(take && b == bsel);
+                int base = 0;
+                if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&a.cand_count[bsel], __popcll(mine));
+                base = __shfl(base, leader, 64);
+                if (take && b == bsel) {
+                    const int lane = threadIdx.x & 63;
+                    const int slot = base + __popcll(mine & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                    if (slot < a.ccap) a.keys[(size_t)b * a.ccap + slot] = amp::make_sortkey(amp::f2ord(p), r * a.K + k, k);
+                    else *a.overflow = 1;
+                    take = false;
+                }
             }
         }
     }
