@@ -58,11 +58,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a
     uint32_t* keys = a.keys_scratch + (size_t)seg * a.max_n + i0;
     const int A = a.A, ld = a.ld;
     // key = order-preserving image of the logit; (logit desc, index asc) == (key desc, index asc)
-    const int k = amp::select_topk(sm, n, a.k, keys, [&](int i) {
+    auto key_fn = [&](int i) {
         const int g = i0 + i, pix = g / A, an = g - pix * A;
         uint32_t key = f2ord(pred[(size_t)pix * ld + an]);
         return key ? key : 1u;   // 0 is the "not a candidate" marker of select_topk (only a negative NaN maps there)
-    });
+    };
+    // chunks are at most TOPK_CHUNK = 48 * 1024 keys: they live in registers; anything larger (nch capped by the merge) goes
+    // through the scratch copy
+    const int k = (n <= TOPK_CHUNK) ? amp::select_topk_reg<TOPK_CHUNK / 1024>(sm, n, a.k, key_fn) : amp::select_topk(sm, n, a.k, keys, key_fn);
     if (a.nch[lvl] == 1) {
         for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
             const unsigned long long wv = sm.sorted[i];

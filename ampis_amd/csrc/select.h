@@ -124,4 +124,94 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
     return k;
 }
 
+// The same selection with the keys held in registers: n <= PER * 1024 keys, thread (wave w, lane l) owns
+// i = w * PER * 64 + j * 64 + l for j < PER -- a contiguous range per wave, so the index-ordered compaction needs no second layout.
+// The memory version re-reads its keys from L2 in every one of its seven passes; for the RPN's chunks of <= 49 152 logits that
+// latency, not the arithmetic, was the kernel.
+template <int PER, class KeyFn>
+__device__ inline int select_topk_reg(SelectSmem& sm, int n, int kmax, KeyFn key_fn) {
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int base = wave * PER * 64 + lane;
+    __syncthreads();   // previous users of sm are done
+    if (tid < 256) sm.hist[tid] = 0;
+    if (tid == 0) sm.ncand = 0;
+    __syncthreads();
+    uint32_t kreg[PER];
+    unsigned int mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = base + j * 64;
+        kreg[j] = (i < n) ? key_fn(i) : 0u;
+        if (kreg[j]) { atomicAdd(&sm.hist[kreg[j] >> 24], 1u); ++mine; }
+    }
+    if (mine) atomicAdd(&sm.ncand, mine);
+    __syncthreads();
+    const int k = min(kmax, (int)sm.ncand);
+    if (k <= 0) return 0;   // uniform
+    if (tid == 0) { sm.prefix = 0; sm.remaining = (unsigned)k; }
+    __syncthreads();
+    for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        if (round > 0) {
+            if (tid < 256) sm.hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = sm.prefix;
+            const uint32_t himask = 0xffffffffu << (shift + 8);
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (kreg[j] && (kreg[j] & himask) == prefix) atomicAdd(&sm.hist[(kreg[j] >> shift) & 0xff], 1u);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            unsigned int rem = sm.remaining;
+            int d = 255;
+            for (; d > 0; --d) {
+                const unsigned int c = sm.hist[d];
+                if (c >= rem) break;
+                rem -= c;
+            }
+            sm.prefix |= ((uint32_t)d << shift);
+            sm.remaining = rem;
+        }
+        __syncthreads();
+    }
+    const uint32_t T = sm.prefix;
+    const unsigned int need_eq = sm.remaining;
+    unsigned int cgt = 0, ceq = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        cgt += __popcll(__ballot(kreg[j] > T));
+        ceq += __popcll(__ballot(kreg[j] == T));
+    }
+    if (lane == 0) { sm.wave_gt[wave] = cgt; sm.wave_eq[wave] = ceq; }
+    for (int i = tid; i < SELECT_MAX_K; i += SELECT_THREADS) sm.sorted[i] = 0ull;
+    __syncthreads();
+    unsigned int rgt = 0, req = 0, gt_total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { rgt += sm.wave_gt[w]; req += sm.wave_eq[w]; }
+        gt_total += sm.wave_gt[w];
+    }
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t key = kreg[j];
+        const bool gt = key > T, eq = key == T;
+        const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
+        const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)(base + j * 64));
+        if (gt) sm.sorted[rgt + __popcll(mgt & below)] = word;
+        if (eq) {
+            const unsigned int r = req + __popcll(meq & below);
+            if (r < need_eq) sm.sorted[gt_total + r] = word;
+        }
+        rgt += __popcll(mgt);
+        req += __popcll(meq);
+    }
+    __syncthreads();
+    int N = 64;
+    while (N < k) N <<= 1;
+    bitonic_desc<SELECT_THREADS>(sm.sorted, N);
+    return k;
+}
+
 }  // namespace amp
