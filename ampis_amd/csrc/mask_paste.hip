@@ -63,6 +63,28 @@ __device__ __forceinline__ float tap(const float* sp, int y, int x) {
     return ((unsigned)y < (unsigned)MS && (unsigned)x < (unsigned)MS) ? sp[y * MS + x] : 0.f;
 }
 
+// The four taps of a column stay the same while the source row does (a 28-row mask pasted into a 200-row box: ~7 output rows per
+// source row), and all lanes of a wave walk the same output row: reload them only when ay.i0 changes (wave-uniform branch).
+// Same products, same summation order as paste_bit.
+struct ColTaps {
+    int i0;
+    float t00, t01, t10, t11;
+};
+__device__ __forceinline__ int paste_bit_cached(const float* sp, Axis ax, Axis ay, float thr, ColTaps& c) {
+    if (ay.i0 != c.i0) {
+        c.i0 = ay.i0;
+        c.t00 = tap(sp, ay.i0, ax.i0); c.t01 = tap(sp, ay.i0, ax.i0 + 1);
+        c.t10 = tap(sp, ay.i0 + 1, ax.i0); c.t11 = tap(sp, ay.i0 + 1, ax.i0 + 1);
+    }
+    const float w = ax.w1, e = __fsub_rn(1.0f, w), n = ay.w1, s = __fsub_rn(1.0f, n);
+    const float nw = __fmul_rn(s, e), ne = __fmul_rn(s, w), sw = __fmul_rn(n, e), se = __fmul_rn(n, w);
+    float v = __fmul_rn(c.t00, nw);
+    v = __fadd_rn(v, __fmul_rn(c.t01, ne));
+    v = __fadd_rn(v, __fmul_rn(c.t10, sw));
+    v = __fadd_rn(v, __fmul_rn(c.t11, se));
+    return v >= thr ? 1 : 0;
+}
+
 __device__ __forceinline__ int paste_bit(const float* sp, Axis ax, Axis ay, float thr) {
     const float w = ax.w1, e = __fsub_rn(1.0f, w), n = ay.w1, s = __fsub_rn(1.0f, n);
     const float nw = __fmul_rn(s, e), ne = __fmul_rn(s, w), sw = __fmul_rn(n, e), se = __fmul_rn(n, w);
@@ -126,9 +148,10 @@ __global__ __launch_bounds__(PT) void paste_rle_kernel(const PasteArgs a) {
             prev = paste_bit(sp, pax, pay, thr);
         }
         int cnt = 0;
+        ColTaps ct; ct.i0 = -(1 << 30);
         for (int iy = 0; iy < ny; ++iy) {
             Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
-            const int bit = paste_bit(sp, ax, ay, thr);
+            const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
             cnt += (bit != prev);
             prev = bit;
         }
@@ -190,9 +213,10 @@ __global__ __launch_bounds__(PT) void paste_rle_kernel(const PasteArgs a) {
         }
         int w = colcnt[cx];
         const unsigned int base = (unsigned int)x * (unsigned int)H + (unsigned int)y0i;
+        ColTaps ct; ct.i0 = -(1 << 30);
         for (int iy = 0; iy < ny; ++iy) {
             Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
-            const int bit = paste_bit(sp, ax, ay, thr);
+            const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
             if (bit != prev) posbuf[w++] = base + (unsigned int)iy;
             prev = bit;
         }
