@@ -35,6 +35,24 @@ int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t
     return AMP_OK;
 }
 
+/* n run-length lists out of one pool (list i = pool[off[i] .. off[i] + len[i])) -> n counts strings, back to back in `out`;
+ * string i = out[str_off[i] .. str_off[i + 1]).  One call per image instead of one per mask (a ctypes round trip each). */
+int amp_rle_to_strings(const uint32_t* pool, const unsigned long long* off, const int* len, int n, char* out, size_t cap,
+                       size_t* str_off) {
+    AMP_REQUIRE((pool || n == 0) && (off || n == 0) && (len || n == 0) && out && str_off && n >= 0, "amp_rle_to_strings: bad argument");
+    size_t p = 0;
+    str_off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        size_t l = 0;
+        AMP_REQUIRE(p < cap, "amp_rle_to_strings: output buffer too small (cap=%zu)", cap);
+        const int st = amp_rle_to_string(pool + off[i], len[i], out + p, cap - p, &l);
+        if (st != AMP_OK) return st;
+        p += l;
+        str_off[i + 1] = p;
+    }
+    return AMP_OK;
+}
+
 int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int* m_out) {
     AMP_REQUIRE((s || len == 0) && cnts && m_out, "amp_rle_from_string: null argument");
     int m = 0;

@@ -108,13 +108,10 @@ class MaskRCNN:
         for b in range(B):
             k = int(n[b])
             h, w = int(d.out_h[b]), int(d.out_w[b])
-            masks = []
-            for i in range(k):
-                cnts = pool[int(off[b, i]): int(off[b, i]) + int(ln[b, i])]
-                if rle == "counts":
-                    masks.append({"size": [h, w], "counts": cnts.copy()})
-                else:
-                    masks.append({"size": [h, w], "counts": _rle.counts_to_string(cnts)})
+            if rle == "counts":
+                masks = [{"size": [h, w], "counts": pool[int(off[b, i]): int(off[b, i]) + int(ln[b, i])].copy()} for i in range(k)]
+            else:       # one C call per image: a ctypes round trip per mask cost 3 ms of a 9 ms DefaultPredictor call at 400 masks
+                masks = [{"size": [h, w], "counts": c} for c in _rle.counts_to_strings(pool, off[b, :k], ln[b, :k])]
             out.append(dict(boxes=boxes[b, :k].copy(), scores=scores[b, :k].copy(),
                             classes=classes[b, :k].astype(np.int64), masks=masks, image_size=(h, w)))
         return out

@@ -17,6 +17,24 @@ def counts_to_string(cnts):
     return buf.raw[: n.value]
 
 
+def counts_to_strings(pool, off, ln):
+    """RLE strings of many masks in one call: mask i = pool[off[i] : off[i] + ln[i]] (uint32 run lengths)."""
+    n = len(off)
+    if n == 0:
+        return []
+    pool = np.ascontiguousarray(pool, dtype=np.uint32)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    ln = np.ascontiguousarray(ln, dtype=np.int32)
+    cap = 7 * int(ln.sum()) + 8 * n + 8
+    buf = C.create_string_buffer(cap)
+    so = np.zeros(n + 1, dtype=np.uintp)
+    check(lib().amp_rle_to_strings(pool.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), ln.ctypes.data_as(C.c_void_p), n,
+                                   buf, cap, so.ctypes.data_as(C.c_void_p)), "amp_rle_to_strings")
+    raw = buf.raw
+    so = so.tolist()
+    return [raw[so[i]: so[i + 1]] for i in range(n)]
+
+
 def string_to_counts(s):
     if isinstance(s, str):
         s = s.encode("ascii")

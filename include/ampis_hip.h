@@ -239,6 +239,9 @@ int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float*
 
 /* Host-side COCO RLE codec (all pointers HOST) --------------------------------------------------- */
 int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t* len);
+/* n lists out of one pool (list i = pool[off[i] .. +len[i])) -> n strings back to back; string i = out[str_off[i] .. str_off[i+1]) */
+int amp_rle_to_strings(const uint32_t* pool, const unsigned long long* off, const int* len, int n, char* out, size_t cap,
+                       size_t* str_off /* [n+1] */);
 int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int* m_out);
 int amp_rle_encode(const uint8_t* mask_colmajor, int h, int w, uint32_t* cnts, int cap, int* m_out);
 int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colmajor);
