@@ -165,6 +165,52 @@ int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscr
     return AMP_OK;
 }
 
+/* IoU of every pair out of two pools of run-length lists (list i = pool[off[i] .. off[i] + len[i])): out[d * ng + g], the matrix
+ * pycocotools.mask.iou(dt, gt, iscrowd) returns.  Like rleIou it looks at the bounding boxes first (h = mask height, 0 = skip that
+ * test): boxes that do not overlap mean IoU 0 without walking the runs -- for a few hundred instances per micrograph that is all but
+ * a few pairs per row. */
+int amp_rle_iou_matrix(const uint32_t* dpool, const unsigned long long* doff, const int* dlen, int nd, const uint32_t* gpool,
+                       const unsigned long long* goff, const int* glen, int ng, const unsigned char* iscrowd, int h, double* out) {
+    AMP_REQUIRE(nd >= 0 && ng >= 0 && h >= 0 && (nd == 0 || (dpool && doff && dlen)) && (ng == 0 || (gpool && goff && glen)) &&
+                (out || nd == 0 || ng == 0), "amp_rle_iou_matrix: bad argument");
+    struct Box { long long x0, x1, y0, y1; bool any; };
+    auto bbox = [&](const uint32_t* c, int m) {
+        Box b{1LL << 60, -1, 1LL << 60, -1, false};
+        unsigned long long p = 0;
+        for (int i = 0; i < m; ++i) {
+            const unsigned long long l = c[i];
+            if ((i & 1) && l > 0) {
+                b.any = true;
+                if (h > 0) {
+                    const long long xa = (long long)(p / h), xb = (long long)((p + l - 1) / h);
+                    b.x0 = std::min(b.x0, xa); b.x1 = std::max(b.x1, xb);
+                    if (xa == xb) { b.y0 = std::min(b.y0, (long long)(p % h)); b.y1 = std::max(b.y1, (long long)((p + l - 1) % h)); }
+                    else { b.y0 = 0; b.y1 = h - 1; }
+                } else {
+                    b.x0 = std::min(b.x0, (long long)p); b.x1 = std::max(b.x1, (long long)(p + l - 1));   // linear extent
+                    b.y0 = 0; b.y1 = 0;
+                }
+            }
+            p += l;
+        }
+        return b;
+    };
+    std::vector<Box> db((size_t)nd), gb((size_t)ng);
+    for (int d = 0; d < nd; ++d) { AMP_REQUIRE(dlen[d] > 0, "amp_rle_iou_matrix: empty run list"); db[d] = bbox(dpool + doff[d], dlen[d]); }
+    for (int g = 0; g < ng; ++g) { AMP_REQUIRE(glen[g] > 0, "amp_rle_iou_matrix: empty run list"); gb[g] = bbox(gpool + goff[g], glen[g]); }
+    for (int d = 0; d < nd; ++d)
+        for (int g = 0; g < ng; ++g) {
+            const Box &a = db[d], &b = gb[g];
+            double v = 0.0;
+            if (a.any && b.any && a.x0 <= b.x1 && b.x0 <= a.x1 && a.y0 <= b.y1 && b.y0 <= a.y1) {
+                const int st = amp_rle_iou(dpool + doff[d], dlen[d], gpool + goff[g], glen[g], iscrowd ? (int)iscrowd[g] : 0, &v);
+                if (st != AMP_OK) return st;
+            }
+            out[(size_t)d * ng + g] = v;
+        }
+    return AMP_OK;
+}
+
 // out = A & B (intersect != 0) or A | B, both over the same h*w. Returns the number of runs in *m_out.
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out) {
     AMP_REQUIRE(A && B && out && m_out && ka > 0 && kb > 0, "amp_rle_merge2: bad argument");

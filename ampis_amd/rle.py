@@ -84,18 +84,28 @@ def area(r):
     return int(a.value)
 
 
+def _pool(counts_list):
+    off = np.zeros(len(counts_list), dtype=np.uint64)
+    ln = np.asarray([len(c) for c in counts_list], dtype=np.int32)
+    if len(counts_list):
+        off[1:] = np.cumsum(ln[:-1], dtype=np.uint64)
+    pool = np.ascontiguousarray(np.concatenate(counts_list) if len(counts_list) else np.zeros(1, np.uint32), dtype=np.uint32)
+    return pool, off, ln
+
+
 def iou(dt, gt, iscrowd):
-    """len(dt) x len(gt) float64 matrix, like pycocotools.mask.iou on RLE lists."""
+    """len(dt) x len(gt) float64 matrix, like pycocotools.mask.iou on RLE lists (one C call: amp_rle_iou_matrix)."""
     out = np.zeros((len(dt), len(gt)), dtype=np.float64)
-    dc = [_counts(x) for x in dt]
-    gc = [_counts(x) for x in gt]
-    v = C.c_double()
-    for j, g in enumerate(gc):
-        crowd = int(bool(iscrowd[j])) if len(iscrowd) else 0
-        for i, d in enumerate(dc):
-            check(lib().amp_rle_iou(d.ctypes.data_as(C.c_void_p), len(d), g.ctypes.data_as(C.c_void_p), len(g), crowd,
-                                    C.byref(v)), "amp_rle_iou")
-            out[i, j] = v.value
+    if len(dt) == 0 or len(gt) == 0:
+        return out
+    dp, do, dl = _pool([_counts(x) for x in dt])
+    gp, go, gl = _pool([_counts(x) for x in gt])
+    crowd = np.ascontiguousarray([int(bool(c)) for c in iscrowd], dtype=np.uint8) if len(iscrowd) else None
+    assert crowd is None or len(crowd) == len(gt)
+    h = int(dt[0]["size"][0]) if isinstance(dt[0], dict) and "size" in dt[0] else 0
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().amp_rle_iou_matrix(vp(dp), vp(do), vp(dl), len(dt), vp(gp), vp(go), vp(gl), len(gt),
+                                   vp(crowd) if crowd is not None else None, h, vp(out)), "amp_rle_iou_matrix")
     return out
 
 

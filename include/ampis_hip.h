@@ -247,6 +247,10 @@ int amp_rle_encode(const uint8_t* mask_colmajor, int h, int w, uint32_t* cnts, i
 int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colmajor);
 int amp_rle_area(const uint32_t* cnts, int m, unsigned long long* area);
 int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscrowd, double* iou);
+/* all-pairs IoU of two pools of run lists (pycocotools.mask.iou): out[d * ng + g]; bounding boxes are compared first (h = mask height) */
+int amp_rle_iou_matrix(const uint32_t* dpool, const unsigned long long* doff, const int* dlen, int nd, const uint32_t* gpool,
+                       const unsigned long long* goff, const int* glen, int ng, const unsigned char* iscrowd /* [ng] or NULL */, int h,
+                       double* out);
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out);
 /* polygon (k vertices, flat xy) -> runs of an h x w mask (pycocotools rleFrPoly / frPyObjects) */
 int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, int cap, int* m_out);
