@@ -14,6 +14,31 @@ from . import rle as _rle
 _TAP_DTYPES = {0: np.float32, 1: np.int32, 2: np.uint64, 3: np.int8, 4: np.uint8}
 
 
+class PackedGt:
+    """The amp_gt struct of a batch: per image dict(boxes [G,4], classes [G], polygons list[G] of flat xy arrays) flattened once.
+    Keeps the arrays alive; reusable across steps (a data loader packs in its worker, not in the training loop)."""
+
+    def __init__(self, gt):
+        B = len(gt)
+        off = np.zeros(B + 1, dtype=np.int32)
+        for b, g in enumerate(gt):
+            off[b + 1] = off[b] + len(g["boxes"])
+        total = int(off[B])
+        boxes = np.ascontiguousarray(np.concatenate([np.asarray(g["boxes"], np.float32).reshape(-1, 4) for g in gt]) if total else np.zeros((0, 4), np.float32))
+        classes = np.ascontiguousarray(np.concatenate([np.asarray(g["classes"], np.int32).reshape(-1) for g in gt]) if total else np.zeros(0, np.int32), dtype=np.int32)
+        polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
+        assert len(polys) == total, "one polygon per instance"
+        poff = np.zeros(total + 1, dtype=np.int32)
+        if total:
+            poff[1:] = np.cumsum([len(p) for p in polys])
+        pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
+        self.B, self.total = B, total
+        self._keep = (off, boxes, classes, poff, pxy)
+        self.struct = Gt(B, off.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(C.POINTER(C.c_float)),
+                         classes.ctypes.data_as(C.POINTER(C.c_int)), poff.ctypes.data_as(C.POINTER(C.c_int)),
+                         pxy.ctypes.data_as(C.POINTER(C.c_double)))
+
+
 class MaskRCNN:
     def __init__(self, ctx, num_classes, max_batch=1, max_h=1344, max_w=1344, max_out_hw=4096,
                  detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
@@ -118,31 +143,24 @@ class MaskRCNN:
 
     LOSS_NAMES = ("loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc")
 
-    def forward_losses(self, images, gt, seed=0, backward=False):
+    def forward_losses(self, images, gt, seed=0, backward=False, device_ptr=None, shape=None):
         """Training-mode forward: the loss dict `model(data)` returns to LossEvalHook (ampis/data_utils.py:111-122).
         images uint8 [B,H,W,3]; gt: per image dict(boxes [G,4], classes [G], polygons list of flat xy arrays).
-        backward=True also runs the backward pass (gradients stay on the device until sgd_step / get_tensor)."""
-        images = np.ascontiguousarray(images, dtype=np.uint8)
-        B, H, W, _ = images.shape
-        assert len(gt) == B
-        off = np.zeros(B + 1, dtype=np.int32)
-        for b, g in enumerate(gt):
-            off[b + 1] = off[b] + len(g["boxes"])
-        total = int(off[B])
-        boxes = np.ascontiguousarray(np.concatenate([np.asarray(g["boxes"], np.float32).reshape(-1, 4) for g in gt]) if total else np.zeros((0, 4), np.float32))
-        classes = np.ascontiguousarray(np.concatenate([np.asarray(g["classes"], np.int32).reshape(-1) for g in gt]) if total else np.zeros(0, np.int32), dtype=np.int32)
-        polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
-        assert len(polys) == total, "one polygon per instance"
-        poff = np.zeros(total + 1, dtype=np.int32)
-        if total:
-            poff[1:] = np.cumsum([len(p) for p in polys])
-        pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
-        g = Gt(B, off.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(C.POINTER(C.c_float)),
-               classes.ctypes.data_as(C.POINTER(C.c_int)), poff.ctypes.data_as(C.POINTER(C.c_int)),
-               pxy.ctypes.data_as(C.POINTER(C.c_double)))
+        backward=True also runs the backward pass (gradients stay on the device until sgd_step / get_tensor).
+        `gt` may be a PackedGt (the flat arrays of the C ABI, built once by a data-loader worker); images may already be on the
+        device (images=None, device_ptr + shape=(B,H,W))."""
+        if device_ptr is not None:
+            B, H, W = shape
+            img_p, on_host = C.c_void_p(int(device_ptr)), 0
+        else:
+            images = np.ascontiguousarray(images, dtype=np.uint8)
+            B, H, W, _ = images.shape
+            img_p, on_host = images.ctypes.data_as(C.c_void_p), 1
+        packed = gt if isinstance(gt, PackedGt) else PackedGt(gt)
+        assert packed.B == B
         out = (C.c_float * 5)()
         fn = lib().amp_model_forward_backward if backward else lib().amp_model_forward_losses
-        check(fn(self._h, images.ctypes.data_as(C.c_void_p), 1, B, H, W, C.byref(g), int(seed) & 0xFFFFFFFF, out),
+        check(fn(self._h, img_p, on_host, B, H, W, C.byref(packed.struct), int(seed) & 0xFFFFFFFF, out),
               "amp_model_forward_backward" if backward else "amp_model_forward_losses")
         return {n: float(out[i]) for i, n in enumerate(self.LOSS_NAMES)}
 
