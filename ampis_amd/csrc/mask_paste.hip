@@ -42,6 +42,9 @@ struct PasteArgs {
     unsigned long long* rle_off;     // [N]
     int* rle_len;             // [N]
     int* overflow;
+    unsigned int* pos_pool;   // optional: transition positions go here (own counter) and `pool` holds run lengths only, densely
+    unsigned long long pos_cap;
+    unsigned long long* pos_used;
     int max_rows;             // capacity of the per-row LDS tables
 };
 
@@ -185,21 +188,31 @@ __global__ __launch_bounds__(PT) void paste_rle_kernel(const PasteArgs a) {
         run += c;
     }
     if (tid == 0) {
-        const unsigned long long need = 2ull * (unsigned long long)T + 1ull;
+        // run lengths (T + 1 words, what the host reads back) and the positions they are made from (T words of scratch): one
+        // region when there is no separate scratch pool, else two pools so that the read-back is the run lengths only
+        const unsigned long long need = a.pos_pool ? (unsigned long long)T + 1ull : 2ull * (unsigned long long)T + 1ull;
         const unsigned long long off = atomicAdd(a.pool_used, need);
+        unsigned long long poff = off + (unsigned long long)T + 1ull;
         int ok = 1;
         if (off + need > a.pool_cap) { ok = 0; *a.overflow = 1; }
+        if (a.pos_pool) {
+            poff = atomicAdd(a.pos_used, (unsigned long long)T);
+            if (poff + (unsigned long long)T > a.pos_cap) { ok = 0; *a.overflow = 1; }
+        }
         s_misc[0] = ok;
         s_misc[1] = (int)(off & 0xffffffffull);
         s_misc[2] = (int)(off >> 32);
+        s_misc[3] = (int)(poff & 0xffffffffull);
+        s_misc[4] = (int)(poff >> 32);
         a.rle_off[n] = off;
         a.rle_len[n] = ok ? T + 1 : 0;
     }
     __syncthreads();
     if (!s_misc[0]) return;
     const unsigned long long off = ((unsigned long long)(unsigned)s_misc[2] << 32) | (unsigned)s_misc[1];
+    const unsigned long long poff = ((unsigned long long)(unsigned)s_misc[4] << 32) | (unsigned)s_misc[3];
     unsigned int* counts = a.pool + off;
-    unsigned int* posbuf = counts + T + 1;
+    unsigned int* posbuf = (a.pos_pool ? a.pos_pool : a.pool) + poff;
 
     // ---- pass 2: transition positions (column-major linear index p = x*H + y) ----
     for (int cx = tid; cx < nx; cx += PT) {
@@ -254,13 +267,15 @@ int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
                   int* rle_len, int* overflow) {
     return amp_paste_rle_sized(ctx, prob, det_boxes, det_batch, N, out_h, out_w, max_out_hw, in_h, in_w, nullptr, threshold, out_boxes,
-                               valid, pool, pool_cap, pool_used, rle_off, rle_len, overflow);
+                               valid, pool, pool_cap, pool_used, rle_off, rle_len, overflow, nullptr, 0, nullptr);
 }
 
 int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
                         const int* out_w, int max_out_hw, int in_h, int in_w, const int* in_hw, float threshold, float* out_boxes,
                         int* valid, unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used,
-                        unsigned long long* rle_off, int* rle_len, int* overflow) {
+                        unsigned long long* rle_off, int* rle_len, int* overflow, unsigned int* pos_scratch,
+                        unsigned long long pos_cap, unsigned long long* pos_used) {
+    AMP_REQUIRE(!pos_scratch || pos_used, "amp_paste_rle: a position scratch pool needs its counter");
     AMP_REQUIRE(ctx && prob && det_boxes && det_batch && out_h && out_w && out_boxes && valid && pool && pool_used && rle_off &&
                 rle_len && overflow, "amp_paste_rle: null argument");
     AMP_REQUIRE(max_out_hw >= 1 && max_out_hw <= 8192, "amp_paste_rle: max_out_hw=%d out of range [1,8192]", max_out_hw);
@@ -268,6 +283,7 @@ int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes,
     PasteArgs a;
     a.prob = prob; a.det_boxes = det_boxes; a.det_batch = det_batch; a.out_h = out_h; a.out_w = out_w;
     a.N = N; a.in_h = in_h; a.in_w = in_w; a.in_hw = in_hw; a.threshold = threshold;
+    a.pos_pool = pos_scratch; a.pos_cap = pos_cap; a.pos_used = pos_used;
     a.out_boxes = out_boxes; a.valid = valid; a.pool = pool; a.pool_cap = pool_cap; a.pool_used = pool_used;
     a.rle_off = rle_off; a.rle_len = rle_len; a.overflow = overflow;
     a.max_rows = max_out_hw + 2;

@@ -83,7 +83,10 @@ struct amp_model {
     std::vector<int> r_n, r_classes, r_rle_len;
     std::vector<float> r_boxes, r_scores;
     std::vector<unsigned long long> r_rle_off;
-    std::vector<uint32_t> r_pool;
+    std::vector<uint32_t> r_pool;       // (fallback when the pinned pool below could not be allocated)
+    uint32_t* h_pool = nullptr;         // pinned, host-cacheable: the run lengths of one call land here by DMA and are handed out in place
+    size_t h_pool_counts = 0;
+    const uint32_t* r_pool_ptr = nullptr;
     std::vector<int> r_out_h, r_out_w;
     float last_stage_ms[8];
     // ---- training ----
@@ -507,9 +510,10 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(o_valid, int, (size_t)std::max(N, 1));
     AMP_ALLOC(o_off, unsigned long long, (size_t)std::max(N, 1));
     AMP_ALLOC(o_len, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(pool_used, unsigned long long, 1);
+    AMP_ALLOC(pool_used, unsigned long long, 2);      // [0] run lengths (read back), [1] position scratch
     const size_t res1 = ws.off;
     AMP_ALLOC(rle_pool, unsigned int, (size_t)c.rle_pool_counts);
+    AMP_ALLOC(pos_pool, unsigned int, (size_t)c.rle_pool_counts);
     if (dry) return AMP_OK;
     AMP_REQUIRE(res1 - res0 <= m->h_res_bytes, "amp_model_infer: result staging too small");
 
@@ -520,7 +524,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_REQUIRE(max_hw <= c.max_out_hw, "amp_model_infer: output size %d exceeds cfg.max_out_hw=%d", max_hw, c.max_out_hw);
     for (int b = 0; b < B; ++b) { m->h_small[b] = out_h[b]; m->h_small[B + b] = out_w[b]; }
     AMP_HIP_CHECK(hipMemcpyAsync(d_out_hw, m->h_small, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    AMP_HIP_CHECK(hipMemsetAsync(pool_used, 0, sizeof(unsigned long long), ctx->stream));
+    AMP_HIP_CHECK(hipMemsetAsync(pool_used, 0, 2 * sizeof(unsigned long long), ctx->stream));
     if (N > 0) {
         AMP_TRY(amp_compact_dets(ctx, B, D, det_count, det_boxes, det_scores, det_classes, m_boxes, m_scores, m_classes, m_batch));
         // ---------------- mask head ----------------
@@ -536,7 +540,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
         AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
         AMP_TRY(amp_paste_rle_sized(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, T.img_hw, c.mask_threshold, o_boxes,
-                              o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1));
+                              o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1,
+                              pos_pool, (unsigned long long)c.rle_pool_counts, pool_used + 1));
         tap(m, "mask_prob", mprob, 0, {N, 28, 28});
         tap(m, "mask_rois", m_boxes, 0, {N, 4});
     }
@@ -554,12 +559,22 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         hb = (const float*)host_of(o_boxes); hs = (const float*)host_of(m_scores); hc = (const int*)host_of(m_classes);
         hv = (const int*)host_of(o_valid); hl = (const int*)host_of(o_len); ho = (const unsigned long long*)host_of(o_off);
         const unsigned long long used = *(const unsigned long long*)host_of(pool_used);
-        // only the count halves of the pool are needed, but they are interleaved with the position scratch: copy the used prefix
+        // the pool holds run lengths only (positions live in their own scratch pool): the used prefix is exactly what the caller gets
+        if (m->h_pool && used <= m->h_pool_counts) {
+            // DMA into host-cacheable pinned memory and hand that out: a pageable destination made the runtime stage the bytes and
+            // the CPU copy them once more while the GPU sat idle (0.3 ms per step for 2.5 MB)
+            if (used) AMP_HIP_CHECK(hipMemcpyAsync(m->h_pool, rle_pool, (size_t)used * 4, hipMemcpyDeviceToHost, ctx->stream));
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            m->r_pool_ptr = m->h_pool;
+        } else {
         m->r_pool.resize((size_t)used);
         // (straight into the pageable vector: reading 2 MB back out of pinned, CPU-uncached staging cost 0.8 ms per step)
         if (used) AMP_HIP_CHECK(hipMemcpy(m->r_pool.data(), rle_pool, (size_t)used * 4, hipMemcpyDeviceToHost));
+        m->r_pool_ptr = m->r_pool.data();
+        }
     } else {
         m->r_pool.clear();
+        m->r_pool_ptr = m->r_pool.data();
     }
     m->r_n.assign(B, 0);
     m->r_boxes.assign((size_t)B * D * 4, 0.f);
@@ -1090,6 +1105,9 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     (void)hipHostMalloc(&m->h_counts, (size_t)(cfg->max_batch + 8) * sizeof(int));
     m->h_res_bytes = (size_t)cfg->max_batch * cfg->detections_per_image * 48 + 16 * 256;
     (void)hipHostMalloc(&m->h_res, m->h_res_bytes);
+    // run-length staging: pinned for the DMA, non-coherent = cacheable for the host that reads it after the stream sync
+    m->h_pool_counts = (size_t)std::min<unsigned long long>(m->cfg.rle_pool_counts, (unsigned long long)64 << 20);
+    if (hipHostMalloc(reinterpret_cast<void**>(&m->h_pool), m->h_pool_counts * 4, hipHostMallocNonCoherent) != hipSuccess) { m->h_pool = nullptr; m->h_pool_counts = 0; (void)hipGetLastError(); }
     (void)hipHostMalloc(&m->h_small, (size_t)(2 * cfg->max_batch + cfg->max_batch * cfg->detections_per_image + 8) * sizeof(int));
     *out = m;
     return AMP_OK;
@@ -1106,6 +1124,7 @@ void amp_model_destroy(amp_model* m) {
     (void)hipHostFree(m->h_counts);
     (void)hipHostFree(m->h_small);
     (void)hipHostFree(m->h_res);
+    if (m->h_pool) (void)hipHostFree(m->h_pool);
     delete m;
 }
 
@@ -1392,7 +1411,7 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
     out->classes = m->r_classes.data();
     out->rle_off = m->r_rle_off.data();
     out->rle_len = m->r_rle_len.data();
-    out->rle_counts = m->r_pool.data();
+    out->rle_counts = m->r_pool_ptr;
     out->out_h = m->r_out_h.data();
     out->out_w = m->r_out_w.data();
     return AMP_OK;

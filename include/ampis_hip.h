@@ -216,11 +216,14 @@ int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const
                   const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,
                   int* rle_len, int* overflow);
-/* same; in_hw = device int [B][2]: the network-input size of each image (detector_postprocess scales by output / image size) or NULL */
+/* same; in_hw = device int [B][2]: the network-input size of each image (detector_postprocess scales by output / image size) or NULL;
+ * pos_scratch (+ capacity, device counter) = a second pool for the transition positions the run lengths are made from: `pool` then
+ * holds the run lengths only, densely (half the bytes to read back); NULL = positions behind each mask's run lengths in `pool`. */
 int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
                         const int* out_w, int max_out_hw, int in_h, int in_w, const int* in_hw, float threshold, float* out_boxes,
                         int* valid, unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used,
-                        unsigned long long* rle_off, int* rle_len, int* overflow);
+                        unsigned long long* rle_off, int* rle_len, int* overflow, unsigned int* pos_scratch,
+                        unsigned long long pos_cap, unsigned long long* pos_used);
 
 /* Stage a18: training-mode label assignment, seeded sampling and losses (+ their gradients w.r.t. the network outputs) ---- */
 int amp_anchor_labels(amp_ctx* ctx, const amp_rpn_levels* lv, int B, const float* gt_boxes, const int* gt_off, int total_gt,
