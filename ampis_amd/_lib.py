@@ -86,6 +86,7 @@ def _declare(L):
         "amp_timer_start": ([vp], i),
         "amp_prof_begin": ([vp, i], i),
         "amp_prof_end": ([vp, C.POINTER(ProfSummary)], i),
+        "amp_prof_pause": ([vp, i], i),
         "amp_timer_stop": ([vp, C.POINTER(f)], i),
         "amp_destroy": ([vp], None),
         "amp_sync": ([vp], i),
@@ -217,6 +218,9 @@ class Context:
 
     def prof_begin(self, max_launches=8192):
         check(lib().amp_prof_begin(self._h, int(max_launches)), "amp_prof_begin")
+
+    def prof_pause(self, paused=True):
+        check(lib().amp_prof_pause(self._h, int(bool(paused))), "amp_prof_pause")
 
     def prof_end(self):
         s = ProfSummary()

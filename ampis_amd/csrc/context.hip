@@ -110,6 +110,12 @@ int amp_prof_begin(amp_ctx* ctx, int max_launches) {
     return AMP_OK;
 }
 
+int amp_prof_pause(amp_ctx* ctx, int paused) {
+    AMP_REQUIRE(ctx, "amp_prof_pause: null context");
+    ctx->prof_on = !paused;
+    return AMP_OK;
+}
+
 int amp_prof_end(amp_ctx* ctx, amp_prof_summary* out) {
     AMP_REQUIRE(ctx && out, "amp_prof_end: null argument");
     ctx->prof_on = false;

@@ -33,6 +33,7 @@ PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 # register-only back-to-back v_mfma_f32_32x32x16_f16 on random operands 1655 TFLOP/s, on constant operands 2475; the fp32 MFMA holds
 # 155 either way).  Reported beside `peak`, never instead of it.
 SUSTAINED_F16_MFMA_RANDOM_TFLOPS = 1655.0
+PROF_EVERY = 5                 # HIP-event pairs around the conv launches on every 5th timed step
 
 
 def log(msg):
@@ -276,15 +277,22 @@ def main():
             step()
             log(f"[{mode}] warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
         barrier()
-        ctx.prof_begin(max_launches=steps * 96)
+        # per-launch HIP event pairs on every PROF_EVERY-th timed step: the pairs themselves cost ~5 us of idle GPU per launch (0.55 ms
+        # = 2.7 % of a step when every step carries them)
+        ctx.prof_begin(max_launches=(steps // PROF_EVERY + 1) * 96)
         t0 = time.perf_counter()
         ndet = 0
-        for _ in range(steps):
+        prof_steps = 0
+        for i in range(steps):
+            sampled = i % PROF_EVERY == 0
+            ctx.prof_pause(not sampled)
+            prof_steps += int(sampled)
             d = step()
             ndet += sum(d.n[b] for b in range(BATCH))
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         prof = ctx.prof_end()
+        prof["steps"] = prof_steps
         log(f"[{mode}] timed {steps} steps in {el:.3f} s")
         barrier()
         if world > 1:
@@ -304,7 +312,7 @@ def main():
                   "value": round(world * BATCH * args.steps / s_el, 3), "unit": "images/s", "ms_per_step": round(s_el / args.steps * 1e3, 3),
                   "roofline": {"bound": "mfma", "kernel": "conv_glds_kernel<128>", "achieved": round(s_ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(s_ach / PEAK_F32_MFMA_TFLOPS, 4),
-                               "kernel_ms_per_step": round(s_prof["ms"][0] / args.steps, 3)}}
+                               "kernel_ms_per_step": round(s_prof["ms"][0] / s_prof["steps"], 3)}}
 
     out = None
     if rank == 0:
@@ -346,9 +354,10 @@ def main():
                                              "toggling inputs; 2475 on constants), / 3 (profiles/r01/mfma_peak.json)"} if mode == "f16x3" else {}),
                          "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v8.json)",
-                         "launches_per_step": prof["launches"][0] / args.steps,
-                         "kernel_ms_per_step": round(prof["ms"][0] / args.steps, 3),
-                         "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / args.steps, 3),
+                         "launches_per_step": prof["launches"][0] / prof["steps"],
+                         "kernel_ms_per_step": round(prof["ms"][0] / prof["steps"], 3),
+                         "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / prof["steps"], 3),
+                         "events_on": f"every {PROF_EVERY}th timed step ({prof['steps']} of {args.steps} steps, {prof['launches'][0]} launches of the dominant kernel)",
                          "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
         }
 

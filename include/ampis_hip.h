@@ -65,6 +65,8 @@ typedef struct amp_prof_summary {
 } amp_prof_summary;
 int  amp_prof_begin(amp_ctx* ctx, int max_launches);
 int  amp_prof_end(amp_ctx* ctx, amp_prof_summary* out);
+/* between begin and end: stop / resume recording (the event pairs themselves cost ~5 us of idle GPU per launch: sample some steps) */
+int  amp_prof_pause(amp_ctx* ctx, int paused);
 
 /* Device memory helpers (so that hosts without torch can drive the library) ----------------- */
 int amp_malloc(amp_ctx* ctx, size_t bytes, void** out);
