@@ -105,30 +105,38 @@ class DatasetMapper:
         self._rng = np.random.default_rng(seed)
         self.force_size = None      # set by the train loader so that all images of a batch share one scale choice
 
-    def __call__(self, dataset_dict):
+    def draw(self):
+        """The random choices of the next image (scale, flip), drawn in call order from the mapper's generator.  The train loader
+        draws them in its producer thread and hands the deterministic rest (`apply`) to worker threads."""
+        c = self.cfg
+        if not self.is_train:
+            return int(c.INPUT.MIN_SIZE_TEST), False
+        sizes = c.INPUT.MIN_SIZE_TRAIN
+        sizes = (sizes,) if isinstance(sizes, int) else tuple(sizes)
+        min_size = self.force_size if self.force_size is not None else int(sizes[self._rng.integers(len(sizes))])
+        flip = str(c.INPUT.get("RANDOM_FLIP", "horizontal")) == "horizontal" and bool(self._rng.random() < 0.5)
+        return min_size, flip
+
+    def apply(self, dataset_dict, min_size, flip):
+        """Image read + ResizeShortestEdge (+ flip, ground truth): no random state, safe to run in a worker thread."""
         from .engine.defaults import read_image_bgr, resize_shortest_edge
         c = self.cfg
         img = dataset_dict["image_bgr"] if "image_bgr" in dataset_dict else read_image_bgr(dataset_dict["file_name"])
         h, w = img.shape[:2]
-        if self.is_train:
-            sizes = c.INPUT.MIN_SIZE_TRAIN
-            sizes = (sizes,) if isinstance(sizes, int) else tuple(sizes)
-            min_size = self.force_size if self.force_size is not None else int(sizes[self._rng.integers(len(sizes))])
-            max_size = int(c.INPUT.MAX_SIZE_TRAIN)
-        else:
-            min_size, max_size = int(c.INPUT.MIN_SIZE_TEST), int(c.INPUT.MAX_SIZE_TEST)
+        max_size = int(c.INPUT.MAX_SIZE_TRAIN) if self.is_train else int(c.INPUT.MAX_SIZE_TEST)
         out = resize_shortest_edge(np.ascontiguousarray(img), min_size, max_size)
         nh, nw = out.shape[:2]
         d = {k: v for k, v in dataset_dict.items() if k not in ("annotations", "image_bgr")}
         d["height"], d["width"] = h, w
-        flip = False
         if self.is_train:
-            flip = str(c.INPUT.get("RANDOM_FLIP", "horizontal")) == "horizontal" and bool(self._rng.random() < 0.5)
             if flip:
                 out = out[:, ::-1]
             d["gt"] = transform_annotations(dataset_dict.get("annotations", []), nw / w, nh / h, flip, nw, nh)
         d["image_bgr"] = np.ascontiguousarray(out)
         return d
+
+    def __call__(self, dataset_dict):
+        return self.apply(dataset_dict, *self.draw())
 
 
 def build_detection_test_loader(cfg, dataset_name, mapper=None):
@@ -167,18 +175,65 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0)
         while True:
             yield from g.permutation(len(dicts)).tolist()
 
-    def batches():
+    def plans():
+        """Per batch: the (dataset dict, scale, flip) of every image, all random choices made here, in order."""
         s = stream()
         size_rng = np.random.default_rng(seed + 7)
         k = 0
         while True:
-            batch = []
+            plan = []
             mapper.force_size = int(sizes[size_rng.integers(len(sizes))])
-            while len(batch) < per_rank:
+            while len(plan) < per_rank:
                 idx = next(s)
                 if k % world_size == rank:
-                    batch.append(mapper(dicts[idx]))
+                    plan.append((dicts[idx],) + tuple(mapper.draw()))
                 k += 1
-            yield batch
+            yield plan
 
-    return batches()
+    workers = int(cfg.DATALOADER.get("NUM_WORKERS", 0)) if "DATALOADER" in cfg else 0
+    if workers <= 0 or not hasattr(mapper, "apply"):
+        return ([mapper.apply(*t) if hasattr(mapper, "apply") else mapper(t[0]) for t in plan] for plan in plans())
+    return _prefetched(plans(), mapper, workers)
+
+
+def _prefetched(plans, mapper, workers, depth=3):
+    """DATALOADER.NUM_WORKERS threads decode / resize / transform the images of the next `depth` batches while the GPU trains on the
+    current one (detectron2 uses worker processes; PIL and numpy release the GIL for the heavy parts).  Order and content are exactly
+    those of the sequential loader: every random choice was drawn by the producer before the work was handed out."""
+    import queue
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    q = queue.Queue(maxsize=depth)
+    pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="amp-loader")
+    stop = threading.Event()
+
+    def produce():
+        try:
+            for plan in plans:
+                futs = [pool.submit(mapper.apply, *t) for t in plan]
+                while not stop.is_set():
+                    try:
+                        q.put(futs, timeout=0.2)
+                        break
+                    except queue.Full:
+                        continue
+                if stop.is_set():
+                    return
+        except BaseException as e:   # noqa: BLE001 -- surfaces in the consumer
+            q.put(e)
+
+    t = threading.Thread(target=produce, name="amp-loader-producer", daemon=True)
+    t.start()
+
+    def consume():
+        try:
+            while True:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                yield [f.result() for f in item]
+        finally:
+            stop.set()
+            pool.shutdown(wait=False, cancel_futures=True)
+
+    return consume()

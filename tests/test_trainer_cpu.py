@@ -73,6 +73,33 @@ def test_train_loader_shards_the_same_stream():
     DatasetCatalog.clear()
 
 
+def test_threaded_loader_equals_the_sequential_one():
+    """DATALOADER.NUM_WORKERS threads prefetch the next batches; scales, flips, order and pixels are those of the sequential loader."""
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog, build_detection_train_loader
+    _register(11)
+    def loader(workers):
+        cfg = get_cfg()
+        cfg.DATASETS.TRAIN = ("cpu_Train",)
+        cfg.SOLVER.IMS_PER_BATCH = 3
+        cfg.INPUT.MIN_SIZE_TRAIN = (32, 40, 48)
+        cfg.INPUT.MAX_SIZE_TRAIN = 80
+        cfg.DATALOADER.NUM_WORKERS = workers
+        return build_detection_train_loader(cfg, rank=0, world_size=1, seed=5)
+    seq, thr = loader(0), loader(3)
+    flips = 0
+    for _ in range(12):
+        a, b = next(seq), next(thr)
+        assert [d["image_id"] for d in a] == [d["image_id"] for d in b]
+        for x, y in zip(a, b):
+            assert x["image_bgr"].shape == y["image_bgr"].shape and np.array_equal(x["image_bgr"], y["image_bgr"])
+            assert np.array_equal(x["gt"]["boxes"], y["gt"]["boxes"])
+            flips += int(x["gt"]["boxes"][0][0] > 10)
+    assert 0 < flips < 36, "both orientations occur"
+    thr.close()
+    DatasetCatalog.clear()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
