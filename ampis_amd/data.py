@@ -196,6 +196,20 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0)
     return _prefetched(plans(), mapper, workers)
 
 
+class CollatedBatch(list):
+    """A batch (list of mapped dicts, what `model(batch)` takes) that also carries its stacked frame, per-image sizes and flattened
+    annotations, prepared off the training thread."""
+    collated = None
+
+
+def _collate(futures):
+    batch = CollatedBatch(f.result() for f in futures)
+    if all("gt" in d for d in batch):
+        from .engine.defaults import TrainModel
+        batch.collated = TrainModel.collate(batch)
+    return batch
+
+
 def _prefetched(plans, mapper, workers, depth=3):
     """DATALOADER.NUM_WORKERS threads decode / resize / transform the images of the next `depth` batches while the GPU trains on the
     current one (detectron2 uses worker processes; PIL and numpy release the GIL for the heavy parts).  Order and content are exactly
@@ -205,12 +219,13 @@ def _prefetched(plans, mapper, workers, depth=3):
     from concurrent.futures import ThreadPoolExecutor
     q = queue.Queue(maxsize=depth)
     pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="amp-loader")
+    collator = ThreadPoolExecutor(max_workers=1, thread_name_prefix="amp-collate")   # its own thread: it waits on the pool's futures
     stop = threading.Event()
 
     def produce():
         try:
             for plan in plans:
-                futs = [pool.submit(mapper.apply, *t) for t in plan]
+                futs = collator.submit(_collate, [pool.submit(mapper.apply, *t) for t in plan])
                 while not stop.is_set():
                     try:
                         q.put(futs, timeout=0.2)
@@ -231,9 +246,10 @@ def _prefetched(plans, mapper, workers, depth=3):
                 item = q.get()
                 if isinstance(item, BaseException):
                     raise item
-                yield [f.result() for f in item]
+                yield item.result()
         finally:
             stop.set()
             pool.shutdown(wait=False, cancel_futures=True)
+            collator.shutdown(wait=False, cancel_futures=True)
 
     return consume()

@@ -168,14 +168,22 @@ class TrainModel:
         sizes = None if (min(hs) == H and min(ws) == W) else list(zip(hs, ws))
         return imgs, sizes
 
+    @staticmethod
+    def collate(batch):
+        """Common frame + per-image sizes + flattened annotations of a batch (what the C ABI takes).  The train loader does this in
+        its worker threads and leaves the result on the batch (`CollatedBatch.collated`); `__call__` does it itself otherwise."""
+        from ..model import PackedGt
+        imgs, sizes = TrainModel.stack(batch)
+        return imgs, sizes, PackedGt([d["gt"] for d in batch])
+
     def __call__(self, batch, backward=False, seed=None):
         assert self.training, "TrainModel is the training-mode surface; use DefaultPredictor for inference"
-        imgs, sizes = self.stack(batch)
+        imgs, sizes, gt = getattr(batch, "collated", None) or self.collate(batch)
         self.net.set_image_sizes(sizes)
         if seed is None:
             self._seed += 1
             seed = 0x5EED0000 + self._seed
-        return self.net.forward_losses(imgs, [d["gt"] for d in batch], seed=seed, backward=backward)
+        return self.net.forward_losses(imgs, gt, seed=seed, backward=backward)
 
 
 class DefaultTrainer:
