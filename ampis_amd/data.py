@@ -103,7 +103,7 @@ class DatasetMapper:
         self.cfg = cfg
         self.is_train = is_train
         self._rng = np.random.default_rng(seed)
-        self.force_size = None      # set by the train loader so that all images of a batch share one scale choice
+        self.force_size = None      # a fixed scale instead of the MIN_SIZE_TRAIN draw (tests)
 
     def draw(self):
         """The random choices of the next image (scale, flip), drawn in call order from the mapper's generator.  The train loader
@@ -157,8 +157,9 @@ def build_detection_test_loader(cfg, dataset_name, mapper=None):
 
 def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0):
     """Infinite iterator of per-rank batches (lists of mapped dicts). TrainingSampler semantics: an infinite stream of seeded
-    shuffles of the dataset indices, rank r takes elements r, r+world, ...; IMS_PER_BATCH is the GLOBAL batch.  All images of
-    one batch use the same MIN_SIZE_TRAIN choice so they can be stacked (detectron2 draws it per image and pads)."""
+    shuffles of the dataset indices, rank r takes elements r, r+world, ...; IMS_PER_BATCH is the GLOBAL batch.  MIN_SIZE_TRAIN is
+    drawn per image, as detectron2's ResizeShortestEdge does; a batch of differently sized images is stacked top-left into a common
+    frame with its per-image sizes (TrainModel.stack, amp_model_set_image_sizes)."""
     names = cfg.DATASETS.TRAIN
     dicts = [d for n in names for d in DatasetCatalog.get(n)]
     dicts = [d for d in dicts if len(d.get("annotations", [])) > 0]       # FILTER_EMPTY_ANNOTATIONS
@@ -167,9 +168,6 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0)
     assert total % world_size == 0, "SOLVER.IMS_PER_BATCH must be divisible by the number of GPUs"
     per_rank = total // world_size
     mapper = mapper or DatasetMapper(cfg, True, seed=seed + 1000 * rank)
-    sizes = cfg.INPUT.MIN_SIZE_TRAIN
-    sizes = (sizes,) if isinstance(sizes, int) else tuple(sizes)
-
     def stream():
         g = np.random.default_rng(seed)
         while True:
@@ -178,11 +176,9 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0)
     def plans():
         """Per batch: the (dataset dict, scale, flip) of every image, all random choices made here, in order."""
         s = stream()
-        size_rng = np.random.default_rng(seed + 7)
         k = 0
         while True:
             plan = []
-            mapper.force_size = int(sizes[size_rng.integers(len(sizes))])
             while len(plan) < per_rank:
                 idx = next(s)
                 if k % world_size == rank:

@@ -96,6 +96,8 @@ def test_threaded_loader_equals_the_sequential_one():
             assert np.array_equal(x["gt"]["boxes"], y["gt"]["boxes"])
             flips += int(x["gt"]["boxes"][0][0] > 10)
     assert 0 < flips < 36, "both orientations occur"
+    shapes = {d["image_bgr"].shape[0] for _ in range(6) for d in next(seq)}
+    assert len(shapes) > 1, "MIN_SIZE_TRAIN is drawn per image: one batch may mix scales"
     thr.close()
     DatasetCatalog.clear()
 
