@@ -106,3 +106,41 @@ def test_train_validate_checkpoint_predict(tmp_path):
     outs = predictor(val[0]["image_bgr"])
     assert outs["instances"].image_size == (192, 256)
     DatasetCatalog.clear()
+
+
+def test_trainer_with_mixed_scales(tmp_path):
+    """MIN_SIZE_TRAIN with several choices: the scale is drawn per image, batches mix sizes and go through the per-image-size path;
+    training still runs, learns and checkpoints."""
+    from ampis_amd import checkpoint, model_zoo, params as P
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog, MetadataCatalog
+    from ampis_amd.engine import DefaultTrainer
+    DatasetCatalog.clear()
+    train = _ddicts(4, 192, 256, 70)
+    DatasetCatalog.register("particle_Train", lambda: train)
+    MetadataCatalog.get("particle_Train").set(thing_classes=["particle"])
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.DATASETS.TRAIN, cfg.DATASETS.TEST = ("particle_Train",), ("particle_Train",)
+    cfg.SOLVER.IMS_PER_BATCH, cfg.SOLVER.MAX_ITER, cfg.SOLVER.CHECKPOINT_PERIOD = 3, 8, 100
+    cfg.SOLVER.BASE_LR, cfg.SOLVER.WARMUP_ITERS = 0.001, 2
+    os.makedirs(tmp_path / "models", exist_ok=True)
+    checkpoint.save_checkpoint(tmp_path / "models" / "init.pth", P.init_params(1, seed=4, style="spread"))
+    cfg.MODEL.WEIGHTS, cfg.MODEL.ROI_HEADS.NUM_CLASSES = str(tmp_path / "models" / "init.pth"), 1
+    cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (128, 160, 192), 256
+    cfg.OUTPUT_DIR = str(tmp_path / "out")
+    trainer = DefaultTrainer(cfg)
+    trainer.resume_or_load(resume=False)
+    seen = []
+    orig = trainer.model.__call__
+    import types
+    def spy(self, batch, **kw):
+        seen.append(sorted({d["image_bgr"].shape[:2] for d in batch}))
+        return orig(batch, **kw)
+    trainer.model.__class__ = type("Spy", (trainer.model.__class__,), {"__call__": spy})
+    trainer.train()
+    tl = [v for v, _ in trainer.storage.history("total_loss")]
+    assert len(tl) == 8 and all(np.isfinite(tl))
+    assert any(len(s) > 1 for s in seen), "at least one batch mixed scales"
+    assert os.path.isfile(os.path.join(cfg.OUTPUT_DIR, "model_final.pth"))
+    DatasetCatalog.clear()
