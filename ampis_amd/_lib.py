@@ -48,7 +48,7 @@ class Gt(C.Structure):
 
 
 class ProfSummary(C.Structure):
-    _fields_ = [("launches", C.c_longlong * 2), ("ms", C.c_double * 2), ("flops", C.c_double * 2), ("truncated", C.c_int)]
+    _fields_ = [("launches", C.c_longlong * 3), ("ms", C.c_double * 3), ("flops", C.c_double * 3), ("truncated", C.c_int)]
 
 
 class Dets(C.Structure):
@@ -163,6 +163,18 @@ def _declare(L):
         "amp_small_k_dgrad": ([vp, vp, i, i, vp, i, vp, vp, C.c_size_t], i),
         "amp_deconv_grad_transpose": ([vp, vp, vp, i, i, i, i], i),
         "amp_sgd_update": ([vp, vp, vp, vp, C.c_size_t, f, f, f, f], i),
+        "amp_comm_unique_id": ([vp], i),
+        "amp_comm_init": ([vp, i, i, vp], i),
+        "amp_comm_destroy": ([vp], i),
+        "amp_comm_info": ([vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)], i),
+        "amp_barrier": ([vp], i),
+        "amp_allreduce": ([vp, vp, C.c_size_t, i, i], i),
+        "amp_comm_stats": ([vp, C.POINTER(f), C.POINTER(f)], i),
+        "amp_grad_bucket_of": ([C.c_char_p], i),
+        "amp_plan_grad_buckets": ([i, vp, vp, vp, C.c_size_t, i, vp, vp, vp, C.POINTER(i)], i),
+        "amp_model_grad_buckets": ([vp, i, vp, vp, vp, C.POINTER(i)], i),
+        "amp_model_set_grad_overlap": ([vp, i], i),
+        "amp_model_allreduce_grads": ([vp], i),
         "amp_model_get_tap": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_longlong)], i),
     }
     for name, (args, res) in sig.items():
@@ -226,6 +238,46 @@ class Context:
         s = ProfSummary()
         check(lib().amp_prof_end(self._h, C.byref(s)), "amp_prof_end")
         return {"launches": list(s.launches), "ms": list(s.ms), "flops": list(s.flops), "truncated": bool(s.truncated)}
+
+    # ---- RCCL communicator of this context (include/ampis_hip.h "Multi-GPU exchange") ----
+    COMM_ID_BYTES = 128
+    F32, F64, I32 = 0, 1, 2
+    SUM, MAX = 0, 1
+
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128 bytes every rank passes to comm_init (hand them over by any side channel)."""
+        buf = (C.c_ubyte * Context.COMM_ID_BYTES)()
+        check(lib().amp_comm_unique_id(buf), "amp_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == self.COMM_ID_BYTES
+        buf = (C.c_ubyte * self.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().amp_comm_init(self._h, int(rank), int(world), buf), "amp_comm_init")
+
+    def comm_info(self):
+        """(rank, world, rccl_version); world == 0 when the context has no communicator."""
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        check(lib().amp_comm_info(self._h, C.byref(r), C.byref(w), C.byref(v)), "amp_comm_info")
+        return r.value, w.value, v.value
+
+    def comm_destroy(self):
+        check(lib().amp_comm_destroy(self._h), "amp_comm_destroy")
+
+    def barrier(self):
+        check(lib().amp_barrier(self._h), "amp_barrier")
+
+    def allreduce(self, dptr, count, dtype=0, op=0):
+        check(lib().amp_allreduce(self._h, C.c_void_p(int(dptr)), int(count), int(dtype), int(op)), "amp_allreduce")
+
+    def comm_stats(self):
+        e, s = C.c_float(), C.c_float()
+        check(lib().amp_comm_stats(self._h, C.byref(e), C.byref(s)), "amp_comm_stats")
+        return {"exposed_ms": e.value, "span_ms": s.value}
+
+    def d2h(self, arr, src):
+        check(lib().amp_memcpy_d2h(self._h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(int(src)), arr.nbytes), "amp_memcpy_d2h")
 
     def malloc(self, nbytes):
         p = C.c_void_p()

@@ -30,6 +30,8 @@ void set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
+#define AMP_TRY_STATUS(expr) do { int _s = (expr); if (_s != AMP_OK) return _s; } while (0)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Bijective XCD-aware block remap: blocks b and b+8 share an XCD under the observed
@@ -66,6 +68,7 @@ __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(
 }  // namespace amp
 
 #include <vector>
+struct amp_comm;   // comm.hip: RCCL communicator + its stream and events
 struct amp_prof_rec { hipEvent_t e0, e1; double flops; int variant; };
 struct amp_ctx {
     int device;
@@ -85,6 +88,7 @@ struct amp_ctx {
     void* topk_scratch = nullptr;          // chunk candidates of amp_rpn_topk (levels cut into several workgroups)
     size_t topk_bytes = 0;
     size_t split_bytes = 0;
+    amp_comm* comm = nullptr;              // amp_comm_init: RCCL communicator of this context (one rank per context)
 };
 
 namespace amp {
@@ -93,6 +97,11 @@ namespace amp {
 // by 2^s before the operand split and the sum by 2^-s (data gradients: tiny values would otherwise sit in the f16 subnormals).
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
              const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0);
+// comm.hip (all no-ops / errors are explicit when the context has no communicator)
+int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr);   // grouped in-place SUM, after the compute stream's work so far
+int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete on the compute stream (exposed-time reference)
+int comm_wait_done(amp_ctx* ctx);              // compute stream waits (device side) for every collective issued so far
+int comm_agree_flag(amp_ctx* ctx, int* d_flag); // MAX of a device int over the ranks, complete on return
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
                   float* out, int* level_out, int out_split);   // out_split = 1: the pooled tensor in the split operand format
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3

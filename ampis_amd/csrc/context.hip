@@ -125,7 +125,7 @@ int amp_prof_end(amp_ctx* ctx, amp_prof_summary* out) {
         const amp_prof_rec& r = ctx->prof_pool[i];
         float ms = 0.f;
         AMP_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
-        const int v = r.variant ? 1 : 0;
+        const int v = (r.variant >= 0 && r.variant < 3) ? r.variant : 1;
         out->launches[v] += 1;
         out->ms[v] += ms;
         out->flops[v] += r.flops;
@@ -136,6 +136,7 @@ int amp_prof_end(amp_ctx* ctx, amp_prof_summary* out) {
 
 void amp_destroy(amp_ctx* ctx) {
     if (!ctx) return;
+    (void)amp_comm_destroy(ctx);
     for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);

@@ -107,6 +107,10 @@ struct amp_model {
     uint8_t* img_stage = nullptr;       // device copy of host images (amp_model_infer / forward_losses with imgs_on_host), grown on demand
     size_t img_stage_bytes = 0;
     std::vector<int> img_hw;            // optional per-image valid sizes for the next batches
+    // ---- gradient exchange (comm.hip): merged arena ranges per bucket, in the order the backward pass completes them ----
+    std::vector<int> gb_bucket;
+    std::vector<size_t> gb_off, gb_n;
+    int grad_overlap = -1;              // -1: on when the context has a communicator; 0 / 1: amp_model_set_grad_overlap
 };
 
 static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
@@ -207,6 +211,18 @@ void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_li
     T* var = ws.get<T>((size_t)(n));                                                          \
     if (!var) { amp::set_error("amp_model: workspace exhausted allocating %s (%zu bytes, cap %zu)", #var, \
                                (size_t)(n) * sizeof(T), ws.cap); return AMP_ERR_NOMEM; }
+
+// Hand bucket b of the gradient arena to RCCL: everything the backward pass has launched so far is ordered before it, everything
+// it launches from here on overlaps it.  No-op without a communicator or with the overlap switched off.
+int issue_bucket(amp_model* m, int b) {
+    amp_ctx* ctx = m->ctx;
+    if (m->ws.dry || !ctx->comm || m->grad_overlap == 0) return AMP_OK;
+    size_t off[64], n[64];
+    int nr = 0;
+    for (size_t i = 0; i < m->gb_bucket.size() && nr < 64; ++i)
+        if (m->gb_bucket[i] == b) { off[nr] = m->gb_off[i]; n[nr] = m->gb_n[i]; ++nr; }
+    return amp::comm_allreduce_ranges(ctx, m->garena, off, n, nr);
+}
 
 struct Trunk {
     float* feat[5];
@@ -781,6 +797,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // Gradients of the five losses (each with weight 1) w.r.t. every trainable parameter, into m->garena (same offsets as the
     // parameters).  Stem and res2 are frozen (FREEZE_AT = 2), FrozenBN has no parameters; its scale is folded into the weight
     // transforms (data gradients) and the wgrad reduce (weight gradients).
+    if (!dry) AMP_TRY(amp::comm_wait_done(ctx));    // a previous exchange of this arena (a step without sgd_step, a re-run) must have finished
     const size_t WG_SCRATCH = (size_t)64 << 20;     // floats: split-K slabs of the largest layer
     const size_t WT_SCRATCH = (size_t)13 << 20;     // floats: transformed weights of the largest layer (fc1: 12.85 M)
     AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
@@ -865,6 +882,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_HIP_CHECK(hipMemsetAsync(GB(cw), 0, (size_t)cw.cout * 4, ctx->stream));
         }
     }
+    AMP_TRY(issue_bucket(m, 0));
 
     // ---- box head ----
     AMP_ALLOC(d_fc2, float, (size_t)R * 1024);
@@ -885,6 +903,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
         AMP_TRY(amp_roi_align_bwd(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled));
     }
+    AMP_TRY(issue_bucket(m, 1));
 
     // ---- RPN head (shared weights: gradients accumulate over the 5 levels) ----
     for (int l = 0; l < 5; ++l) {
@@ -899,6 +918,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(bgrad(cconv, d_t, (long long)B * T.fh[l] * T.fw[l], l > 0));
         AMP_TRY(dgrad(cconv, d_t, B, T.fh[l], T.fw[l], 1, d_feat[l], nullptr, d_feat[l]));   // accumulate in place
     }
+    AMP_TRY(issue_bucket(m, 2));
 
     // ---- FPN ----
     if (!dry) AMP_TRY(amp_subsample2_bwd(ctx, d_feat[4], d_feat[3], B, T.fh[3], T.fw[3], 256));    // p6 = p5[::2, ::2]
@@ -929,6 +949,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         if (l >= 3) AMP_TRY(dgrad(cl, d_lat, B, fh_, fw_, 0, nullptr, nullptr, d_res[s_]));
         d_lat_prev = d_lat_next;
     }
+    AMP_TRY(issue_bucket(m, 3));
 
     // ---- ResNet res5 .. res3 (reverse block order) ----
     float* dcur = nullptr;
@@ -992,8 +1013,12 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             dcur = d_in;
             dcur_masked = fuse;
         }
+        if (bi == 0 || m->blocks[bi - 1].stage != ba.stage) AMP_TRY(issue_bucket(m, 7 - ba.stage));   // res5 -> 4, res4 -> 5, res3 -> 6
     }
-    if (!dry) m->grads_valid = true;
+    if (!dry) {
+        if (m->grad_overlap != 0) AMP_TRY(amp::comm_mark_producer_end(ctx));
+        m->grads_valid = true;
+    }
     return AMP_OK;
 }
 
@@ -1353,8 +1378,52 @@ int amp_model_finalize(amp_model* m) {
         const bool has_bn = m->host_raw.count(key + ".norm.weight") != 0;
         if (!has_bn && cw.shift) m->trainable.push_back({cw.shift, (size_t)cw.cout});
     }
+    {   // gradient-exchange plan: one entry per trainable tensor -> merged ranges per bucket
+        std::vector<int> tb;
+        std::vector<size_t> to, tn;
+        for (auto& kv : m->conv) {
+            const int b = amp_grad_bucket_of(kv.first.c_str());
+            if (b < 0) continue;
+            const ConvW& cw = kv.second;
+            tb.push_back(b); to.push_back((size_t)(cw.w - m->parena)); tn.push_back((size_t)cw.cout * cw.kh * cw.kw * (cw.groups > 1 ? 64 : cw.cin));
+            if (!m->host_raw.count(kv.first + ".norm.weight") && cw.shift) { tb.push_back(b); to.push_back((size_t)(cw.shift - m->parena)); tn.push_back((size_t)cw.cout); }
+        }
+        const int cap = 64 * AMP_GRAD_BUCKETS;
+        m->gb_bucket.assign(cap, 0); m->gb_off.assign(cap, 0); m->gb_n.assign(cap, 0);
+        int cnt = 0;
+        // gaps bridged: the 64-float alignment padding and the FrozenBN scale / shift vectors between two weights (gradient 0)
+        AMP_TRY(amp_plan_grad_buckets((int)tb.size(), tb.data(), to.data(), tn.data(), 64, cap, m->gb_bucket.data(), m->gb_off.data(), m->gb_n.data(), &cnt));
+        m->gb_bucket.resize(cnt); m->gb_off.resize(cnt); m->gb_n.resize(cnt);
+    }
     m->finalized = true;
     return AMP_OK;
+}
+
+int amp_model_grad_buckets(amp_model* m, int cap, int* out_bucket, size_t* out_off, size_t* out_n, int* out_count) {
+    AMP_REQUIRE(m && out_bucket && out_off && out_n && out_count, "amp_model_grad_buckets: null argument");
+    AMP_REQUIRE(m->finalized, "amp_model_grad_buckets: call amp_model_finalize first");
+    AMP_REQUIRE((int)m->gb_bucket.size() <= cap, "amp_model_grad_buckets: %zu ranges, capacity %d", m->gb_bucket.size(), cap);
+    for (size_t i = 0; i < m->gb_bucket.size(); ++i) { out_bucket[i] = m->gb_bucket[i]; out_off[i] = m->gb_off[i]; out_n[i] = m->gb_n[i]; }
+    *out_count = (int)m->gb_bucket.size();
+    return AMP_OK;
+}
+
+int amp_model_set_grad_overlap(amp_model* m, int mode) {
+    AMP_REQUIRE(m && (mode == 0 || mode == 1), "amp_model_set_grad_overlap: bad argument");
+    m->grad_overlap = mode;
+    return AMP_OK;
+}
+
+int amp_model_allreduce_grads(amp_model* m) {
+    AMP_REQUIRE(m && m->garena && m->ctx->comm, "amp_model_allreduce_grads: needs cfg.train_enable and a communicator on the context");
+    AMP_REQUIRE(m->grads_valid, "amp_model_allreduce_grads: no gradients (call amp_model_forward_backward first)");
+    const int keep = m->grad_overlap;
+    m->grad_overlap = 1;
+    int st = AMP_OK;
+    for (int b = 0; b < AMP_GRAD_BUCKETS && st == AMP_OK; ++b) st = issue_bucket(m, b);
+    if (st == AMP_OK) st = amp::comm_mark_producer_end(m->ctx);
+    m->grad_overlap = keep;
+    return st;
 }
 
 static int stage_images(amp_model* m, const uint8_t* host, size_t bytes) {
@@ -1433,6 +1502,7 @@ int amp_model_forward_backward(amp_model* m, const uint8_t* imgs_bgr, int imgs_o
 int amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale) {
     AMP_REQUIRE(m && m->garena && m->varena, "amp_model_sgd_step: the model was created without cfg.train_enable");
     AMP_REQUIRE(m->grads_valid, "amp_model_sgd_step: no gradients (call amp_model_forward_backward first)");
+    AMP_TRY(amp::comm_wait_done(m->ctx));    // the gradient exchange (if any) completes before the first update kernel, on the device
     for (auto& t : m->trainable)
         AMP_TRY(amp_sgd_update(m->ctx, t.p, m->garena + (t.p - m->parena), m->varena + (t.p - m->parena), t.n, lr, momentum, weight_decay, grad_scale));
     m->grads_valid = false;
@@ -1468,6 +1538,8 @@ static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, 
     m->ctx->conv_mode = mode;
     if (st == AMP_OK && mode == AMP_CONV_F16X3) {   // an activation beyond the fp16 range: the step again, entirely on fp32 MFMA
         int flag = 0;
+        // with a communicator every rank takes the SAME decision (MAX of the flag): the re-run issues collectives too
+        if (backward) AMP_TRY(amp::comm_agree_flag(m->ctx, m->ctx->d_conv_flag));
         if (amp_conv_range_flag(m->ctx, 1, &flag) == AMP_OK && flag) {
             if (m->f32_reruns++ == 0)
                 fprintf(stderr, "[ampis_hip] an activation exceeded the fp16 range of AMP_CONV_F16X3; re-running the step in AMP_CONV_F32\n");

@@ -531,11 +531,23 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
     a.rowtab = rowtab;
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
+    amp_prof_rec* rec = nullptr;      // live profile (amp_prof_begin): slot 2 = the weight-gradient MFMA kernel alone
+    if (ctx->prof_on) {
+        if (ctx->prof_used < ctx->prof_pool.size()) {
+            rec = &ctx->prof_pool[ctx->prof_used++];
+            rec->flops = 2.0 * (double)M * (double)a.N * (double)a.Kp;
+            rec->variant = 2;
+            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
+        } else {
+            ctx->prof_truncated = true;
+        }
+    }
     if (ctx->conv_mode == AMP_CONV_F16X3) {
         launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag);   // the fp32 kernel needs no shift
     } else {
         hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
     }
+    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     const size_t nk = (size_t)a.N * a.Kp;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, ctx->stream, scratch,
                        a.nsplit, nk, a.Kp, scale, grad, accumulate);

@@ -189,8 +189,9 @@ class TrainModel:
 class DefaultTrainer:
     """detectron2's DefaultTrainer surface (notebook cell 22; subclassed by AmpisTrainer, ampis/data_utils.py:135-177):
     DefaultTrainer(cfg) -> .resume_or_load(resume=False) -> .train(); .model, .cfg, .iter, .max_iter, .storage, build_hooks().
-    One process per GPU; with torch.distributed initialised (backend nccl = RCCL) each rank trains on its shard of the global
-    batch and the flat gradient arena is all-reduced before the SGD step."""
+    One process per GPU (engine.launch starts them); with torch.distributed initialised each rank trains on its shard of the
+    global batch, and the gradient arena is all-reduced bucket by bucket over RCCL while the backward pass is still running
+    (utils/comm.py; torch.distributed only hands the RCCL id to the ranks)."""
 
     def __init__(self, cfg):
         from ..data import build_detection_train_loader
@@ -204,6 +205,8 @@ class DefaultTrainer:
         self.num_classes = int(cfg.MODEL.ROI_HEADS.NUM_CLASSES)
         dev = _device_index(cfg.MODEL.DEVICE) if ":" in str(cfg.MODEL.DEVICE) else (int(os.environ.get("LOCAL_RANK", "0")) if not str(cfg.MODEL.DEVICE).startswith("cpu") else _device_index(cfg.MODEL.DEVICE))
         self.ctx = _lib.Context(dev)
+        if self.world_size > 1 and comm.backend() == "rccl":
+            comm.attach_rccl(self.ctx)       # the gradient exchange and synchronize() run on RCCL inside the library from here on
         self.arch = P.arch_from_cfg(cfg)     # a grouped (ResNeXt) backbone is inference-only: amp_model_create refuses to train it
         self.params = P.init_params(self.num_classes, seed=max(int(cfg.get("SEED", -1)), 0), style="d2", arch=self.arch)
         self._net = None

@@ -181,6 +181,19 @@ class MaskRCNN:
         check(lib().amp_model_grad_arena(self._h, C.byref(p), C.byref(n)), "amp_model_grad_arena")
         return p.value, n.value
 
+    def grad_buckets(self):
+        """[(bucket, offset, n)] float ranges of the gradient arena in the order the backward pass completes (and exchanges) them."""
+        cap = 512
+        b, o, n, cnt = (C.c_int * cap)(), (C.c_size_t * cap)(), (C.c_size_t * cap)(), C.c_int()
+        check(lib().amp_model_grad_buckets(self._h, cap, b, o, n, C.byref(cnt)), "amp_model_grad_buckets")
+        return [(b[i], o[i], n[i]) for i in range(cnt.value)]
+
+    def set_grad_overlap(self, on):
+        check(lib().amp_model_set_grad_overlap(self._h, int(bool(on))), "amp_model_set_grad_overlap")
+
+    def allreduce_grads(self):
+        check(lib().amp_model_allreduce_grads(self._h), "amp_model_allreduce_grads")
+
     def get_tensor(self, name, grad=False):
         """Current value (or gradient) of a parameter in detectron2 / torch layout."""
         from . import params as P

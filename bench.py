@@ -1,21 +1,66 @@
 """bench.py — images/s of Mask R-CNN R50-FPN inference on synthetic 1024x1024 micrographs (BASELINE.json configs[1]).
 
-python bench.py --gpus N --steps K --warmup W       (N > 1: launched by torch.distributed.run, one rank per GPU)
+python bench.py --gpus N --steps K --warmup W       (N > 1: one rank per GPU -- started by torch.distributed.run, or by bench.py itself when RANK is not set)
 
 A step = one pass of the hot path (amp_model_infer: preprocess -> backbone -> FPN -> RPN -> proposals -> box head ->
 detections -> mask head -> paste -> RLE counts on the host) over one batch of 8 images that is already resident in HBM.
-Image-parallel replicas: every rank runs the same per-GPU batch, no data-path collective ("weak" scaling); RCCL is only
+Image-parallel replicas: every rank runs the same per-GPU batch, no data-path collective ("weak" scaling); RCCL (through the C ABI) is only
 used for the barrier and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=10)
+    ap.add_argument("--train-steps", type=int, default=50, help="timed training steps of the secondary `train` object (0 = skip)")
+    ap.add_argument("--train-warmup", type=int, default=10)
+    ap.add_argument("--x101-steps", type=int, default=5, help="timed steps of the secondary `x101_2048` object (0 = skip)")
+    ap.add_argument("--no-strict", action="store_true", help="skip the fp32-MFMA reference run of the headline workload")
+    ap.add_argument("--no-two-pipelines", action="store_true", help="skip the secondary `two_pipelines` object")
+    ap.add_argument("--no-host-inclusive", action="store_true", help="skip the secondary `host_inclusive` object")
+    ap.add_argument("--train-timeout", type=float, default=420.0, help="watchdog for the secondary legs, seconds")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (no RANK in the environment): start the N ranks ourselves, one process per
+    GPU, through torch.distributed.run -- BEFORE this process has made any GPU call (a process that has initialised HIP must not
+    be replaced or forked) -- pass their output through and exit with their code."""
+    import socket
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] --gpus {args.gpus} without RANK in the environment: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+ARGS = None
+if __name__ == "__main__":
+    ARGS = parse_args()
+    if ARGS.gpus > 1 and "RANK" not in os.environ:
+        self_launch(ARGS)
+    if os.environ.get("AMP_BENCH_DRY_LAUNCH"):     # tests/test_comm_cpu.py: prove the self-launch on a host without GPUs
+        print(f"dry-launch rank {os.environ.get('RANK', '0')} of {os.environ.get('WORLD_SIZE', '1')} local {os.environ.get('LOCAL_RANK', '0')}", flush=True)
+        sys.exit(0)
 
 import numpy as np
 import torch
@@ -78,10 +123,60 @@ def cpu_baseline(n_images):
 
 
 TRAIN_BATCH = 16
+PROFILE_DIRS = ("r02", "r01")      # committed rocprofv3 --pmc summaries (tools/profile_round.sh): newest first
 
 
-def train_leg(ctx, infer_model, dev, rank, world, steps, barrier):
-    """images/s of a full training step; whole-job aggregate over the ranks (weak scaling, global batch 16 x N)."""
+def pmc_traffic(kernel_keys):
+    """HBM bytes per launch of the first of `kernel_keys` found in the committed PMC summaries (profiles/rNN/pmc_summary*.json)."""
+    import glob
+    for d in PROFILE_DIRS:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")), reverse=True):
+            try:
+                k = json.load(open(f))["kernels"]
+            except Exception:
+                continue
+            for key in kernel_keys:
+                if key in k and k[key].get("hbm_bytes_per_launch"):
+                    return k[key]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), key
+    return None, None, None
+
+
+class Ranks:
+    """Barrier and max-over-ranks for the timed regions.  N > 1: the device collectives are the library's own RCCL calls
+    (amp_barrier / amp_allreduce on the context's communicator); torch.distributed (gloo) only carried the RCCL id.
+    AMP_BENCH_REHEARSAL=1 (two ranks sharing the card of a one-GPU box, where RCCL refuses to run): gloo on host values."""
+
+    def __init__(self, ctx, dev, world, staged):
+        self.ctx, self.dev, self.world, self.staged = ctx, dev, world, staged
+        self._d = ctx.malloc(8) if (world > 1 and not staged) else None
+
+    def barrier(self):
+        if self.world > 1:
+            if self.staged:
+                torch.distributed.barrier()
+            else:
+                self.ctx.barrier()
+        torch.cuda.synchronize(self.dev)
+
+    def max(self, value):
+        if self.world == 1:
+            return value
+        if self.staged:
+            t = torch.tensor([value], dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        a = np.array([value], dtype=np.float64)
+        self.ctx.h2d(self._d, a)
+        self.ctx.allreduce(self._d, 1, self.ctx.F64, self.ctx.MAX)
+        self.ctx.sync()
+        self.ctx.d2h(a, self._d)
+        return float(a[0])
+
+
+def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
+    """images/s of a full training step; whole-job aggregate over the ranks (weak scaling, global batch 16 x N).  The gradient
+    exchange is the library's bucketed RCCL all-reduce, issued from inside amp_model_forward_backward as the backward pass
+    completes each bucket."""
     from ampis_amd.utils import comm
     infer_model.close()                       # give its workspace back before the 40 GiB training workspace
     log(f"rank {rank}: creating the training model (local batch {TRAIN_BATCH})")
@@ -95,6 +190,14 @@ def train_leg(ctx, infer_model, dev, rank, world, steps, barrier):
     d_imgs = ctx.malloc(imgs.nbytes)
     ctx.h2d(d_imgs, imgs)
     packed = PackedGt(gts)
+    if world == 1 and ctx.comm_info()[1] == 0 and not ranks.staged:
+        # one rank: still bring RCCL up (a communicator of size 1), so that the N=1 line measures the step WITH the exchange
+        # machinery the N>1 runs use (bucket events, communication stream, the wait in front of SGD)
+        try:
+            comm.attach_rccl(ctx)
+        except Exception as e:   # noqa: BLE001
+            log(f"rank {rank}: RCCL communicator of size 1 not available ({e}); training step timed without the exchange machinery")
+    has_comm = ctx.comm_info()[1] > 0
 
     def step(i):
         losses = model.forward_losses(None, packed, seed=i, backward=True, device_ptr=d_imgs, shape=(TRAIN_BATCH, SIZE, SIZE))
@@ -102,33 +205,63 @@ def train_leg(ctx, infer_model, dev, rank, world, steps, barrier):
         model.sgd_step(1e-3, 0.9, 1e-4, grad_scale=scale)
         return losses
 
-    for i in range(2):
+    for i in range(warmup):
         step(i)
-    barrier()
+    ranks.barrier()
+    ctx.prof_begin(max_launches=(steps // PROF_EVERY + 1) * 512)
+    exposed, span, nstat = 0.0, 0.0, 0
     t0 = time.perf_counter()
+    prof_steps = 0
     for i in range(steps):
-        losses = step(10 + i)
+        sampled = i % PROF_EVERY == 0
+        ctx.prof_pause(not sampled)
+        prof_steps += int(sampled)
+        losses = step(1000 + i)
+        if has_comm and sampled:      # event times of this step's exchange (waits for the step: only on the sampled steps)
+            st = ctx.comm_stats()
+            exposed += st["exposed_ms"]; span += st["span_ms"]; nstat += 1
     ctx.sync()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
-    barrier()
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+    prof = ctx.prof_end()
+    ranks.barrier()
+    el = ranks.max(el)
+    buckets = model.grad_buckets()
     model.close()
-    return {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
-            "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
-            "steps": steps, "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
-            "dtype": "f32 (forward, data-gradient and weight-gradient convs: f16x3 split-operand MFMA, fp32 accumulate)"
-                     if ctx.conv_mode == ctx.CONV_F16X3 else "f32",
-            "workload": "BASELINE configs[2] (N=1) / configs[3] (N=8): K=2, ~480 GT instances/image (polygons), 256 anchors + 512 RoIs "
-                        "sampled per image, seeded random-init weights, uint8 images resident in HBM, annotations (boxes, classes, polygons) passed from the host each step",
-            "grad_allreduce_MB": round(P.count_params(K) * 4 / 1e6, 1) if world > 1 else 0.0,
-            "last_losses": {k: round(v, 4) for k, v in losses.items()}}
+    f16 = ctx.conv_mode == ctx.CONV_F16X3
+    peak = PEAK_F16X3_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    wg_ms, wg_fl, wg_n = prof["ms"][2], prof["flops"][2], prof["launches"][2]
+    ach = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
+    kname = "wgrad_f16x3_kernel" if f16 else "wgrad_mfma_kernel"
+    traffic, traffic_src, traffic_key = pmc_traffic([k for k in ("wgrad_f16x3_kernel<1>", "wgrad_f16x3_kernel", "wgrad_mfma_kernel") if k.startswith(kname)])
+    conv_ms = prof["ms"][0] + prof["ms"][1]
+    out = {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
+           "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
+           "steps": steps, "warmup": warmup, "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
+           "dtype": "f32 (forward, data-gradient and weight-gradient convs: f16x3 split-operand MFMA, fp32 accumulate)" if f16 else "f32",
+           "workload": "BASELINE configs[2] (N=1) / configs[3] (N=8): K=2, ~480 GT instances/image (polygons), 256 anchors + 512 RoIs "
+                       "sampled per image, seeded random-init weights, uint8 images resident in HBM, annotations (boxes, classes, polygons) passed from the host each step",
+           "roofline": {"bound": "mfma", "kernel": f"{kname} (dW = dY^T X, 128x128 tiles, split-K slabs reduced in fixed order)",
+                        "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                        **({"frac_of_sustained": round(ach / (SUSTAINED_F16_MFMA_RANDOM_TFLOPS / 3.0), 4)} if f16 else {}),
+                        "traffic": traffic, "traffic_from": (f"{traffic_src}: {traffic_key}" if traffic_src else None),
+                        "launches_per_step": round(wg_n / max(prof_steps, 1), 1), "kernel_ms_per_step": round(wg_ms / max(prof_steps, 1), 3),
+                        "fwd_dgrad_conv_ms_per_step": round(conv_ms / max(prof_steps, 1), 3),
+                        "fwd_dgrad_conv_tflops": round((prof["flops"][0] + prof["flops"][1]) / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
+                        "events_on": f"every {PROF_EVERY}th timed step ({prof_steps} of {steps})", "truncated": prof["truncated"]},
+           "grad_exchange": {"backend": "rccl (amp_comm_*, issued inside amp_model_forward_backward)" if has_comm else
+                                        ("staged (rehearsal: gloo on host buffers)" if world > 1 else "none (1 rank, no communicator)"),
+                             "rccl_ranks": ctx.comm_info()[1] if has_comm else 0,
+                             "rccl_version": ctx.comm_info()[2] if has_comm else None,
+                             "buckets": len({b for b, _, _ in buckets}), "ranges": len(buckets),
+                             "MB_per_step": round(sum(n for _, _, n in buckets) * 4 / 1e6, 1),
+                             "exposed_comm_ms": round(exposed / nstat, 3) if nstat else None,
+                             "comm_span_ms": round(span / nstat, 3) if nstat else None},
+           "last_losses": {k: round(v, 4) for k, v in losses.items()}}
+    return out
 
 
-def two_pipelines_leg(local_rank, dev, rank, world, steps, barrier, params, imgs):
+def two_pipelines_leg(local_rank, dev, rank, world, steps, ranks, params, imgs):
     """The headline workload with TWO batches in flight per GPU: two contexts (own HIP stream, own model workspace), one host thread
     each.  A single pipeline leaves the chip idle while the host waits for the detection counts and the results, in the ramp and tail
     of every launch and in the under-filled grids of the small layers; a second pipeline fills those.  Same kernels, same batch of 8
@@ -163,15 +296,12 @@ def two_pipelines_leg(local_rank, dev, rank, world, steps, barrier, params, imgs
     run(2)
     counts[0] = counts[1] = 0
     n_each = max(1, steps // 2)
-    barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     run(n_each)
     el = time.perf_counter() - t0
-    barrier()
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+    ranks.barrier()
+    el = ranks.max(el)
     for m in models:
         m.close()
     if errors:
@@ -181,7 +311,27 @@ def two_pipelines_leg(local_rank, dev, rank, world, steps, barrier, params, imgs
             "ms_per_step": round(el / (2 * n_each) * 1e3, 3), "detections_per_image_mean": round(sum(counts) / (2 * n_each * BATCH), 2)}
 
 
-def x101_leg(ctx, dev, rank, world, steps, barrier):
+def host_inclusive_leg(model, imgs, dev, world, steps, ranks):
+    """The headline workload as the reference's `predictor(img)` sees it: the uint8 batch starts on the HOST (24 MB over PCIe per
+    step) and the masks come back as COCO compressed-RLE byte strings (what compress_pred stores, ampis/data_utils.py:275).  Never
+    `value`: the contract times inputs resident in HBM."""
+    model.infer(imgs)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    nm = 0
+    for _ in range(steps):
+        out = model.infer(imgs)
+        nm += sum(len(o["masks"]) for o in out)
+    torch.cuda.synchronize(dev)
+    el = ranks.max(time.perf_counter() - t0)
+    ranks.barrier()
+    return {"what": "same workload, timer also around H2D of the uint8 batch (pageable host memory) and the encoding of every mask's run lengths "
+                    "to COCO RLE strings + the per-image result dicts",
+            "value": round(world * BATCH * steps / el, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(el / steps * 1e3, 3),
+            "rle_strings_per_step": round(nm / steps, 1)}
+
+
+def x101_leg(ctx, dev, rank, world, steps, ranks):
     """BASELINE configs[4] per GPU: X-101-32x8d-FPN inference on native 2048x2048 synthetic micrographs, 500 detections/image."""
     S, D, XB = 2048, 500, 2
     log(f"rank {rank}: creating the X-101-32x8d model (batch {XB} x {S}x{S})")
@@ -196,7 +346,7 @@ def x101_leg(ctx, dev, rank, world, steps, barrier):
     ctx.h2d(d_imgs, imgs)
     for _ in range(2):
         model.infer_raw(None, device_ptr=d_imgs, shape=(XB, S, S))
-    barrier()
+    ranks.barrier()
     ctx.prof_begin(max_launches=steps * 256)
     t0 = time.perf_counter()
     ndet = 0
@@ -206,53 +356,45 @@ def x101_leg(ctx, dev, rank, world, steps, barrier):
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
     prof = ctx.prof_end()
-    barrier()
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        el = float(t.item())
+    ranks.barrier()
+    el = ranks.max(el)
     model.close()
     conv_ms = prof["ms"][0] + prof["ms"][1]
+    f16 = ctx.conv_mode == ctx.CONV_F16X3
     return {"metric": "images/sec Mask R-CNN X-101-32x8d-FPN @2048x2048 inference", "value": round(world * XB * steps / el, 3),
-            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "batch_per_gpu": XB, "dtype": "f32",
+            "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2), "steps": steps, "batch_per_gpu": XB,
+            "dtype": "f32 (convs: f16x3 split-operand MFMA, fp32 accumulate)" if f16 else "f32",
             "workload": "BASELINE configs[4]: native 2048x2048 (no tiling), K=2, 1000 proposals/img, TEST.DETECTIONS_PER_IMAGE=500, "
                         "seeded random-init weights, grouped 3x3 convs as 64-wide block-diagonal MFMA tiles",
             "detections_per_image_mean": round(ndet / (steps * XB), 1),
             "conv_useful_tflops": round((prof["flops"][0] + prof["flops"][1]) / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=10)
-    ap.add_argument("--train-steps", type=int, default=4, help="timed training steps of the secondary `train` object (0 = skip)")
-    ap.add_argument("--x101-steps", type=int, default=5, help="timed steps of the secondary `x101_2048` object (0 = skip)")
-    ap.add_argument("--no-strict", action="store_true", help="skip the fp32-MFMA reference run of the headline workload")
-    ap.add_argument("--no-two-pipelines", action="store_true", help="skip the secondary `two_pipelines` object")
-    ap.add_argument("--train-timeout", type=float, default=300.0, help="watchdog for the secondary legs, seconds")
-    args = ap.parse_args()
-
+def main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU fallback for the hot path"
-    if os.environ.get("AMP_BENCH_REHEARSAL"):    # rehearsal of the N>1 code path on a one-GPU box: every rank on device 0, gloo collectives
+    staged = bool(os.environ.get("AMP_BENCH_REHEARSAL"))   # rehearsal of the N>1 code path on a one-GPU box: every rank on device 0, gloo on host buffers
+    if staged:
         local_rank = 0
+        os.environ["AMP_COMM_BACKEND"] = "staged"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        if os.environ.get("AMP_BENCH_REHEARSAL"):
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        # torch.distributed on gloo is the side channel only: it carries the RCCL id to the ranks; every device collective below
+        # (barrier, max of the elapsed times, the gradient all-reduce) is an RCCL call made by libampis_hip.so
+        torch.distributed.init_process_group("gloo")
 
     log(f"rank {rank}/{world}: creating model")
     ctx = _lib.Context(local_rank)
+    rccl = None
+    if world > 1 and not staged:
+        from ampis_amd.utils import comm
+        rccl = comm.attach_rccl(ctx)
+        log(f"rank {rank}: RCCL communicator up (rank {rccl[0]} of {rccl[1]}, version {rccl[2]})")
+    ranks = Ranks(ctx, dev, world, staged)
     model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     params = P.init_params(K, seed=0, style="spread")
     model.load_params(params)
@@ -264,11 +406,6 @@ def main():
     def step():
         return model.infer_raw(None, device_ptr=d_imgs, shape=(BATCH, SIZE, SIZE))
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
-
     def timed(mode, warmup, steps):
         """W untimed + exactly K timed steps in one conv arithmetic, bracketed by barrier + synchronize; max over ranks."""
         ctx.conv_mode = mode
@@ -276,7 +413,7 @@ def main():
             t = time.perf_counter()
             step()
             log(f"[{mode}] warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
-        barrier()
+        ranks.barrier()
         # per-launch HIP event pairs on every PROF_EVERY-th timed step: the pairs themselves cost ~5 us of idle GPU per launch (0.55 ms
         # = 2.7 % of a step when every step carries them)
         ctx.prof_begin(max_launches=(steps // PROF_EVERY + 1) * 96)
@@ -294,12 +431,8 @@ def main():
         prof = ctx.prof_end()
         prof["steps"] = prof_steps
         log(f"[{mode}] timed {steps} steps in {el:.3f} s")
-        barrier()
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t.item())
-        return el, prof, ndet
+        ranks.barrier()
+        return ranks.max(el), prof, ndet
 
     mode = "f32" if os.environ.get("AMP_CONV_MODE") == "f32" else "f16x3"
     elapsed, prof, ndet = timed(mode, args.warmup, args.steps)
@@ -316,19 +449,14 @@ def main():
 
     out = None
     if rank == 0:
-        traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_summary_v8.json")))
-            key = ("conv_f16x3_kernel<256>" if "conv_f16x3_kernel<256>" in pmc["kernels"] else "conv_f16x3_kernel<128>") if mode == "f16x3" \
-                else "conv_glds_kernel<128>"
-            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        keys = ["conv_glds_kernel<256,F16>", "conv_f16x3_kernel<256>", "conv_f16x3_kernel<128>"] if mode == "f16x3" else ["conv_glds_kernel<128>"]
+        traffic, traffic_src, traffic_key = pmc_traffic(keys)   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * BATCH * args.steps / elapsed
         ach = prof["flops"][0] / (prof["ms"][0] * 1e-3) / 1e12 if prof["ms"][0] > 0 else 0.0
         peak = PEAK_F16X3_TFLOPS if mode == "f16x3" else PEAK_F32_MFMA_TFLOPS
         conv_all = (prof["flops"][0] + prof["flops"][1]) / ((prof["ms"][0] + prof["ms"][1]) * 1e-3) / 1e12
+        all_conv_ms = (prof["ms"][0] + prof["ms"][1]) / prof["steps"]
         out = {
             "metric": "images/sec Mask R-CNN R50-FPN @1024x1024 inference", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -340,10 +468,11 @@ def main():
                                    "outputs boxes+scores+classes+COCO-RLE counts on host",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
-                       "parallelism": f"image-parallel replicas x{world}, no data-path collective"},
+                       "parallelism": f"image-parallel replicas x{world}, no data-path collective"
+                                      + (f"; barrier / max-over-ranks on RCCL {rccl[2]} through the C ABI" if rccl else "")},
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_f16x3_kernel<256|128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, 3 MFMAs per product, 128x256x32 "
-                                    "8-wave / 128x128x32 4-wave tiles, LDS-DMA weights, register-staged split activations)") if mode == "f16x3" else
+                         "kernel": ("wide f16x3 tiles: conv_glds_kernel<256|128,F16> / conv_f16x3_kernel<256|128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, "
+                                    "3 MFMAs per product, 128x256x32 8-wave / 128x128x32 4-wave tiles, LDS-DMA operands)") if mode == "f16x3" else
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
@@ -353,10 +482,11 @@ def main():
                              "sustained_is": "measured on this chip: MFMA-only loop on random f16 operands 1655 TFLOP/s (clock drops under "
                                              "toggling inputs; 2475 on constants), / 3 (profiles/r01/mfma_peak.json)"} if mode == "f16x3" else {}),
                          "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_summary_v8.json)",
+                         "traffic_unit": f"HBM bytes per launch of {traffic_key} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "launches_per_step": prof["launches"][0] / prof["steps"],
                          "kernel_ms_per_step": round(prof["ms"][0] / prof["steps"], 3),
-                         "all_conv_ms_per_step": round((prof["ms"][0] + prof["ms"][1]) / prof["steps"], 3),
+                         "all_conv_ms_per_step": round(all_conv_ms, 3),
+                         "non_conv_ms_per_step": round(ms_per_step - all_conv_ms, 3),
                          "events_on": f"every {PROF_EVERY}th timed step ({prof['steps']} of {args.steps} steps, {prof['launches'][0]} launches of the dominant kernel)",
                          "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
         }
@@ -378,39 +508,54 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_images)
         print(json.dumps(out), flush=True)
 
-    # ---- secondary measurement: one training step (BASELINE configs[2] / [3]): local batch 16, forward + 5 losses + backward +
-    # gradient all-reduce over RCCL (N > 1) + SGD.  Never allowed to break the headline line above: an exception is reported in the
-    # object, and a collective that does not return (a rank died) is cut off by a watchdog that prints the headline and exits.
+    # ---- secondary measurements.  Never allowed to break the headline line above: an exception is reported in the object, and a
+    # collective that does not return (a rank died) is cut off by a watchdog that prints the headline and exits NON-ZERO, naming the leg.
     train_obj = None
-    if args.train_steps > 0 or args.x101_steps > 0 or not args.no_two_pipelines:
+    leg = {"name": None}
+    if args.train_steps > 0 or args.x101_steps > 0 or not args.no_two_pipelines or not args.no_host_inclusive:
         def on_stall():
-            log(f"rank {rank}: secondary legs exceeded {args.train_timeout} s; emitting the inference line without them")
-            emit(train_obj if train_obj is not None else {"error": f"secondary legs did not finish within {args.train_timeout} s"})
-            os._exit(0)
+            msg = f"secondary leg '{leg['name']}' did not finish within {args.train_timeout} s"
+            log(f"rank {rank}: {msg}; emitting the inference line without it and exiting with code 3")
+            extra["stalled_leg"] = leg["name"]
+            emit(train_obj if train_obj is not None else {"error": msg})
+            os._exit(3)
         dog = threading.Timer(args.train_timeout, on_stall)
         dog.daemon = True
         dog.start()
-        if not args.no_two_pipelines and mode == "f16x3":
+        if not args.no_host_inclusive:
+            leg["name"] = "host_inclusive"
             try:
-                extra["two_pipelines"] = two_pipelines_leg(local_rank, dev, rank, world, args.steps, barrier, params, imgs)
+                extra["host_inclusive"] = host_inclusive_leg(model, imgs, dev, world, max(4, args.steps // 4), ranks)
+            except Exception as e:   # noqa: BLE001
+                extra["host_inclusive"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_two_pipelines and mode == "f16x3":
+            leg["name"] = "two_pipelines"
+            try:
+                extra["two_pipelines"] = two_pipelines_leg(local_rank, dev, rank, world, args.steps, ranks, params, imgs)
             except Exception as e:   # noqa: BLE001
                 extra["two_pipelines"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if args.train_steps > 0:
+            leg["name"] = "train"
             try:
-                train_obj = train_leg(ctx, model, dev, rank, world, args.train_steps, barrier)
+                train_obj = train_leg(ctx, model, dev, rank, world, args.train_warmup, args.train_steps, ranks)
             except Exception as e:   # noqa: BLE001
                 train_obj = {"error": f"{type(e).__name__}: {e}"[:300]}
         if args.x101_steps > 0:
+            leg["name"] = "x101_2048"
             try:
                 model.close()
-                extra["x101_2048"] = x101_leg(ctx, dev, rank, world, args.x101_steps, barrier)
+                extra["x101_2048"] = x101_leg(ctx, dev, rank, world, args.x101_steps, ranks)
             except Exception as e:   # noqa: BLE001
                 extra["x101_2048"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
     emit(train_obj)
     if world > 1:
+        ranks.barrier()
+        if rccl:
+            from ampis_amd.utils import comm
+            comm.detach_rccl()
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    main(ARGS)

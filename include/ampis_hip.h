@@ -56,11 +56,12 @@ int  amp_timer_stop(amp_ctx* ctx, float* ms_h);
 
 /* Live profile of the dominant kernel: between begin and end every amp_conv2d_nhwc launch on this context is bracketed
  * by a HIP-event pair on the context's stream; end waits for the stream and sums duration and algorithmic FLOPs
- * (2*M*Cout*KH*KW*Cin) per tile variant: [0] = 128x128 tiles (conv_glds_kernel<128>), [1] = 128x64 tiles. */
+ * (2*M*Cout*KH*KW*Cin) per slot: [0] = wide conv tiles (128x128 / 128x256), [1] = 128x64 conv tiles, [2] = the weight-gradient
+ * MFMA kernel of amp_conv2d_wgrad (wgrad_f16x3_kernel / wgrad_mfma_kernel, without its row-table and reduce passes). */
 typedef struct amp_prof_summary {
-    long long launches[2];
-    double ms[2];
-    double flops[2];
+    long long launches[3];
+    double ms[3];
+    double flops[3];
     int truncated;            /* 1 when more launches happened than max_launches */
 } amp_prof_summary;
 int  amp_prof_begin(amp_ctx* ctx, int max_launches);
@@ -341,6 +342,46 @@ int  amp_model_get_tensor(amp_model* m, const char* name, int want_grad, float* 
 int  amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
 int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
+
+/* Multi-GPU exchange: RCCL over xGMI, one process and one communicator per GPU ---------------------------------------
+ * Replaces what the reference gets from detectron2's launch()/DDP + NCCL: the gradient all-reduce under
+ * `DefaultTrainer(cfg).train()` (ampis/data_utils.py:135, notebook cell 22) and `comm.synchronize()`
+ * (ampis/data_utils.py:107).  librccl is dlopen'ed by the first amp_comm_* call; nothing here needs torch.
+ * Rank 0 makes the id, the host hands its AMP_COMM_ID_BYTES bytes to every rank by any side channel (a file, a TCP store,
+ * torch.distributed on gloo), every rank calls amp_comm_init.  Collectives run on a stream owned by the communicator and are
+ * ordered against the context's stream by HIP events. */
+#define AMP_COMM_ID_BYTES 128
+int amp_comm_unique_id(unsigned char* id_h /* [AMP_COMM_ID_BYTES] */);
+int amp_comm_init(amp_ctx* ctx, int rank, int world, const unsigned char* id_h);
+int amp_comm_destroy(amp_ctx* ctx);                                   /* also done by amp_destroy */
+int amp_comm_info(amp_ctx* ctx, int* rank, int* world /* 0: no communicator */, int* rccl_version);
+/* every rank's stream work so far has completed on return (host-blocking) */
+int amp_barrier(amp_ctx* ctx);
+/* in-place all-reduce of a device buffer, ordered after the context's stream and complete before its later work */
+enum { AMP_F32 = 0, AMP_F64 = 1, AMP_I32 = 2 };
+enum { AMP_SUM = 0, AMP_MAX = 1 };
+int amp_allreduce(amp_ctx* ctx, void* buf, size_t count, int dtype, int op);
+/* timing of the last gradient exchange: exposed_ms = from the end of the backward pass (context stream) to the end of the last
+ * bucket (communication stream), 0 when the exchange finished first; span_ms = first bucket ready -> last bucket reduced */
+int amp_comm_stats(amp_ctx* ctx, float* exposed_ms, float* span_ms);
+
+/* The gradient arena is exchanged in AMP_GRAD_BUCKETS buckets, in the order the backward pass completes them:
+ * 0 mask head, 1 box head, 2 RPN head, 3 FPN, 4 res5, 5 res4, 6 res3 (stem and res2 are frozen: -1).  Host-only helpers (no
+ * device call), so that the plan can be checked -- and driven over gloo -- without a GPU. */
+#define AMP_GRAD_BUCKETS 7
+int amp_grad_bucket_of(const char* state_dict_name);
+/* tensors (bucket[t], off[t], n[t]) -> per bucket, in issue order, the merged float ranges of the arena (ranges of one bucket
+ * closer than max_gap floats are joined; the gap holds padding / frozen entries whose gradient is 0) */
+int amp_plan_grad_buckets(int ntensors, const int* bucket, const size_t* off, const size_t* n, size_t max_gap, int cap,
+                          int* out_bucket, size_t* out_off, size_t* out_n, int* out_count);
+/* the plan of this model's arena: ranges in issue order (cap >= 64 is always enough) */
+int amp_model_grad_buckets(amp_model* m, int cap, int* out_bucket, size_t* out_off, size_t* out_n, int* out_count);
+/* mode 1 (default once the context has a communicator): amp_model_forward_backward hands every bucket to RCCL as soon as the
+ * backward pass has completed it, so that the exchange overlaps the remaining weight- and data-gradient kernels, and
+ * amp_model_sgd_step waits for the last bucket on the device.  mode 0: nothing is exchanged inside forward_backward; the host
+ * calls amp_model_allreduce_grads (all buckets at once) or reduces amp_model_grad_arena itself. */
+int amp_model_set_grad_overlap(amp_model* m, int mode);
+int amp_model_allreduce_grads(amp_model* m);
 
 #ifdef __cplusplus
 }
