@@ -97,6 +97,8 @@ def _declare(L):
         "amp_memset": ([vp, vp, i, C.c_size_t], i),
         "amp_conv2d_nhwc": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp], i),
         "amp_conv2d_nhwc_ex": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_conv2d_nhwc_fmt": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i], i),
+        "amp_unsplit_rows": ([vp, vp, C.c_longlong, i, vp], i),
         "amp_group_expand_weights": ([vp, vp, i, i, i, i, vp], i),
         "amp_resize_scratch_bytes": ([i, i, i, i], C.c_size_t),
         "amp_resize_bilinear_u8": ([vp, vp, i, i, vp, i, i, vp], i),
@@ -121,6 +123,7 @@ def _declare(L):
         "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_nms": ([vp, i, i, vp, vp, vp, f, i, vp, vp, vp], i),
         "amp_roi_align": ([vp, C.POINTER(FpnFeats), vp, vp, vp, i, i, vp, vp], i),
+        "amp_roi_align_fmt": ([vp, C.POINTER(FpnFeats), vp, vp, vp, i, i, vp, vp, i], i),
         "amp_box_candidates": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, i, vp, vp], i),
         "amp_box_candidates_sized": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, vp, i, vp, vp], i),
         "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),

@@ -103,7 +103,8 @@ int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete 
 int comm_wait_done(amp_ctx* ctx);              // compute stream waits (device side) for every collective issued so far
 int comm_agree_flag(amp_ctx* ctx, int* d_flag); // MAX of a device int over the ranks, complete on return
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
-                  float* out, int* level_out, int out_split);   // out_split = 1: the pooled tensor in the split operand format
+                  float* out, int* level_out, int out_split, int in_split = 0);   // out_split / in_split = 1: pooled tensor / feature maps in the split row format
+int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
 // only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)
 }

@@ -45,6 +45,7 @@ struct ConvArgs {
     int ntn;  // number of N tiles
     float in_scale, out_scale;   // f16x3 kernels: activations are multiplied by in_scale (a power of two) before the split, the sum by out_scale
     int y_split;            // 1: y is written in the split hi|lo' row format (out_mode 0, Cout % 32 == 0): the next conv's operand
+    int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
@@ -61,6 +62,9 @@ __device__ __forceinline__ unsigned int fastdiv(unsigned int x, unsigned int mul
 // with a residual, 64 dependent dword loads.  Transposed through LDS every lane owns 4 consecutive n of one row per step:
 // 16-B coalesced residual loads (all issued before the first store) and 16-B stores.  Callers pass the wave's tile origin
 // (mw0, nw0) and must have synchronised the workgroup after the last operand reads.
+template <int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue_generic_rows(const ConvArgs& a, float* stage, int lane, int mw0, int nw0, int HoWo);
+
 template <int WTM, int WTN, int MT, int NT, bool CHECK = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* lds, int wave, int lane,
                                               int mw0, int nw0, int HoWo) {
@@ -76,9 +80,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     }
     const int l31 = lane & 31, lh = lane >> 5;
     constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
-    constexpr int F4R = WTN / 4;                       // float4 per row
-    constexpr int RPI = 64 / F4R;                      // rows per iteration (one wave)
-    constexpr int NIT = WTM / RPI;
     float* stage = lds + wave * (WTM * SLD);
     // (the loop's last __syncthreads() already ordered every wave's operand reads before these writes)
 #pragma unroll
@@ -88,6 +89,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + l31] = acc[i][j][e];
+    conv_epilogue_generic_rows<WTM, WTN>(a, stage, lane, mw0, nw0, HoWo);
+}
+
+// the same from MB x NB blocks of 16x16 MFMA accumulators
+template <int WTM, int WTN, int MB, int NB, bool CHECK = false>
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[MB][NB], float* lds, int wave, int lane,
+                                                int mw0, int nw0, int HoWo) {
+    if (CHECK) {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bad = bad || !(fabsf(acc[i][j][e]) <= 3.0e38f);
+        if (bad) atomicOr(a.range_flag, 1);
+    }
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int SLD = WTN + 4;
+    float* stage = lds + wave * (WTM * SLD);
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                stage[(i * 16 + 4 * lq + e) * SLD + j * 16 + l15] = acc[i][j][e];
+    conv_epilogue_generic_rows<WTM, WTN>(a, stage, lane, mw0, nw0, HoWo);
+}
+
+template <int WTM, int WTN>
+__device__ __forceinline__ void conv_epilogue_generic_rows(const ConvArgs& a, float* stage, int lane, int mw0, int nw0, int HoWo) {
+    constexpr int SLD = WTN + 4;                       // padded row of the staging tile (floats)
+    constexpr int F4R = WTN / 4;                       // float4 per row
+    constexpr int RPI = 64 / F4R;                      // rows per iteration (one wave)
+    constexpr int NIT = WTM / RPI;
 
     const int erow = lane / F4R;                       // row within an iteration
     const int ec4 = lane % F4R;
@@ -175,19 +212,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[M
     }
 }
 
+// One K-step (32 k) of the AMP_CONV_F16X3 product on a wave tile of MB x NB blocks of 16 x 16, operands in the LDS row format
+// (per row 64 B of hi halves, 64 B of lo' halves, 16-B chunks XOR-swizzled by (row >> 1) & 7).  v_mfma_f32_16x16x32_f16: lane =
+// (row l15 of a block, k group lq), so the hi halves of k 8lq.. are chunk lq of the row and their lo' halves chunk 4 + lq: one
+// ds_read_b128 each, conflict-free over the 16 rows of a lane group.  Every AMP_CONV_F16X3 forward kernel computes through this
+// function, whoever staged the tiles: that is what makes "split in the kernel" and "split by the producer" the same arithmetic.
+// (Shape: the 16x16x32 MFMA does the flops of the 32x32x16 one in the same cycles with the same LDS bytes, but on random operands
+// the chip holds a higher clock under it -- MI355X_MICROARCH.md -- measured here: +2..9 % on the 3x3 / fc layers.)
+template <int MB, int NB>
+__device__ __forceinline__ void f16x3_step16(const float* As, const float* Bs, int fo_hi, int fo_lo, f32x4 (&acc)[MB][NB], f32x4 (&acx)[MB][NB]) {
+    f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_hi);
+        al[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_lo);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_hi);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_lo);
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
+            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+}
+
 // Fast epilogue for the layouts the model actually uses (Cout % 4 == 0): same LDS transposition and the same arithmetic as
 // conv_epilogue, but straight-line: the row offsets advance by additions (SPATIAL = false: out_mode 0, res_mode 0/1) or come from
 // two multiply-shift divisions per row (SPATIAL = true: upsampled residual, deconv / stride-2 scatter); residual and mask loads of
 // all rows are issued before the first store; a block-uniform `full` flag removes the per-row bounds predicates from every tile
 // but the last one.  (Measured on gfx950: the generic epilogue's per-row branches cost 13-55 % of the short-K layers.)
+template <int WTM, int WTN, bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, float* stage, int lane, int mw0, int nw0);
+template <int WTM, int WTN, bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_rows8(const ConvArgs& a, float* stage, int lane, int mw0, int nw0);
+
 template <int WTM, int WTN, int MT, int NT, bool SPATIAL, bool CHECK = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[MT][NT], float* lds, int wave, int lane,
                                                    int mw0, int nw0) {
     const int l31 = lane & 31, lh = lane >> 5;
     constexpr int SLD = WTN + 4;
-    constexpr int F4R = WTN / 4;
-    constexpr int RPI = 64 / F4R;
-    constexpr int NIT = WTM / RPI;
     float* stage = lds + wave * (WTM * SLD);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -196,6 +265,131 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 stage[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * SLD + j * 32 + l31] = acc[i][j][e];
+    if (a.y_split && !a.mask && a.out_mode == 0) conv_epilogue_rows8<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
+    else conv_epilogue_rows<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
+}
+
+// the same from 16x16 MFMA accumulators (v_mfma_f32_16x16x32_f16: lane = column, 4 consecutive rows per lane group of 16)
+template <int WTM, int WTN, int MT, int NT, bool SPATIAL, bool CHECK = false>
+__device__ __forceinline__ void conv_epilogue_fast16(const ConvArgs& a, f32x4 (&acc)[MT][NT], float* lds, int wave, int lane,
+                                                     int mw0, int nw0) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int SLD = WTN + 4;
+    float* stage = lds + wave * (WTM * SLD);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                stage[(i * 16 + 4 * lq + e) * SLD + j * 16 + l15] = acc[i][j][e];
+    if (a.y_split && !a.mask && a.out_mode == 0) conv_epilogue_rows8<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
+    else conv_epilogue_rows<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
+}
+
+// Split-format output (the trunk's native activation format), 8 channels per lane: a lane's share of an output row is 16 B of hi
+// halves and 16 B of lo' halves (and the same of a split residual), so every global access is a full dwordx4 -- with 4 channels per
+// lane (conv_epilogue_rows) they were 8-B accesses and the memory-bound 1x1 layers ran 10 % slower than with fp32 rows.
+// out_mode 0, no mask (inference), Cout % 32 == 0; same arithmetic, same order as conv_epilogue_rows.
+template <int WTM, int WTN, bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_rows8(const ConvArgs& a, float* stage, int lane, int mw0, int nw0) {
+    constexpr int SLD = WTN + 4;
+    constexpr int L8R = WTN / 8;                       // lanes per row
+    constexpr int RPI = 64 / L8R;                      // rows per iteration
+    constexpr int NIT = WTM / RPI;
+    const int erow = lane / L8R;
+    const int ec8 = lane % L8R;
+    const int n = nw0 + ec8 * 8;
+    const bool nv = n < a.Cout;                        // Cout % 32 == 0
+    float sc[8], sh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        sc[q] = (nv && a.scale) ? a.scale[n + q] : 1.f;
+        sh[q] = (nv && a.shift) ? a.shift[n + q] : 0.f;
+    }
+    const bool has_res = a.res_mode != 0;
+    const size_t col_b = (size_t)(n >> 5) * 128 + (size_t)(n & 31) * 2;   // byte offset of this lane's hi halves inside a split row
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                      // two passes of NIT / 2 rows: bounds the live registers
+        constexpr int HN = NIT / 2;
+        size_t yrow[HN], rrow[HN];                     // float index of the row start in y / res
+        bool mv[HN];
+        f32x4 r0[HN], r1[HN];
+#pragma unroll
+        for (int t = 0; t < HN; ++t) {
+            const int it = h * HN + t;
+            const int mrow = mw0 + it * RPI + erow;
+            mv[t] = nv && mrow < a.M;
+            const unsigned int m = min((unsigned int)mrow, (unsigned int)(a.M - 1));
+            yrow[t] = (size_t)m * a.Cout;
+            rrow[t] = yrow[t];
+            if (SPATIAL && a.res_mode == 2) {
+                const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+                const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
+                const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+                const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+                rrow[t] = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout;
+            }
+        }
+        if (has_res) {
+#pragma unroll
+            for (int t = 0; t < HN; ++t) {
+                if (!mv[t]) continue;
+                if (a.res_split) {
+                    const char* rb = reinterpret_cast<const char*>(a.res + rrow[t]) + col_b;
+                    r0[t] = *reinterpret_cast<const f32x4*>(rb);          // 8 hi halves
+                    r1[t] = *reinterpret_cast<const f32x4*>(rb + 64);     // 8 lo' halves
+                } else {
+                    r0[t] = *reinterpret_cast<const f32x4*>(a.res + rrow[t] + n);
+                    r1[t] = *reinterpret_cast<const f32x4*>(a.res + rrow[t] + n + 4);
+                }
+            }
+        }
+        if (h == 0) __builtin_amdgcn_wave_barrier();   // staging writes of this wave precede its reads (same-wave LDS order)
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < HN; ++t) {
+            const int it = h * HN + t;
+            const float* sp = stage + (it * RPI + erow) * SLD + ec8 * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            f16x8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = q < 4 ? v0[q] : v1[q - 4];
+                if (CHECK) bad = bad || !(fabsf(v) <= 3.0e38f);
+                float o = __fadd_rn(__fmul_rn(v, sc[q]), sh[q]);
+                if (has_res) {
+                    float r;
+                    if (a.res_split) {
+                        const f16x8 rh = __builtin_bit_cast(f16x8, r0[t]), rl = __builtin_bit_cast(f16x8, r1[t]);
+                        r = __fadd_rn((float)rh[q], __fmul_rn((float)rl[q], 1.0f / LO_SCALE));
+                    } else {
+                        r = q < 4 ? r0[t][q] : r1[t][q - 4];
+                    }
+                    o = __fadd_rn(o, r);
+                }
+                if (a.relu) o = fmaxf(o, 0.f);
+                const _Float16 hh = (_Float16)o;
+                hi[q] = hh;
+                lo[q] = (_Float16)((o - (float)hh) * LO_SCALE);
+            }
+            if (mv[t]) {
+                char* base = reinterpret_cast<char*>(a.y + yrow[t]) + col_b;
+                *reinterpret_cast<f16x8*>(base) = hi;
+                *reinterpret_cast<f16x8*>(base + 64) = lo;
+            }
+        }
+        if (CHECK && bad) atomicOr(a.range_flag, 1);
+    }
+}
+
+// rows of a wave's staged [WTM][WTN] tile -> affine, residual, ReLU, mask -> y (fp32 or split rows)
+template <int WTM, int WTN, bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, float* stage, int lane, int mw0, int nw0) {
+    constexpr int SLD = WTN + 4;
+    constexpr int F4R = WTN / 4;
+    constexpr int RPI = 64 / F4R;
+    constexpr int NIT = WTM / RPI;
 
     const int erow = lane / F4R;
     const int ec4 = lane % F4R;
@@ -249,7 +443,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvArgs& a, f32x16 (&a
 #pragma unroll
         for (int it = 0; it < NIT; ++it) mv[it] = FULL || (nv && mw0 + it * RPI + erow < a.M);
         f32x4 rres[NIT], mk[NIT];
-        if (has_res) {
+        if (has_res && a.res_split) {
+            // the residual tensor lives in the split row format: this lane's 4 channels are 8 B of hi halves and 8 B of lo' halves
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (mv[it]) {
+                    const char* rb = reinterpret_cast<const char*>(a.res + (roff[it] - (size_t)n)) + (n >> 5) * 128 + (n & 31) * 2;
+                    const f16x4 rh = *reinterpret_cast<const f16x4*>(rb);
+                    const f16x4 rl = *reinterpret_cast<const f16x4*>(rb + 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rres[it][q] = __fadd_rn((float)rh[q], __fmul_rn((float)rl[q], 1.0f / LO_SCALE));
+                }
+        } else if (has_res) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (mv[it]) rres[it] = *reinterpret_cast<const f32x4*>(a.res + roff[it]);
@@ -564,17 +769,23 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
         }
     };
 
-    f32x16 acc[MT][NT];
-    f32x16 acx[F16 ? MT : 1][F16 ? NT : 1];      // F16: cross-term sums (scaled by 2^11)
+    f32x16 acc[MT][NT];                          // fp32 MFMA (F16 = false)
+    constexpr int MB = WTM / 16, NB = WTN / 16;  // F16: blocks of 16 x 16 (f16x3_step16)
+    f32x4 acc16[MB][NB], acx16[MB][NB];          // hi*hi sums; cross-term sums (scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[i][j][e] = 0.f;
-                if (F16) acx[F16 ? i : 0][F16 ? j : 0][e] = 0.f;
-            }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc16[i][j][e] = 0.f; acx16[i][j][e] = 0.f; }
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
 
     // fragment read offsets (floats): row*32 + 4*((2q+lh) ^ swz(row)), swz(row) = (l31>>1)&7 for every 32-row fragment
     const int fswz = (l31 >> 1) & 7;
@@ -593,29 +804,8 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
         const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
         const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
         if (F16) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {       // chunk 2kk+lh = hi halves of k 16kk+8lh.., chunk 4+2kk+lh = their lo' halves
-                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + foff[kk]);
-                    al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + foff[2 + kk]);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + foff[kk]);
-                    bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + foff[2 + kk]);
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        f32x16& cx = acx[F16 ? i : 0][F16 ? j : 0];
-                        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], cx, 0, 0, 0);
-                        cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], cx, 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            }
+            f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
+                                 fo16_hi, fo16_lo, acc16, acx16);
         } else {
 #pragma unroll
             for (int q = 0; q < BK / 8; ++q) {
@@ -639,15 +829,165 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 
     if (F16) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[F16 ? i : 0][F16 ? j : 0][e], 1.0f / LO_SCALE));
+                for (int e = 0; e < 4; ++e)
+                    acc16[i][j][e] = __fadd_rn(acc16[i][j][e], __fmul_rn(acx16[i][j][e], 1.0f / LO_SCALE));
+        if (EPI == 0) conv_epilogue16<WTM, WTN, MB, NB, true>(a, acc16, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+        else conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc16, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+    } else {
+        if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, false>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+        else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, false>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
     }
-    if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, F16>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
-    else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, F16>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv_split_kernel: AMP_CONV_F16X3 with BOTH operands already in the split hi|lo' row format (the trunk's native activation
+// format in inference, and the pre-split weights), 8 waves on a 128x256 or 256x128 tile, one workgroup per CU.
+// Compared with conv_glds_kernel<.., F16 = true> (two LDS buffers, vmcnt(0) + barrier at the end of every K-step) the operand
+// tiles travel through a ring of THREE LDS buffers: the LDS-DMA of tile s+2 is issued when tile s starts computing, and the wait
+// in front of tile s is vmcnt(NDMA) -- everything but the youngest tile's requests.  Why: a K-step is 24 MFMAs per wave
+// (1536 cycles per SIMD at two waves per SIMD, ~0.8 us) but an LDS-DMA request needs ~1.1 us from issue to landing when every CU
+// streams (MI355X_MICROARCH.md, cost cell "ldsdma-fill"), so with one tile in flight every step ended in a stall on its own
+// prefetch; with two in flight the request has two steps to land.  3 x 48 KB = 144 KB of the CU's 160 KB.
+// ------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kernel(const ConvArgs a, const unsigned int x_bytes,
+                                                                                    const unsigned int w_bytes) {
+    constexpr int WTM = 64, WTN = 64;
+    constexpr int NWM = BM / WTM, NWN = BN / WTN, NW = NWM * NWN;
+    constexpr int MB = WTM / 16, NB = WTN / 16;
+    constexpr int GA = BM / NW / 8;       // DMA instructions per wave per K-step for A (8 rows x 128 B each)
+    constexpr int GB = BN / NW / 8;       // ... for B
+    constexpr int NDMA = GA + GB;
+    constexpr int NSTAGE = 3;
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int SLD = WTN + 4;
+    constexpr int STAGE_FLOATS = NW * WTM * SLD;
+    constexpr int LDS_FLOATS = (NSTAGE * TILE_FLOATS > STAGE_FLOATS) ? NSTAGE * TILE_FLOATS : STAGE_FLOATS;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+    static_assert(GA >= 1 && GB >= 1 && NDMA < 16, "tile / wave split");
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = tile % a.ntn;
+    const int tile_m = tile / a.ntn;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+
+    // ---- staging geometry (as conv_glds_kernel): instruction g of this wave fills rows wave*R + 8g + (lane>>3), 16-B position lane&7 ----
+    const int srow = lane >> 3, spos = lane & 7;
+    int a_iy0[GA], a_ix0[GA], a_pb[GA], a_chunk[GA];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+        const int r = wave * (BM / NW) + 8 * g + srow;
+        a_chunk[g] = 4 * (spos ^ ((r >> 1) & 7));
+        const int m = m0 + r;
+        if (m < a.M) {
+            const unsigned int b = fastdiv((unsigned int)m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = (unsigned int)m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            a_iy0[g] = (int)oy * a.stride - a.pad;
+            a_ix0[g] = (int)ox * a.stride - a.pad;
+            a_pb[g] = (int)b * a.H * a.W;
+        } else {
+            a_iy0[g] = -(1 << 28);
+            a_ix0[g] = 0;
+            a_pb[g] = 0;
+        }
+    }
+    unsigned int b_voff[GB];
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * (BN / NW) + 8 * g + srow;
+        const int n = n0 + r;
+        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+    unsigned int a_voff[GA];
+
+    const int csteps = a.Cin / BK;
+    int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the tile being STAGED
+
+    auto stage = [&](int buf) {
+        if (cs == 0) {
+#pragma unroll
+            for (int g = 0; g < GA; ++g) {
+                const int iy = a_iy0[g] + ky, ix = a_ix0[g] + kx;
+                const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                a_voff[g] = v ? (unsigned int)(((a_pb[g] + iy * a.W + ix) * a.Cin + a_chunk[g]) * 4) : OOB_VOFF;
+            }
+        }
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + BM * BK;
+        const int a_soff = cs * (BK * 4);
+        const int b_soff = kstep * (BK * 4);
+#pragma unroll
+        for (int g = 0; g < GA; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK),
+                                                     16, (int)a_voff[g], a_soff, 0, 0);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK),
+                                                     16, (int)b_voff[g], b_soff, 0, 0);
+        ++kstep;
+        if (++cs == csteps) {
+            cs = 0;
+            if (++kx == a.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    f32x4 acc[MB][NB], acx[MB][NB];            // hi*hi sums; cross-term sums (scaled by 2^11): 128 registers
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+
+    stage(0);
+    if (a.nsteps > 1) stage(1);
+    int cur = 0, nxt = 2;                      // ring positions of the tile being computed / staged
+    for (int step = 0; step < a.nsteps; ++step) {
+        // tile `step` has landed once all but the youngest tile's requests of this wave are done (LDS-DMA counts in vmcnt, in order)
+        if (step + 1 < a.nsteps) __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        // Bare s_barrier: __syncthreads() is fence + barrier, and the workgroup-release fence waits for vmcnt(0) -- it would drain the
+        // very requests this ring keeps in flight.  Nothing a fence orders is needed here: the tiles are written by LDS-DMA (covered by
+        // the vmcnt above) and read by ds_read whose data the MFMAs of the previous step have already consumed.  The empty asm
+        // statements keep the compiler from moving LDS accesses across the barrier.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave's share of tile `step` is in LDS; everyone is done with tile step-1
+        asm volatile("" ::: "memory");
+        if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
+        f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
+                             fo16_hi, fo16_lo, acc, acx);
+        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+    }
+    __syncthreads();                           // all operand reads done: the epilogue re-uses the buffers as its staging tile
+
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+    conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 
@@ -807,15 +1147,17 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
         }
     };
 
-    f32x16 acc[MT][NT], acx[MT][NT];       // hi*hi sums; cross-term sums (scaled by 2^11)
+    constexpr int MB = WTM / 16, NB = WTN / 16;
+    f32x4 acc[MB][NB], acx[MB][NB];        // hi*hi sums; cross-term sums (scaled by 2^11): blocks of 16 x 16 (f16x3_step16)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
 
-    const int fswz = (l31 >> 1) & 7;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
 
     fetch(0);
     commit(0);
@@ -825,31 +1167,8 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 
     for (int step = 0; step < a.nsteps; ++step) {
         const int cur = step & 1;
-        const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
-        const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ch = 4 * ((2 * kk + lh) ^ fswz), cl = 4 * ((4 + 2 * kk + lh) ^ fswz);
-            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + ch);
-                al[i] = *reinterpret_cast<const f16x8*>(As + i * 32 * BK + cl);
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + ch);
-                bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 32 * BK + cl);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
-                    acx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
+        f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
+                             fo16_hi, fo16_lo, acc, acx);
         // A(step+1) is in registers (loads issued a step ago, behind the previous barrier), B(step+1) is landing in LDS[cur^1]
         if (step + 1 < a.nsteps) commit(cur ^ 1);
         // The weight DMA into LDS[cur^1] must have LANDED before anyone reads it.  The compiler only counts the register loads of
@@ -862,16 +1181,16 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 
     // fold the cross terms in (their 2^-11 is exact), then the shared epilogue
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 4; ++e) {
                 acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
                 if (SCALED) acc[i][j][e] *= a.out_scale;
             }
-    if (EPI == 0) conv_epilogue<WTM, WTN, MT, NT, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
-    else conv_epilogue_fast<WTM, WTN, MT, NT, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+    if (EPI == 0) conv_epilogue16<WTM, WTN, MB, NB, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN, HoWo);
+    else conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 // w [rows][K] fp32 -> split rows: per K-step of 32, 32 f16 hi halves (64 B) then 32 f16 lo' halves (64 B)
@@ -915,6 +1234,13 @@ void launch_f16x3s(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, 
     }
 }
 
+template <int BM, int BN>
+void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    constexpr int NT_ = (BM / 64) * (BN / 64) * 64;
+    if (epi == 2) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+}
+
 void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (epi == 1) hipLaunchKernelGGL((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     else hipLaunchKernelGGL((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
@@ -952,6 +1278,8 @@ void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
 
 static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles where Cout % 256 == 0
 extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
+static int g_split_ring = getenv("AMP_SPLIT_RING") ? atoi(getenv("AMP_SPLIT_RING")) : 1;    // EXPERIMENT switch: the 3-buffer conv_split_kernel for pre-split inputs (0: the 2-buffer conv_glds_kernel<.., F16>)
+extern "C" void amp_debug_set_split_ring(int v) { g_split_ring = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
 extern "C" void amp_debug_set_conv_generic_epilogue(int on) { g_conv_generic_epi = on; }
 static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
@@ -968,6 +1296,39 @@ extern "C" int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, i
     hipLaunchKernelGGL(split_weights_kernel, dim3(2048), dim3(256), 0, ctx->stream, w, (size_t)rows, K, reinterpret_cast<unsigned int*>(w_split));
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
+}
+
+namespace {
+__global__ void unsplit_rows_kernel(const unsigned int* __restrict__ in, size_t rows, int C, float* __restrict__ out) {
+    const size_t total = rows * (size_t)(C / 2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (C / 2);
+        const int kp = (int)(i - r * (C / 2));
+        const int step = kp / 16, j = kp % 16;
+        const unsigned int hw = in[r * C + step * 32 + j], lw = in[r * C + step * 32 + 16 + j];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)(hw >> (16 * q)));
+            const _Float16 l = __builtin_bit_cast(_Float16, (unsigned short)(lw >> (16 * q)));
+            out[r * C + 2 * kp + q] = __fadd_rn((float)h, __fmul_rn((float)l, 1.0f / LO_SCALE));
+        }
+    }
+}
+}  // namespace
+
+// the inverse of amp_split_weights / of a producer's split output: rows of hi|lo' halves -> fp32 (hi + lo' * 2^-11, exact)
+extern "C" int amp_unsplit_rows(amp_ctx* ctx, const float* x_split, long long rows, int C, float* out) {
+    AMP_REQUIRE(ctx && x_split && out && rows > 0 && C > 0 && C % 32 == 0, "amp_unsplit_rows: bad argument (C %% 32 != 0?)");
+    hipLaunchKernelGGL(unsplit_rows_kernel, dim3(2048), dim3(256), 0, ctx->stream, reinterpret_cast<const unsigned int*>(x_split), (size_t)rows, C, out);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+extern "C" int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
+                                   const float* res, float* y, int fmt) {
+    AMP_REQUIRE(fmt >= 0 && fmt < 8, "amp_conv2d_nhwc_fmt: bad fmt");
+    AMP_REQUIRE(fmt == 0 || (ctx && ctx->conv_mode == AMP_CONV_F16X3), "amp_conv2d_nhwc_fmt: split formats exist in AMP_CONV_F16X3 only");
+    return amp::conv_run(ctx, d, 1, x, w, nullptr, 0, scale, shift, res, nullptr, y, 0, fmt);
 }
 
 extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
@@ -1079,9 +1440,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     a.range_flag = ctx->d_conv_flag;
     const bool x_is_split = (fmt & 1) != 0;
     a.y_split = (fmt & 2) ? 1 : 0;
+    a.res_split = (fmt & 4) ? 1 : 0;
+    AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
-    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && w_split && a.Cin % 32 == 0 && !a.grouped && in_shift == 0),
-                "conv: a split-format input needs AMP_CONV_F16X3 with pre-split weights");
+    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && in_shift == 0 && glds),
+                "conv: a split-format input needs AMP_CONV_F16X3, Cin %% 32 == 0, a dense layer and operands below 2 GiB");
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
     a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
     if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && (glds || stem)) {
@@ -1103,7 +1466,14 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         // amortise a single round (fc1: M = 8000, K = 12544: 64-wide tiles re-read the 400 MB activation matrix from HBM)
         const int nblk256 = (a.Cout % 256 == 0) ? ntm * (a.Cout / 256) : 0;
         const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= 64));
-        if (x_is_split) {      // both operands by LDS-DMA
+        const int ntm256 = amp::cdiv(a.M, 256);
+        if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
+            a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
+            launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (x_is_split && g_split_ring && epi != 0 && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {
+            a.ntn = a.Cout / 128; a.nblk = ntm256 * a.ntn;                  // Cout = 128 (or 384, ...): 256 x 128 tiles
+            launch_split<256, 128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (x_is_split) {      // both operands by LDS-DMA
             if (wide256) {
                 a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
                 launch_f16x3s<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

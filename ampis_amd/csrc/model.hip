@@ -231,6 +231,7 @@ struct Trunk {
     amp_fpn_feats ff;
     int max_n;
     const int* img_hw;    // device [B][2] per-image sizes (amp_model_set_image_sizes) or null: clip / rescale with these, not the frame
+    bool feat_split;      // p2..p6 are in the split row format (the trunk's native activation format in AMP_CONV_F16X3 inference)
 };
 
 // Shared by inference and training: preprocess -> ResNet-50 -> FPN -> RPN head. With ws.dry nothing is launched.
@@ -259,13 +260,34 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     } else {
         T.img_hw = nullptr;
     }
+    // AMP_CONV_F16X3 inference: from the max-pool on, every activation of the trunk lives in the split hi|lo' row format (same bytes,
+    // same row offsets as fp32): each conv epilogue writes it, the next conv stages it by LDS-DMA without splitting anything, and
+    // residual / FPN top-down adds and RoIAlign decode it exactly (hi + lo' * 2^-11).  A conv that cannot read the format (grouped
+    // 3x3 of ResNeXt, weights beyond the fp16 range) gets an fp32 input from its producer.  Training keeps fp32 activations: the
+    // backward kernels read them.
+    const bool native = !dry && !m->saving && split_chain(m, {});
+    auto reads_split = [&](const std::string& key) {
+        if (!native) return false;
+        auto it = m->conv.find(key);
+        return it != m->conv.end() && it->second.w_split != nullptr && it->second.groups == 1 && it->second.cin % 32 == 0;
+    };
+    bool native_all = native;          // every dense conv of backbone / FPN / RPN can read the format
+    if (native)
+        for (auto& kv : m->conv) {
+            const std::string& k = kv.first;
+            const bool trunk = k.rfind("backbone.", 0) == 0 || k.rfind("proposal_generator.", 0) == 0;
+            if (trunk && k != "backbone.bottom_up.stem.conv1" && kv.second.groups == 1 && !reads_split(k)) native_all = false;
+        }
+    const int SPL = 5;                 // tap dtype of a split tensor
+    auto FMT = [](bool x_split, bool y_split, bool res_split) { return (x_split ? 1 : 0) | (y_split ? 2 : 0) | (res_split ? 4 : 0); };
+
     int h = Hp / 2, w = Wp / 2;
     AMP_ALLOC(stem, float, (size_t)B * h * w * 64);
     if (!dry) AMP_TRY(launch_conv(m, CONV("backbone.bottom_up.stem.conv1"), x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
     const int h4 = (h + 2 - 3) / 2 + 1, w4 = (w + 2 - 3) / 2 + 1;
     AMP_ALLOC(pool, float, (size_t)B * h4 * w4 * 64);
-    if (!dry) AMP_TRY(amp_maxpool3x3s2(ctx, stem, B, h, w, 64, pool));
-    if (!dry) tap(m, "stem_pool", pool, 0, {B, h4, w4, 64});
+    if (!dry) AMP_TRY(amp::maxpool_run(ctx, stem, B, h, w, 64, pool, native_all ? 1 : 0));
+    if (!dry) tap(m, "stem_pool", pool, native_all ? SPL : 0, {B, h4, w4, 64});
 
     float* cur = pool;
     int ch = h4, cw_ = w4;
@@ -283,7 +305,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             const float* shortcut = cur;
             if (b == 0) {
                 AMP_ALLOC(sc, float, (size_t)B * oh * ow * kOut[s]);
-                if (!dry) AMP_TRY(launch_conv(m, CONV((p + ".shortcut").c_str()), cur, B, ch, cw_, st, 0, false, 0, nullptr, 0, sc));
+                if (!dry) AMP_TRY(launch_conv(m, CONV((p + ".shortcut").c_str()), cur, B, ch, cw_, st, 0, false, 0, nullptr, 0, sc, FMT(native_all, native_all, false)));
                 shortcut = sc;
             }
             // RESNETS.STRIDE_IN_1X1: the block's stride sits in conv1 (MSRA R50) or in the 3x3 conv2 (ResNeXt)
@@ -292,12 +314,11 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             AMP_ALLOC(t1, float, (size_t)B * h1 * w1 * m->mid[s]);
             AMP_ALLOC(t2, float, (size_t)B * oh * ow * m->mid[s]);
             if (!dry) {
-                // t1 feeds only the 3x3: in AMP_CONV_F16X3 inference it travels in the split operand format (see split_chain)
-                const bool tchain = !m->saving && CONV((p + ".conv2").c_str()).groups == 1 && split_chain(m, {(p + ".conv2").c_str()}) &&
-                                    CONV((p + ".conv1").c_str()).w_split != nullptr;
-                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1, tchain ? 2 : 0));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2, tchain ? 1 : 0));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out));
+                // formats: the block's input / output and the shortcut follow native_all; t1 / t2 are split when their one consumer reads it
+                const bool t1s = reads_split(p + ".conv2"), t2s = reads_split(p + ".conv3");
+                AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1, FMT(native_all, t1s, false)));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2, FMT(t1s, t2s, false)));
+                AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out, FMT(t2s, native_all, native_all)));
             }
             (void)mark;
             if (m->saving) {
@@ -313,7 +334,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             ch = oh; cw_ = ow;
         }
         res_out[s] = cur; res_h[s] = ch; res_w[s] = cw_;
-        if (!dry) tap(m, kStage[s], cur, 0, {B, ch, cw_, kOut[s]});
+        if (!dry) tap(m, kStage[s], cur, native_all ? SPL : 0, {B, ch, cw_, kOut[s]});
     }
 
     // ---------------- FPN ----------------
@@ -327,11 +348,10 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         AMP_ALLOC(lat, float, (size_t)B * res_h[s] * res_w[s] * 256);
         AMP_ALLOC(outp, float, (size_t)B * res_h[s] * res_w[s] * 256);
         if (!dry) {
-            // the finest lateral sum (l = 2) is read by its output conv only (the coarser ones are also the top-down residual of
-            // the next level and stay fp32): split operand format in AMP_CONV_F16X3 inference
-            const bool lchain = l == 2 && !m->saving && split_chain(m, {ln.c_str(), on.c_str()});
-            AMP_TRY(launch_conv(m, CONV(ln.c_str()), res_out[s], B, res_h[s], res_w[s], 1, 0, false, prev_lat ? 2 : 0, prev_lat, 0, lat, lchain ? 2 : 0));
-            AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp, lchain ? 1 : 0));
+            // lateral sums and outputs in the native format: the coarser lateral is decoded by the finer level's top-down add
+            AMP_TRY(launch_conv(m, CONV(ln.c_str()), res_out[s], B, res_h[s], res_w[s], 1, 0, false, prev_lat ? 2 : 0, prev_lat, 0, lat,
+                                FMT(native_all, native_all, native_all && prev_lat != nullptr)));
+            AMP_TRY(launch_conv(m, CONV(on.c_str()), lat, B, res_h[s], res_w[s], 1, 1, false, 0, nullptr, 0, outp, FMT(native_all, native_all, false)));
         }
         prev_lat = lat;
         m->lat[s] = lat;
@@ -343,7 +363,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     feat[4] = p6;
     if (!dry) {
         const char* fn[5] = {"p2", "p3", "p4", "p5", "p6"};
-        for (int l = 0; l < 5; ++l) tap(m, fn[l], feat[l], 0, {B, fh[l], fw[l], 256});
+        for (int l = 0; l < 5; ++l) tap(m, fn[l], feat[l], native_all ? SPL : 0, {B, fh[l], fw[l], 256});
     }
 
     // ---------------- RPN head ----------------
@@ -359,8 +379,8 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         const size_t keep = ws.off;
         AMP_ALLOC(t, float, (size_t)B * fh[l] * fw[l] * 256);
         if (!dry) {
-            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.conv"), feat[l], B, fh[l], fw[l], 1, 1, true, 0, nullptr, 0, t));
-            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.pred"), t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred));
+            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.conv"), feat[l], B, fh[l], fw[l], 1, 1, true, 0, nullptr, 0, t, FMT(native_all, native_all, false)));
+            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.pred"), t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred, FMT(native_all, false, false)));
         }
         (void)mark;
         if (m->saving) m->rpn_t[l] = t; else ws.off = keep;
@@ -375,6 +395,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     for (int l = 0; l < 5; ++l) { T.feat[l] = feat[l]; T.fh[l] = fh[l]; T.fw[l] = fw[l]; }
     T.lv = lv;
     T.max_n = max_n;
+    T.feat_split = native_all;
     memset(&T.ff, 0, sizeof(T.ff));
     T.ff.C = 256;
     for (int l = 0; l < 4; ++l) { T.ff.feat[l] = feat[l]; T.ff.h[l] = fh[l]; T.ff.w[l] = fw[l]; T.ff.stride[l] = fstride[l]; }
@@ -478,7 +499,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(det_classes, int, (size_t)B * D);
     if (!dry) {
         const bool bchain = split_chain(m, {"roi_heads.box_head.fc1", "roi_heads.box_head.fc2"});
-        AMP_TRY(amp::roi_align_run(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr, bchain ? 1 : 0));
+        AMP_TRY(amp::roi_align_run(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr, bchain ? 1 : 0, T.feat_split ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1, bchain ? 3 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2, bchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
@@ -547,7 +568,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         const bool mchain = split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2", "roi_heads.mask_head.mask_fcn3",
                                             "roi_heads.mask_head.mask_fcn4", "roi_heads.mask_head.deconv"});
         const int io = mchain ? 3 : 0;      // split in, split out
-        AMP_TRY(amp::roi_align_run(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr, mchain ? 1 : 0));
+        AMP_TRY(amp::roi_align_run(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr, mchain ? 1 : 0, T.feat_split ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
@@ -702,7 +723,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         for (int i = 0; i < R; ++i) iota[i] = i / RB;
         AMP_HIP_CHECK(hipMemcpyAsync(roi_batch_idx, iota.data(), (size_t)R * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // iota is a temporary
-        AMP_TRY(amp_roi_align(ctx, &T.ff, rois, roi_batch_idx, nullptr, R, 7, pooled, nullptr));
+        AMP_TRY(amp::roi_align_run(ctx, &T.ff, rois, roi_batch_idx, nullptr, R, 7, pooled, nullptr, 0, T.feat_split ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
@@ -764,7 +785,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_HIP_CHECK(hipMemcpyAsync(m_cls, hc.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m_poly, hp.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // hb/hc/hp are temporaries
-        AMP_TRY(amp_roi_align(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr));
+        AMP_TRY(amp::roi_align_run(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr, 0, T.feat_split ? 1 : 0));
         for (int i = 1; i <= 4; ++i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
             AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i]));

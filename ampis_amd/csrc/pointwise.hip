@@ -30,6 +30,9 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __rest
     }
 }
 
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <bool Y_SPLIT>
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
                                     int Ho, int Wo) {
     const size_t total = (size_t)B * Ho * Wo * C4;
@@ -54,7 +57,21 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
                 m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
             }
         }
-        reinterpret_cast<f32x4*>(y)[i] = m;
+        if (Y_SPLIT) {      // the trunk's native activation format (AMP_CONV_F16X3 inference): per 32 channels 64 B of hi halves, 64 B of lo' halves
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hh = (_Float16)m[e];
+                hi[e] = hh;
+                lo[e] = (_Float16)((m[e] - (float)hh) * 2048.0f);
+            }
+            const int ch = 4 * c;
+            char* base = reinterpret_cast<char*>(y + (i - c) * 4) + (ch >> 5) * 128 + (ch & 31) * 2;
+            *reinterpret_cast<f16x4*>(base) = hi;
+            *reinterpret_cast<f16x4*>(base + 64) = lo;
+        } else {
+            reinterpret_cast<f32x4*>(y)[i] = m;
+        }
     }
 }
 
@@ -94,14 +111,7 @@ int amp_preprocess(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, in
 }
 
 int amp_maxpool3x3s2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y) {
-    AMP_REQUIRE(ctx && x && y, "amp_maxpool3x3s2: null argument");
-    AMP_REQUIRE(C % 4 == 0 && B > 0 && H > 0 && W > 0, "amp_maxpool3x3s2: bad shape (C %% 4 != 0?)");
-    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, x, y, B, H, W, C / 4,
-                       Ho, Wo);
-    AMP_HIP_CHECK(hipGetLastError());
-    return AMP_OK;
+    return amp::maxpool_run(ctx, x, B, H, W, C, y, 0);
 }
 
 int amp_subsample2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y) {
@@ -116,3 +126,15 @@ int amp_subsample2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, flo
 }
 
 }  // extern "C"
+
+int amp::maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split) {
+    AMP_REQUIRE(ctx && x && y, "amp_maxpool3x3s2: null argument");
+    AMP_REQUIRE(C % 4 == 0 && B > 0 && H > 0 && W > 0, "amp_maxpool3x3s2: bad shape (C %% 4 != 0?)");
+    AMP_REQUIRE(!y_split || C % 32 == 0, "amp_maxpool3x3s2: the split format needs C %% 32 == 0");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    if (y_split) hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, x, y, B, H, W, C / 4, Ho, Wo);
+    else hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, x, y, B, H, W, C / 4, Ho, Wo);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}

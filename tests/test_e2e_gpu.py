@@ -1,7 +1,7 @@
 """End-to-end and stage-wise parity of the HIP Mask R-CNN path (through the C ABI: amp_model_*) against the CPU oracle
 on identical weights and identical input bytes.
 
-Tolerances (fp32, BASELINE.json north_star): box |delta| < 1e-3 px, mask IoU >= 0.999 per matched instance, identical
+Tolerances (fp32, BASELINE.json north_star; the rule is oracle/gate.py): box |delta| < 1e-3 px, masks identical except threshold ties, identical
 class ids.  Stage taps are compared with a relative tolerance that grows with depth (fp32 re-association through ~60
 layers); selection stages (top-k / NMS) are compared on matched sets because a 1e-6 score difference may legally flip
 the order of two near-tied candidates.
@@ -13,7 +13,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 BOX_TOL = 1e-3
-IOU_MIN = 0.999
 
 
 def _nhwc(t):
@@ -119,31 +118,14 @@ def _decode(rle_counts, h, w):
 
 
 def test_final_outputs_match_oracle(setup):
-    """The north-star gate: per image, same number of detections (+-1%), and every oracle instance has a HIP instance
-    with the same class, box |delta| < 1e-3 px and mask IoU >= 0.999 -- for at least 97% of instances; no matched mask may
-    differ by more than 2 pixels (threshold flips of values within ~1e-5 of 0.5 are the only legal difference)."""
+    """The north-star gate (oracle/gate.py): per image the same number of detections; EVERY oracle instance has a HIP twin with the
+    same class, box |delta| < 1e-3 px, score within 1e-4; a mask pixel may differ only where the oracle's own pasted probability
+    is within 1e-4 of the 0.5 threshold (a tie), so every mask without such a tie is bit-identical (IoU 1 >= 0.999)."""
+    from oracle import gate
     out, ref, H, W = setup["out"], setup["ref"], setup["H"], setup["W"]
-    total = good = 0
-    for o, r in zip(out, ref):
-        rb, rs, rc, rm = r["boxes"].numpy(), r["scores"].numpy(), r["classes"].numpy(), r["masks"].numpy()
-        assert abs(len(rb) - len(o["boxes"])) <= max(1, len(rb) // 100)
-        assert np.all(np.diff(o["scores"]) <= 0), "scores must be sorted descending"
-        for i in range(len(rb)):
-            total += 1
-            d = np.abs(o["boxes"] - rb[i]).max(axis=1) if len(o["boxes"]) else np.array([])
-            if len(d) == 0:
-                continue
-            j = int(np.argmin(d))
-            if d[j] >= BOX_TOL or o["classes"][j] != rc[i] or abs(o["scores"][j] - rs[i]) > 1e-4:
-                continue
-            gm = _decode(o["masks"][j]["counts"], H, W)
-            assert int((gm ^ rm[i]).sum()) <= 2
-            inter, union = (gm & rm[i]).sum(), (gm | rm[i]).sum()
-            iou = 1.0 if union == 0 else inter / union
-            if iou >= IOU_MIN:
-                good += 1
-    assert total > 20
-    assert good / total >= 0.97, f"{good}/{total} instances within tolerance"
+    st = gate.merge([gate.check_image(o, r, H, W, lambda m: _decode(m["counts"], H, W)) for o, r in zip(out, ref)])
+    print("e2e gate:", st)
+    assert st["instances"] > 20 and st["identical"] + st["tie_masks"] == st["instances"]
 
 
 def test_mask_prob_tap(setup):

@@ -24,19 +24,12 @@ def _decode(m, h, w):
     return rle.decode({"size": [h, w], "counts": m["counts"]}).astype(bool)
 
 
-def _match(out, ref, h, w, min_good=0.95):
-    rb, rs, rc, rm = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy(), ref["masks"].numpy()
-    assert abs(len(rb) - len(out["boxes"])) <= max(1, len(rb) // 50)
-    good = 0
-    for i in range(len(rb)):
-        d = np.abs(out["boxes"] - rb[i]).max(axis=1)
-        j = int(np.argmin(d))
-        if d[j] < BOX_TOL and out["classes"][j] == rc[i] and abs(out["scores"][j] - rs[i]) < 1e-4:
-            gm = _decode(out["masks"][j], h, w)
-            assert gm.shape == rm[i].shape
-            assert int((gm ^ rm[i]).sum()) <= max(2, int(rm[i].sum()) // 500)
-            good += 1
-    assert len(rb) > 5 and good >= min_good * len(rb), (good, len(rb))
+def _match(out, ref, h, w):
+    """The end-to-end gate of oracle/gate.py (hard per-instance asserts, differing mask pixels must be threshold ties)."""
+    from oracle import gate
+    st = gate.check_image(out, ref, h, w, lambda m: _decode(m, h, w))
+    assert st["instances"] > 5, st
+    return st
 
 
 def test_size_not_a_multiple_of_32_and_rescaled_output(gpu_ctx):

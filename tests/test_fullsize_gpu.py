@@ -84,36 +84,40 @@ def test_bitwise_deterministic(run):
         assert all(np.array_equal(p["counts"], q["counts"]) for p, q in zip(x["masks"], y["masks"]))
 
 
-def test_fullsize_image_against_the_oracle(gpu_ctx):
-    """One benchmark-sized image (1024x1024, 1000 proposals, 200 detections) through the oracle too: the end-to-end gate of
-    tests/test_e2e_gpu.py at BASELINE configs[1] scale (the oracle needs a few seconds per image on the host cores)."""
+def test_fullsize_batch_against_the_oracle(gpu_ctx):
+    """BASELINE configs[1] as benchmarked -- a batch of EIGHT 1024x1024 micrographs, 1000 proposals, 200 detections per image --
+    with two of its images (the first and one from the middle) also run through the oracle (a few seconds per image on the host
+    cores; an image's result does not depend on the batch it rides in, tests/test_edge_cases_gpu.py).  The gate is oracle/gate.py:
+    same detection count, every instance matched (box < 1e-3 px, class, score), differing mask pixels only at threshold ties."""
     import torch
     from ampis_amd import params as P, synth
     from ampis_amd.model import MaskRCNN
-    from oracle import maskrcnn as O
+    from oracle import gate, maskrcnn as O
     from test_e2e_gpu import _decode
-    S, K, D = 1024, 2, 200
+    S, K, D, B = 1024, 2, 200, 8
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    imgs, _ = synth.batch(1, S, S, first_index=7)
+    imgs, _ = synth.batch(B, S, S, first_index=7)
     p = P.init_params(K, seed=0, style="spread")
-    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D))[0]
-    m = MaskRCNN(gpu_ctx, K, max_batch=1, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
     m.load_params(p)
-    o = m.infer(imgs)[0]
+    out = m.infer(imgs)
     m.close()
-    rb, rs, rc, rm = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy(), ref["masks"].numpy()
-    assert len(rb) == D and abs(len(o["boxes"]) - D) <= 2
-    good, worst = 0, []
-    for i in range(len(rb)):
-        d = np.abs(o["boxes"] - rb[i]).max(axis=1)
-        j = int(np.argmin(d))
-        assert d[j] < 1e-3 and o["classes"][j] == rc[i] and abs(o["scores"][j] - rs[i]) < 1e-4, (i, float(d[j]))
-        gm = _decode(o["masks"][j]["counts"], S, S)
-        flips, area = int((gm ^ rm[i]).sum()), int(rm[i].sum())
-        worst.append((flips, area))
-        # threshold flips scale with the outline: masks here reach 10^5 px (outline ~10^3 px), the small-image gate of 2 px does not
-        assert flips <= max(2, 2e-4 * area), (i, flips, area)
-        u = (gm | rm[i]).sum()
-        good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
-    print("flips/area of the 5 worst masks:", sorted(worst, reverse=True)[:5], "masks at IoU>=0.999:", good)
-    assert good >= 0.97 * len(rb), good
+    tp = O.to_torch_params(p)
+    stats = []
+    for b in (0, 5):
+        ref = O.infer(imgs[b:b + 1], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]
+        assert len(ref["boxes"]) == D
+        stats.append(gate.check_image(out[b], ref, S, S, lambda mk: _decode(mk["counts"], S, S)))
+    st = gate.merge(stats)
+    print("full-size gate:", st)
+    assert st["instances"] == 2 * D and st["identical"] + st["tie_masks"] == st["instances"]
+    # where 1e-3 px is below the reference's own fp32 noise (boxes of several hundred px): against an exact-convolution evaluation
+    # of the same network (oracle/exact.py) the HIP path must be as close as the fp32 oracle is
+    from oracle import exact
+    with exact.exact_convs():
+        rex = O.infer(imgs[5:6], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]["boxes"].numpy()
+    r32 = O.infer(imgs[5:6], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]["boxes"].numpy()
+    dist = lambda a: max(float(np.abs(a - rex[i]).max(axis=1).min()) for i in range(len(rex)))
+    d_hip, d_ref = dist(out[5]["boxes"]), dist(r32)
+    print(f"worst box distance from the exact-convolution oracle: HIP {d_hip:.2e} px, fp32 oracle {d_ref:.2e} px")
+    assert d_hip <= max(1e-3, 1.5 * d_ref), (d_hip, d_ref)

@@ -36,25 +36,14 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
     small = resize_shortest_edge(img, 160, 256)
     assert small.shape[:2] == (160, 200)
     ref = O.infer(small[None], O.to_torch_params(npp), O.Cfg(num_classes=K, detections_per_image=D), out_sizes=[(240, 300)])[0]
-    rb, rm = ref["boxes"].numpy(), ref["masks"].numpy()
-    assert abs(len(rb) - len(inst)) <= 1
     res = data_utils.format_outputs("a.png", "particle_Train", outs)
     p = res["pred"]["instances"]
-    # Gate (DESIGN.md "Parity"): every oracle instance has a HIP twin with box |d| < 1e-3 px whose mask differs by at most
-    # 2 pixels (an interpolated value within ~1e-5 of the 0.5 threshold may flip: measured on 800 instances, 2.5-5.5 % of the
-    # masks carry one such pixel in EITHER conv mode).  One flipped pixel already puts a mask under 1000 px below IoU 0.999, so
-    # with 30 upscaled masks the share at IoU >= 0.999 is a noisy statistic: the hard per-instance limits above are the gate,
-    # the share is a sanity floor.
-    good = 0
-    for i in range(len(rb)):
-        d = np.abs(p.pred_boxes - rb[i]).max(axis=1)
-        j = int(np.argmin(d))
-        assert d[j] < 1e-3, (i, d[j])
-        gm = rle.decode(p.pred_masks[j]).astype(bool)
-        assert int((gm ^ rm[i]).sum()) <= 2, (i, int((gm ^ rm[i]).sum()))
-        u = (gm | rm[i]).sum()
-        good += int(u == 0 or (gm & rm[i]).sum() / u >= 0.999)
-    assert good >= 0.85 * len(rb), f"{good}/{len(rb)}"
+    # the gate of oracle/gate.py on what format_outputs stores (numpy boxes / scores / classes, RLE dicts)
+    from oracle import gate
+    hip = dict(boxes=np.asarray(p.pred_boxes), scores=np.asarray(p.scores), classes=np.asarray(p.pred_classes), masks=list(p.pred_masks))
+    st = gate.check_image(hip, ref, 240, 300, lambda m: rle.decode(m).astype(bool))
+    print("predictor gate:", st)
+    assert st["instances"] > 5
 
 
 def test_predictor_refuses_cpu_device():

@@ -220,5 +220,11 @@ def test_paste_rle_matches_oracle(gpu_ctx):
         assert int(runs[i].sum()) == H * W
         got = orle.decode_counts(runs[i], H, W)
         if not np.array_equal(runs[i], orle.encode_counts(ref)):
-            nflip += int((got != ref).sum())   # a pixel whose interpolated value is within 1 ulp of 0.5
-    assert nflip <= 2, f"{nflip} pixels differ from the oracle paste"
+            # identical inputs (same probabilities, same box): a pixel may differ only where the interpolated value sits ON the
+            # threshold -- the two paths sum the four bilinear products in a different order (last-ulp differences)
+            pm, y0, x0 = O.paste_prob(torch.from_numpy(prob[i]), b, H, W)
+            ys, xs = np.nonzero(got != ref)
+            margin = np.abs(pm.numpy()[ys - y0, xs - x0] - 0.5)
+            assert margin.max() < 1e-6, (i, float(margin.max()))
+            nflip += len(ys)
+    assert nflip <= 4, f"{nflip} pixels differ from the oracle paste"

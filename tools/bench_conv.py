@@ -56,6 +56,18 @@ def main():
             kw_args.update(res=torch.randn(B, Ho // 2, Wo // 2, Cout, device=d), res_mode=2)
         elif mode == "deconv":
             kw_args.update(deconv2x2=True)
+        if os.environ.get("AMP_SPLIT_IN") and Cin % 32 == 0 and mode != "deconv" and Cout % 32 == 0:
+            # the trunk-native data path: input (and residual) already in the split row format, output written in it
+            x = ops.split_rows(ctx, x)
+            fmt = ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT
+            if "res" in kw_args:
+                kw_args["res"] = ops.split_rows(ctx, kw_args["res"])
+                fmt |= ops.FMT_RES_SPLIT
+            kw_args["fmt"] = fmt
+            name = name + " [split]"
+        if os.environ.get("AMP_SPLIT_RING") is not None:
+            from ampis_amd import _lib
+            _lib.lib().amp_debug_set_split_ring(int(os.environ["AMP_SPLIT_RING"]))
         for _ in range(2):
             ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw_args)
         torch.cuda.synchronize()
