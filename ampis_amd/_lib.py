@@ -128,6 +128,7 @@ def _declare(L):
         "amp_box_candidates_sized": ([vp, vp, i, vp, vp, i, i, i, C.POINTER(f), f, i, i, vp, vp, vp, i, vp, vp], i),
         "amp_gather_dets": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_mask_prob": ([vp, vp, vp, i, i, vp], i),
+        "amp_mask_deconv_predict": ([vp, vp, i, vp, vp, vp, vp, vp, i, vp], i),
         "amp_paste_rle": ([vp, vp, vp, vp, i, vp, vp, i, i, i, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp], i),
         "amp_paste_rle_sized": ([vp, vp, vp, vp, i, vp, vp, i, i, i, vp, f, vp, vp, vp, C.c_ulonglong, vp, vp, vp, vp, vp, C.c_ulonglong, vp], i),
         "amp_rle_to_string": ([vp, i, vp, C.c_size_t, C.POINTER(C.c_size_t)], i),

@@ -95,8 +95,16 @@ namespace amp {
 // internal convolution entry (conv.hip): w_split = weights already in the f16x3 split layout (amp_split_weights) or null;
 // force_f32 = 1 runs the fp32-MFMA kernel whatever the context mode is; in_shift = s: (AMP_CONV_F16X3 only) the input is multiplied
 // by 2^s before the operand split and the sum by 2^-s (data gradients: tiny values would otherwise sit in the f16 subnormals).
+struct PredictFuse {              // the mask head's tail fused into the deconv's epilogue (conv.hip conv_epilogue_predict)
+    const float* pred_w;          // [K][256] predictor weights, fp32
+    const float* pred_b;          // [K]
+    const int* cls;               // [N] class of each RoI
+    int K;
+    float* prob;                  // [N][28][28]
+};
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-             const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0);
+             const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0,
+             const PredictFuse* fuse = nullptr);
 // comm.hip (all no-ops / errors are explicit when the context has no communicator)
 int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr);   // grouped in-place SUM, after the compute stream's work so far
 int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete on the compute stream (exposed-time reference)

@@ -45,6 +45,13 @@ struct ConvArgs {
     int ntn;  // number of N tiles
     float in_scale, out_scale;   // f16x3 kernels: activations are multiplied by in_scale (a power of two) before the split, the sum by out_scale
     int y_split;            // 1: y is written in the split hi|lo' row format (out_mode 0, Cout % 32 == 0): the next conv's operand
+    // out_mode 3 (conv_split_kernel<128,256> only): the ConvTranspose 2x2 of the mask head with its consumers fused into the epilogue --
+    // ReLU, the 1x1 predictor row of the detection's class, sigmoid -- so the [N,28,28,256] tensor never exists (see conv_epilogue_predict)
+    const float* pred_w;    // [K][C2] predictor weights (fp32), C2 = Cout / 4 = 256
+    const float* pred_b;    // [K]
+    const int* pred_cls;    // [B] class of each RoI (row b of the input)
+    int pred_K;
+    float* prob;            // [B][2Ho][2Wo] mask probabilities
     int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
@@ -844,6 +851,73 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 }
 
 
+// Epilogue of the fused mask-head tail (out_mode 3).  The GEMM is the ConvTranspose2d 2x2 s2 as a 1x1 convolution to
+// Cout = 4 * 256 channels ordered (tap, co); a 128 x 256 tile is therefore 128 input pixels x ONE tap x all 256 output channels.
+// Per tile row (RoI b, input pixel (oy, ox), tap (ky, kx)): v[co] = relu(acc[co] + bias[co]) is the deconv output at output pixel
+// (2oy + ky, 2ox + kx); the predictor's logit for the RoI's class c is  sum_co v[co] * wp[c][co] + bp[c];  the mask probability its
+// sigmoid.  fp32 products and sums in a fixed order (4 columns per lane, xor tree over the 16 lanes of a row, the 4 N-waves in order):
+// deterministic.  Replaces a 1.28 GB write, its read-back, the 1x1 predictor GEMM and mask_prob_kernel (B = 8, 200 detections).
+__device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0) {
+    constexpr int WTM = 64, WTN = 64, SLD = WTN + 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    float* stage = lds + wave * (WTM * SLD);
+    float* red = lds + 8 * (WTM * SLD);                 // [4 N-waves][128 rows] partial sums (2 KiB behind the staging tiles)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) stage[(i * 16 + 4 * lq + e) * SLD + j * 16 + l15] = acc[i][j][e];
+    __builtin_amdgcn_wave_barrier();
+    const int tap = n0 >> 8;                            // Cout = 4 * 256: the tile's N range is one tap
+    const int co = wn * WTN + l15 * 4;                  // this lane's 4 output channels
+    const int mw0 = m0 + wm * WTM;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (a.shift) bias = *reinterpret_cast<const f32x4*>(a.shift + n0 + co);
+    bool bad = false;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + lq;                     // row of the wave tile
+        const unsigned int m = min((unsigned int)(mw0 + rl), (unsigned int)(a.M - 1));
+        const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+        int cls = a.pred_cls[b];
+        cls = (cls >= 0 && cls < a.pred_K) ? cls : 0;
+        const f32x4 wp = *reinterpret_cast<const f32x4*>(a.pred_w + (size_t)cls * 256 + co);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + rl * SLD + l15 * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bad = bad || !(fabsf(v[q]) <= 3.0e38f);
+            const float o = fmaxf(__fadd_rn(v[q], bias[q]), 0.f);
+            s = __fadd_rn(s, __fmul_rn(o, wp[q]));
+        }
+        s = __fadd_rn(s, __shfl_xor(s, 8, 16));
+        s = __fadd_rn(s, __shfl_xor(s, 4, 16));
+        s = __fadd_rn(s, __shfl_xor(s, 2, 16));
+        s = __fadd_rn(s, __shfl_xor(s, 1, 16));
+        if (l15 == 0) red[wn * 128 + wm * WTM + rl] = s;
+    }
+    if (bad) atomicOr(a.range_flag, 1);
+    __syncthreads();
+    if (wn == 0) {                                      // 2 waves x 64 rows: one row per lane
+        const int rl = wm * WTM + lane;
+        const int m = m0 + rl;
+        if (m < a.M) {
+            const unsigned int b = fastdiv((unsigned int)m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = (unsigned int)m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            int cls = a.pred_cls[b];
+            cls = (cls >= 0 && cls < a.pred_K) ? cls : 0;
+            float x = __fadd_rn(__fadd_rn(__fadd_rn(red[rl], red[128 + rl]), red[256 + rl]), red[384 + rl]);
+            x = __fadd_rn(x, a.pred_b[cls]);
+            const float p = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
+            a.prob[((size_t)b * 2 * a.Ho + 2 * oy + (tap >> 1)) * (2 * a.Wo) + 2 * ox + (tap & 1)] = p;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // conv_split_kernel: AMP_CONV_F16X3 with BOTH operands already in the split hi|lo' row format (the trunk's native activation
 // format in inference, and the pre-split weights), 8 waves on a 128x256 or 256x128 tile, one workgroup per CU.
@@ -987,6 +1061,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+    if constexpr (BM == 128 && BN == 256 && EPI == 2) {
+        if (a.out_mode == 3) { conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0); return; }
+    }
     conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
@@ -1331,6 +1408,19 @@ extern "C" int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const f
     return amp::conv_run(ctx, d, 1, x, w, nullptr, 0, scale, shift, res, nullptr, y, 0, fmt);
 }
 
+// Stage a16 tail, fused: x [N,14,14,256] in the split row format -> ConvTranspose2d 2x2 s2 (w_deconv [(ky,kx,co)][256], bias [1024]: the
+// bias of co repeated per tap) -> ReLU -> 1x1 predictor row of classes[n] (pred_w [K][256], pred_b [K]) -> sigmoid -> prob [N,28,28]
+extern "C" int amp_mask_deconv_predict(amp_ctx* ctx, const float* x_split, int N, const float* w_deconv, const float* bias, const float* pred_w,
+                                       const float* pred_b, const int* classes, int K, float* prob) {
+    AMP_REQUIRE(ctx && x_split && w_deconv && bias && pred_w && pred_b && classes && prob && N >= 0 && K >= 1, "amp_mask_deconv_predict: bad argument");
+    AMP_REQUIRE(ctx->conv_mode == AMP_CONV_F16X3, "amp_mask_deconv_predict: AMP_CONV_F16X3 only (the fp32 path runs the three stages)");
+    if (N == 0) return AMP_OK;
+    amp_conv_desc d;
+    d.B = N; d.H = 14; d.W = 14; d.Cin = 256; d.Cout = 1024; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1; d.res_mode = 0; d.out_mode = 1;
+    amp::PredictFuse f{pred_w, pred_b, classes, K, prob};
+    return amp::conv_run(ctx, &d, 1, x_split, w_deconv, nullptr, 0, nullptr, bias, nullptr, nullptr, prob, 0, 1, &f);
+}
+
 extern "C" int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale,
                                   const float* shift, const float* res, const float* mask, float* y) {
     return conv_impl(ctx, d, 1, x, w, scale, shift, res, mask, y);
@@ -1377,7 +1467,8 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
 }
 
 int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
-                  const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift, int fmt) {
+                  const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift, int fmt,
+                  const amp::PredictFuse* fuse) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -1441,6 +1532,14 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     const bool x_is_split = (fmt & 1) != 0;
     a.y_split = (fmt & 2) ? 1 : 0;
     a.res_split = (fmt & 4) ? 1 : 0;
+    a.pred_w = a.pred_b = nullptr; a.pred_cls = nullptr; a.pred_K = 0; a.prob = nullptr;
+    if (fuse) {     // the mask head's deconv with ReLU + predictor + sigmoid in its epilogue (conv_epilogue_predict)
+        AMP_REQUIRE(x_is_split && d->out_mode == 1 && a.Cout == 1024 && a.KH == 1 && a.KW == 1 && a.relu && !res && !mask && !scale && g_split_ring,
+                    "conv: the fused deconv-predict epilogue needs a split input, Cout = 4 x 256, ReLU and the ring kernel");
+        AMP_REQUIRE(fuse->pred_w && fuse->pred_b && fuse->cls && fuse->prob && fuse->K >= 1, "conv: incomplete PredictFuse");
+        a.out_mode = 3;
+        a.pred_w = fuse->pred_w; a.pred_b = fuse->pred_b; a.pred_cls = fuse->cls; a.pred_K = fuse->K; a.prob = fuse->prob;
+    }
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
     AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && in_shift == 0 && glds),
@@ -1467,7 +1566,10 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         const int nblk256 = (a.Cout % 256 == 0) ? ntm * (a.Cout / 256) : 0;
         const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= 64));
         const int ntm256 = amp::cdiv(a.M, 256);
-        if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
+        if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
+            a.ntn = 4; a.nblk = ntm * 4;
+            launch_split<128, 256>(a, 2, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && epi != 0 && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {

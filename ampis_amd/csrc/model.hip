@@ -573,9 +573,21 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn4"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, mchain ? 1 : 0));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
-        AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
+        static const bool no_fuse = getenv("AMP_NO_MASK_FUSE") != nullptr;
+        if (mchain && !no_fuse) {
+            // deconv + ReLU + the predictor row of each detection's class + sigmoid in ONE kernel: the [N,28,28,256] activation
+            // (1.28 GB at 1600 detections) is never written
+            const ConvW& cd = CONV("roi_heads.mask_head.deconv");
+            const ConvW& cp = CONV("roi_heads.mask_head.predictor");
+            amp_conv_desc d;
+            d.B = N; d.H = 14; d.W = 14; d.Cin = 256; d.Cout = 1024; d.KH = 1; d.KW = 1; d.stride = 1; d.pad = 0; d.relu = 1; d.res_mode = 0; d.out_mode = 1;
+            amp::PredictFuse pf{cp.w, cp.shift, m_classes, K, mprob};
+            AMP_TRY(amp::conv_run(ctx, &d, 1, mpooled, cd.w, cd.w_split, 0, nullptr, cd.shift, nullptr, nullptr, mprob, 0, 1, &pf));
+        } else {
+            AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), mpooled, N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, mchain ? 1 : 0));
+            AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
+            AMP_TRY(amp_mask_prob(ctx, mlogits, m_classes, N, Kp, mprob));
+        }
         AMP_TRY(amp_paste_rle_sized(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, T.img_hw, c.mask_threshold, o_boxes,
                               o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1,
                               pos_pool, (unsigned long long)c.rle_pool_counts, pool_used + 1));

@@ -135,6 +135,290 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs a) {
 }
 
 
+// roi_align_lanes_kernel: the same arithmetic, organised for the VALU.  roi_align_kernel is NOT memory-bound: with every RoI on the
+// same few cells (all taps from L2) it runs at 80 % of its time on real proposals (tools/bench_roi.py) -- its time is the sampling
+// arithmetic, ~60 VALU instructions per sample (two IEEE divisions among them) that all 64 lanes execute redundantly on wave-uniform
+// values, next to 32 that do the interpolation.  Here lane j computes the parameters of sample COLUMN j and of sample ROW j of the
+// wave's bin once (same operations, same order: bit-identical), and the sample loops fetch them with v_readlane into scalar
+// registers: per sample the vector unit is left with 4 weight products, 4 loads and the 32 interpolation operations.
+// fp32 feature maps, C <= 256 * k (float4 per lane), sampling grids up to 64 x 64 (larger ones: roi_align_kernel).
+template <int DUMMY>
+__global__ __launch_bounds__(256) void roi_align_lanes_kernel(const RoiArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
+    const long long nbins = (long long)nvalid * a.P * a.P;
+    const int C4 = a.C >> 2;
+    for (long long bin = (long long)blockIdx.x * 4 + wave; bin < nbins; bin += (long long)gridDim.x * 4) {
+        const int pw = (int)(bin % a.P);
+        const int ph = (int)((bin / a.P) % a.P);
+        const int r = (int)(bin / (a.P * a.P));
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        if (a.level_out && ph == 0 && pw == 0 && lane == 0) a.level_out[r] = lv;
+        const int b = a.batch_idx ? a.batch_idx[r] : 0;
+        const int H = a.fh[lv], W = a.fw[lv];
+        const float sc = a.scale[lv];
+        const float sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f);
+        const float sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+        const float ew = __fsub_rn(__fmul_rn(x2, sc), 0.5f);
+        const float eh = __fsub_rn(__fmul_rn(y2, sc), 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)a.P), bw = __fdiv_rn(rw, (float)a.P);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
+        const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
+        const float count = (float)max(gh * gw, 1);
+        // lane j holds the parameters of sample row iy0 + j / sample column ix0 + j (grids beyond 64 go in chunks of 64; unused lanes
+        // compute harmless values)
+        auto row_params = [&](int iy0, int& ylo_w, int& yhi_w, float& ly, float& hy) {
+            float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)(iy0 + lane), 0.5f), bh), (float)gh));
+            const bool ybad = (y < -1.0f) || (y > (float)H);
+            if (y <= 0.f) y = 0.f;
+            int ylo = (int)y, yhi;
+            if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+            ly = __fsub_rn(y, (float)ylo); hy = __fsub_rn(1.0f, ly);
+            ylo_w = ybad ? -1 : ylo * W; yhi_w = yhi * W;            // row offsets in pixels; -1 marks a row outside the map
+        };
+        auto col_params = [&](int ix0, int& xlo, int& xhi, float& lx, float& hx) {
+            float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)(ix0 + lane), 0.5f), bw), (float)gw));
+            const bool xbad = (x < -1.0f) || (x > (float)W);
+            if (x <= 0.f) x = 0.f;
+            xlo = (int)x;
+            if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+            lx = __fsub_rn(x, (float)xlo); hx = __fsub_rn(1.0f, lx);
+            if (xbad) xlo = -1;                                      // -1 marks a column outside the map
+        };
+        int ylo_w, yhi_w, xlo, xhi;
+        float ly, hy, lx, hx;
+        row_params(0, ylo_w, yhi_w, ly, hy);
+        col_params(0, xlo, xhi, lx, hx);
+
+        const f32x4* f4 = reinterpret_cast<const f32x4*>(a.feat[lv]) + (size_t)b * H * W * C4;
+        f32x4* o4 = reinterpret_cast<f32x4*>(a.out) + (size_t)bin * C4;
+        for (int c = lane; c < C4; c += 64) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int iy = 0; iy < gh; ++iy) {
+                if (gh > 64 && (iy & 63) == 0) row_params(iy, ylo_w, yhi_w, ly, hy);
+                const int s_ylo = __builtin_amdgcn_readlane(ylo_w, iy & 63);
+                if (s_ylo < 0) continue;
+                const int s_yhi = __builtin_amdgcn_readlane(yhi_w, iy & 63);
+                const float s_ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), iy & 63));
+                const float s_hy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), iy & 63));
+                for (int ix = 0; ix < gw; ++ix) {
+                    if (gw > 64 && (ix & 63) == 0) col_params(ix, xlo, xhi, lx, hx);
+                    const int s_xlo = __builtin_amdgcn_readlane(xlo, ix & 63);
+                    if (s_xlo < 0) continue;
+                    const int s_xhi = __builtin_amdgcn_readlane(xhi, ix & 63);
+                    const float s_lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), ix & 63));
+                    const float s_hx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), ix & 63));
+                    const float w1 = __fmul_rn(s_hy, s_hx), w2 = __fmul_rn(s_hy, s_lx), w3 = __fmul_rn(s_ly, s_hx), w4 = __fmul_rn(s_ly, s_lx);
+                    const f32x4 v1 = f4[(size_t)(s_ylo + s_xlo) * C4 + c];
+                    const f32x4 v2 = f4[(size_t)(s_ylo + s_xhi) * C4 + c];
+                    const f32x4 v3 = f4[(size_t)(s_yhi + s_xlo) * C4 + c];
+                    const f32x4 v4 = f4[(size_t)(s_yhi + s_xhi) * C4 + c];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
+                        acc[e] = __fadd_rn(acc[e], t);
+                    }
+                }
+                if (gw > 64) col_params(0, xlo, xhi, lx, hx);       // back to the first chunk for the next row
+            }
+            if (gh > 64) row_params(0, ylo_w, yhi_w, ly, hy);       // ... and for the next channel group
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __fdiv_rn(acc[e], count);
+            if (a.out_split) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)acc[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)((acc[e] - (float)h) * 2048.0f);
+                }
+                const int ch = 4 * c;
+                char* base = reinterpret_cast<char*>(o4) + (ch >> 5) * 128 + (ch & 31) * 2;
+                *reinterpret_cast<f16x4*>(base) = hi;
+                *reinterpret_cast<f16x4*>(base + 64) = lo;
+            } else {
+                o4[c] = acc;
+            }
+        }
+    }
+}
+
+// roi_align_rows_kernel: the "tile-major" formulation -- one workgroup (8 waves) per BIN ROW of a RoI copies the distinct cells the
+// bin row touches once into LDS (each cell read once, split rows decoded once), builds the sample-row / sample-column tables once
+// (one thread per sample row / column, the operations of roi_align_kernel in the same order) and then wave w reduces bin w entirely
+// from LDS.  Bit-identical to roi_align_kernel (tests/test_stages_gpu.py).  MEASURED SLOWER than the per-bin kernels on the bench's
+// shapes (8000 proposals, P = 7: 1245 us against 899 us; tools/bench_roi.py) and therefore NOT the default (AMP_ROI_LANES=3 selects
+// it).  Why: RoIAlign here is bound neither by HBM nor by arithmetic but by dependent memory round trips.  With every box on the
+// same cells (all taps L2 hits) the per-bin kernel still needs 70-80 % of its time; a bin is a chain of ~11 round trips (box ->
+// 9 samples -> store) and 28 resident waves per CU hide it up to ~19 TB/s of L2 -> CU traffic.  This kernel cuts that traffic 4x
+// but its chain per bin row (box -> tables -> cells -> barrier -> reduce -> store, ~9 us) runs with only two 72-KiB workgroups per
+// CU; a per-wave LDS patch of 16 cells (tried, removed) had the same problem at 8 waves per CU (1363 us).
+constexpr int ROI_FOOT = 72;          // cells of 1 KiB: 72 KiB per workgroup, two workgroups per CU
+constexpr int ROI_TAB_ROWS = 64;      // sample rows of a bin
+constexpr int ROI_TAB_COLS = 256;     // sample columns of a whole bin row (P * gw)
+struct RoiTab { int lo, hi; float l, h; };   // lo < 0: the sample is outside the map
+
+template <bool IN_SPLIT>
+__global__ __launch_bounds__(512, 2) void roi_align_rows_kernel(const RoiArgs a) {
+    __shared__ __attribute__((aligned(16))) f32x4 foot[ROI_FOOT][64];
+    __shared__ RoiTab rowtab[ROI_TAB_ROWS];
+    __shared__ RoiTab coltab[ROI_TAB_COLS];
+    __shared__ int bounds[4];          // y0, y1, x0, x1 of the cells the valid samples touch
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
+    const long long nrows = (long long)nvalid * a.P;
+    constexpr int C4 = 64;
+    for (long long row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int ph = (int)(row % a.P);
+        const int r = (int)(row / a.P);
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        if (a.level_out && ph == 0 && tid == 0) a.level_out[r] = lv;
+        const int b = a.batch_idx ? a.batch_idx[r] : 0;
+        const int H = a.fh[lv], W = a.fw[lv];
+        const float sc = a.scale[lv];
+        const float sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f);
+        const float sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+        const float ew = __fsub_rn(__fmul_rn(x2, sc), 0.5f);
+        const float eh = __fsub_rn(__fmul_rn(y2, sc), 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)a.P), bw = __fdiv_rn(rw, (float)a.P);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
+        const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
+        const float count = (float)max(gh * gw, 1);
+        const float* fb = a.feat[lv] + (size_t)b * H * W * a.C;
+        const bool tables = gh <= ROI_TAB_ROWS && a.P * gw <= ROI_TAB_COLS && gh > 0 && gw > 0;
+
+        if (tid < 4) bounds[tid] = (tid & 1) ? -1 : (1 << 30);
+        __syncthreads();
+        if (tables) {
+            if (tid < gh) {                                      // sample row tid of this bin row
+                float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)tid, 0.5f), bh), (float)gh));
+                const bool bad = (y < -1.0f) || (y > (float)H);
+                if (y <= 0.f) y = 0.f;
+                int lo = (int)y, hi;
+                if (lo >= H - 1) { lo = hi = H - 1; y = (float)lo; } else { hi = lo + 1; }
+                RoiTab t;
+                t.l = __fsub_rn(y, (float)lo); t.h = __fsub_rn(1.0f, t.l); t.lo = bad ? -1 : lo; t.hi = hi;
+                rowtab[tid] = t;
+                if (!bad) { atomicMin(&bounds[0], lo); atomicMax(&bounds[1], hi); }
+            }
+            if (tid < a.P * gw) {                                // sample column ix of bin pw
+                const int pw = tid / gw, ix = tid - pw * gw;
+                float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                const bool bad = (x < -1.0f) || (x > (float)W);
+                if (x <= 0.f) x = 0.f;
+                int lo = (int)x, hi;
+                if (lo >= W - 1) { lo = hi = W - 1; x = (float)lo; } else { hi = lo + 1; }
+                RoiTab t;
+                t.l = __fsub_rn(x, (float)lo); t.h = __fsub_rn(1.0f, t.l); t.lo = bad ? -1 : lo; t.hi = hi;
+                coltab[tid] = t;
+                if (!bad) { atomicMin(&bounds[2], lo); atomicMax(&bounds[3], hi); }
+            }
+        }
+        __syncthreads();
+        const int y0 = bounds[0], yl = bounds[1], x0 = bounds[2], xl = bounds[3];
+        const bool any = tables && yl >= 0 && xl >= 0;           // at least one sample inside the map
+        const int ny = yl - y0 + 1, nx = xl - x0 + 1;
+        const bool staged = any && ny * nx <= ROI_FOOT;
+        if (staged) {
+            // every distinct cell once: wave w takes cells w, w + 8, ...; split rows are decoded here, once per cell
+            // (all of a wave's loads are issued before the first LDS write: one cell per loop trip cost a full memory round trip each)
+            constexpr int PER_WAVE = ROI_FOOT / 8;
+            f32x4 t[PER_WAVE];
+#pragma unroll
+            for (int u = 0; u < PER_WAVE; ++u) {
+                const int q = wave + 8 * u;
+                if (q < ny * nx) {
+                    const int cy = q / nx, cx = q - cy * nx;
+                    t[u] = load_tap<IN_SPLIT>(fb + ((size_t)(y0 + cy) * W + x0 + cx) * a.C, lane);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PER_WAVE; ++u)
+                if (wave + 8 * u < ny * nx) foot[wave + 8 * u][lane] = t[u];
+        }
+        __syncthreads();
+        for (int pw = wave; pw < a.P; pw += 8) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (staged) {
+                for (int iy = 0; iy < gh; ++iy) {
+                    const RoiTab ty = rowtab[iy];
+                    if (ty.lo < 0) continue;
+                    const int ry0 = (ty.lo - y0) * nx - x0, ry1 = (ty.hi - y0) * nx - x0;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const RoiTab tx = coltab[pw * gw + ix];
+                        if (tx.lo < 0) continue;
+                        const float w1 = __fmul_rn(ty.h, tx.h), w2 = __fmul_rn(ty.h, tx.l), w3 = __fmul_rn(ty.l, tx.h), w4 = __fmul_rn(ty.l, tx.l);
+                        const f32x4 v1 = foot[ry0 + tx.lo][lane];
+                        const f32x4 v2 = foot[ry0 + tx.hi][lane];
+                        const f32x4 v3 = foot[ry1 + tx.lo][lane];
+                        const f32x4 v4 = foot[ry1 + tx.hi][lane];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
+                            acc[e] = __fadd_rn(acc[e], t);
+                        }
+                    }
+                }
+            } else if (!tables || any) {
+                // too many cells or too large a grid for the tables: the direct path (roi_align_kernel's loop)
+                for (int iy = 0; iy < gh; ++iy) {
+                    float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+                    const bool ybad = (y < -1.0f) || (y > (float)H);
+                    if (y <= 0.f) y = 0.f;
+                    int ylo = (int)y, yhi;
+                    if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+                    const float ly = __fsub_rn(y, (float)ylo), hy = __fsub_rn(1.0f, ly);
+                    for (int ix = 0; ix < gw; ++ix) {
+                        float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                        if (ybad || (x < -1.0f) || (x > (float)W)) continue;
+                        if (x <= 0.f) x = 0.f;
+                        int xlo = (int)x, xhi;
+                        if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+                        const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
+                        const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                        const f32x4 v1 = load_tap<IN_SPLIT>(fb + ((size_t)ylo * W + xlo) * a.C, lane);
+                        const f32x4 v2 = load_tap<IN_SPLIT>(fb + ((size_t)ylo * W + xhi) * a.C, lane);
+                        const f32x4 v3 = load_tap<IN_SPLIT>(fb + ((size_t)yhi * W + xlo) * a.C, lane);
+                        const f32x4 v4 = load_tap<IN_SPLIT>(fb + ((size_t)yhi * W + xhi) * a.C, lane);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
+                            acc[e] = __fadd_rn(acc[e], t);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __fdiv_rn(acc[e], count);
+            const long long bin = row * a.P + pw;
+            f32x4* o4 = reinterpret_cast<f32x4*>(a.out) + (size_t)bin * C4;
+            if (a.out_split) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const _Float16 h = (_Float16)acc[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)((acc[e] - (float)h) * 2048.0f);
+                }
+                const int ch = 4 * lane;
+                char* base = reinterpret_cast<char*>(o4) + (ch >> 5) * 128 + (ch & 31) * 2;
+                *reinterpret_cast<f16x4*>(base) = hi;
+                *reinterpret_cast<f16x4*>(base + 64) = lo;
+            } else {
+                o4[lane] = acc;
+            }
+        }
+        __syncthreads();                                         // the tables and the cells are re-used by the next bin row
+    }
+}
+
 // Split-row feature maps (the trunk's native activation format): TWO bins per wave, a lane owns 8 channels of its half-wave's bin, so
 // a tap is one 16-B load of hi halves and one of lo' halves per lane (with 4 channels per lane they were 8-B loads and the kernel ran
 // 50 % longer).  Bins 2w and 2w+1 mostly belong to one RoI (same sampling grid); where they do not, the two halves of the wave run
@@ -232,6 +516,9 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
 
 }  // namespace
 
+static int g_roi_lanes = getenv("AMP_ROI_LANES") ? atoi(getenv("AMP_ROI_LANES")) : 1;   // 1: lane-parallel sample parameters (default); 0: the reference kernel (every lane computes every sample's parameters); 3: one workgroup per bin row, cells staged in LDS (slower, see roi_align_rows_kernel)
+extern "C" void amp_debug_set_roi_lanes(int v) { g_roi_lanes = v; }
+
 namespace amp {
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
                   float* out, int* level_out, int out_split, int in_split);
@@ -266,11 +553,17 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
     const long long nbins = (long long)R * P * P;
     long long g = (nbins + 3) / 4;
     if (g > 65536) g = 65536;
-    if (in_split && f->C == 256) {
+    if (g_roi_lanes == 3 && f->C == 256) {
+        long long gr = (long long)R * P;
+        if (gr > 16384) gr = 16384;
+        if (in_split) hipLaunchKernelGGL(roi_align_rows_kernel<true>, dim3((unsigned)gr), dim3(512), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(roi_align_rows_kernel<false>, dim3((unsigned)gr), dim3(512), 0, ctx->stream, a);
+    } else if (in_split && f->C == 256) {
         long long g2 = (nbins + 7) / 8;              // two bins per wave
         if (g2 > 65536) g2 = 65536;
         hipLaunchKernelGGL(roi_align_split_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
     } else if (in_split) hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
+    else if (g_roi_lanes) hipLaunchKernelGGL(roi_align_lanes_kernel<0>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(roi_align_kernel<false>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;

@@ -229,6 +229,11 @@ int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const flo
 
 /* Stages a16 / a17 / a3: mask probability, paste + threshold + RLE counts ----------------------- */
 int amp_mask_prob(amp_ctx* ctx, const float* logits, const int* classes, int N, int K, float* prob);
+/* the tail of the mask head in one kernel (AMP_CONV_F16X3): x_split [N,14,14,256] (split rows) -> ConvTranspose2d 2x2 s2 (w_deconv
+ * [(ky,kx,co)][256], bias [1024] = the 256 biases once per tap) -> ReLU -> predictor row of classes[n] (pred_w [K][256], pred_b [K]) ->
+ * sigmoid -> prob [N,28,28]; the [N,28,28,256] activation is never written */
+int amp_mask_deconv_predict(amp_ctx* ctx, const float* x_split, int N, const float* w_deconv, const float* bias, const float* pred_w,
+                            const float* pred_b, const int* classes, int K, float* prob);
 int amp_paste_rle(amp_ctx* ctx, const float* prob, const float* det_boxes, const int* det_batch, int N, const int* out_h,
                   const int* out_w, int max_out_hw, int in_h, int in_w, float threshold, float* out_boxes, int* valid,
                   unsigned int* pool, unsigned long long pool_cap, unsigned long long* pool_used, unsigned long long* rle_off,

@@ -228,3 +228,73 @@ def test_paste_rle_matches_oracle(gpu_ctx):
             assert margin.max() < 1e-6, (i, float(margin.max()))
             nflip += len(ys)
     assert nflip <= 4, f"{nflip} pixels differ from the oracle paste"
+
+
+def test_roi_align_lane_parallel_kernel_equals_the_reference_kernel(gpu_ctx):
+    """roi_align_lanes_kernel (sample parameters computed once per bin, one lane per sample row / column, broadcast by v_readlane)
+    is the same arithmetic as roi_align_kernel (every lane computes every sample): bit-identical, including sampling grids beyond
+    64 samples per side (chunked), boxes outside the map and empty boxes."""
+    from ampis_amd import ops, _lib
+    g = torch.Generator().manual_seed(5)
+    B, H, W, C = 2, 128, 160, 256
+    feats = [torch.randn(B, H // s, W // s, C, generator=g).to(DEV) for s in (1, 2, 4, 8)]
+    R = 400
+    ctr = torch.rand(R, 2, generator=g) * torch.tensor([4.0 * W, 4.0 * H])
+    size = torch.exp(torch.rand(R, 2, generator=g) * 6.5 + 0.5)
+    rois = torch.cat([ctr - size / 2, ctr + size / 2], 1).float()
+    rois[0] = torch.tensor([-300.0, -200.0, -100.0, -50.0])          # entirely outside
+    rois[1] = torch.tensor([10.0, 10.0, 10.0, 40.0])                 # zero width
+    rois[2] = torch.tensor([0.0, 0.0, 4.0 * W, 4.0 * H])             # the whole image: level p5 ... 
+    rois[3] = torch.tensor([0.0, 0.0, 20000.0, 30.0])                # > 64 sample columns per bin on p5 (clamped level)
+    rois = rois.to(DEV)
+    bidx = (torch.arange(R) % B).int().to(DEV)
+    outs = []
+    try:
+        for v in (0, 1, 3):
+            _lib.lib().amp_debug_set_roi_lanes(v)
+            outs.append([ops.roi_align(gpu_ctx, feats, rois, bidx, P)[0] for P in (7, 14)])
+    finally:
+        _lib.lib().amp_debug_set_roi_lanes(1)
+    torch.cuda.synchronize()
+    for k in (1, 2):          # outs[1]: lane-parallel parameters, outs[2]: one workgroup per bin row, cells staged once in LDS
+        for a, b in zip(outs[0], outs[k]):
+            assert torch.equal(a, b), k
+
+
+def test_fused_mask_tail_matches_the_three_stage_chain(gpu_ctx):
+    """amp_mask_deconv_predict (ConvTranspose 2x2 + ReLU + predictor row of the class + sigmoid in the deconv's epilogue) against
+    (a) the three kernels it replaces and (b) torch in fp64."""
+    import ctypes as C
+    from ampis_amd import ops, _lib
+    g = torch.Generator().manual_seed(12)
+    N, K = 37, 3
+    x = (torch.randn(N, 14, 14, 256, generator=g).clamp_(min=0) * 2).to(DEV)
+    wd = (torch.randn(256, 256, 2, 2, generator=g) * 0.05)                       # ConvTranspose2d weight [Cin][Cout][2][2]
+    bd = torch.randn(256, generator=g) * 0.1
+    wp = (torch.randn(K, 256, generator=g) * 0.05)
+    bp = torch.randn(K, generator=g) * 0.1
+    cls = torch.randint(0, K, (N,), generator=g).int()
+    # library layout of the deconv: [(ky,kx,co)][ci], bias repeated per tap
+    w_lib = wd.permute(2, 3, 1, 0).reshape(1024, 1, 1, 256).contiguous().to(DEV)
+    b_lib = bd.repeat(4).contiguous().to(DEV)
+    xs = ops.split_rows(gpu_ctx, x)
+    prob = torch.empty(N, 28, 28, device=DEV)
+    wp_d, bp_d, cls_d = wp.to(DEV), bp.to(DEV), cls.to(DEV)          # (kept alive: the call only takes their addresses)
+    _lib.check(_lib.lib().amp_mask_deconv_predict(gpu_ctx.handle, _lib.ptr(xs), N, _lib.ptr(w_lib), _lib.ptr(b_lib), _lib.ptr(wp_d),
+                                                  _lib.ptr(bp_d), _lib.ptr(cls_d), K, _lib.ptr(prob)), "amp_mask_deconv_predict")
+    # (a) the unfused chain of the library
+    y = ops.conv2d_nhwc(gpu_ctx, x, w_lib, None, b_lib, relu=True, deconv2x2=True)                       # [N,28,28,256]
+    Kp = 4
+    wpp = torch.zeros(Kp, 1, 1, 256); wpp[:K, 0, 0] = wp
+    bpp = torch.zeros(Kp); bpp[:K] = bp
+    logits = ops.conv2d_nhwc(gpu_ctx, y, wpp.to(DEV), None, bpp.to(DEV))
+    torch.cuda.synchronize()
+    chain = torch.sigmoid(logits.cpu()[torch.arange(N), :, :, cls.long()])
+    # (b) fp64 reference
+    ref = torch.nn.functional.conv_transpose2d(x.cpu().double().permute(0, 3, 1, 2), wd.double(), bd.double(), stride=2).relu()
+    ref = torch.einsum("nchw,nc->nhw", ref, wp.double()[cls.long()]) + bp.double()[cls.long()].view(-1, 1, 1)
+    ref = torch.sigmoid(ref)
+    e_chain, e_fused = (chain.double() - ref).abs().max().item(), (prob.cpu().double() - ref).abs().max().item()
+    print("max |prob - fp64|: three-stage chain", e_chain, "fused", e_fused)
+    assert e_chain < 2e-6 and e_fused < 2e-6
+    assert not gpu_ctx.conv_range_flag()

@@ -1,0 +1,43 @@
+"""RoIAlign micro-benchmark at the bench's shape (B=8, 1024^2 -> p2..p5, 256 channels): realistic proposals vs degenerate ones that
+all hit the same few cells (everything from L2): tells memory time from instruction / latency time."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ampis_amd import ops
+
+ctx = ops.torch_context(0)
+if os.environ.get('AMP_ROI_LANES'):
+    from ampis_amd import _lib
+    _lib.lib().amp_debug_set_roi_lanes(int(os.environ['AMP_ROI_LANES']))
+d = "cuda:0"
+B, S, C = 8, 1024, 256
+g = torch.Generator().manual_seed(0)
+feats = [torch.randn(B, S // s, S // s, C, device=d) for s in (4, 8, 16, 32)]
+fs = [ops.split_rows(ctx, f) for f in feats]
+
+
+def rois_like_proposals(n_per_img):
+    ctr = torch.rand(B * n_per_img, 2, generator=g) * S
+    size = torch.exp(torch.randn(B * n_per_img, 2, generator=g) * 0.6 + 4.3).clamp(8, 800)      # median ~74 px
+    r = torch.cat([ctr - size / 2, ctr + size / 2], 1).clamp(0, S).float()
+    return r.to(d), (torch.arange(B * n_per_img) // n_per_img).int().to(d)
+
+
+def run(name, rois, bidx, P, fmt, F):
+    for _ in range(2):
+        ops.roi_align(ctx, F, rois, bidx, P, fmt=fmt)
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for _ in range(5):
+        ops.roi_align(ctx, F, rois, bidx, P, fmt=fmt)
+    ms = ctx.timer_stop() / 5
+    out_gb = rois.shape[0] * P * P * C * 4 / 1e9
+    print(f"{name:44s} P={P:2d} R={rois.shape[0]:5d}  {ms * 1e3:8.1f} us   (output {out_gb:.2f} GB -> {out_gb / ms:.2f} TB/s of writes)", flush=True)
+
+
+for P, n in ((7, 1000), (14, 200)):
+    rois, bidx = rois_like_proposals(n)
+    same = rois.clone(); same[:] = torch.tensor([100.0, 100.0, 174.0, 174.0])
+    for nm, F, fmt in (("fp32 maps", feats, 0), ("split maps -> split out", fs, 3)):
+        run(f"{nm}, proposal-like boxes", rois, bidx, P, fmt, F)
+        run(f"{nm}, every box the same 74 px box", same, bidx * 0, P, fmt, F)
