@@ -158,6 +158,7 @@ def _declare(L):
         "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_model_forward_backward": ([vp, vp, i, i, i, i, C.POINTER(Gt), C.c_uint, C.POINTER(f)], i),
         "amp_model_grad_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
+        "amp_model_momentum_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
         "amp_model_sgd_step": ([vp, f, f, f, f], i),
         "amp_model_get_tensor": ([vp, C.c_char_p, i, vp, C.c_size_t], i),
         "amp_roi_align_bwd": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp], i),

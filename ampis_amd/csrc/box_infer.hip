@@ -13,6 +13,7 @@ struct CandArgs {
     int B, Rcap, K, ld;
     float wx, wy, ww, wh, scale_clamp, score_thresh, img_h, img_w;
     const int* img_hw;        // optional device [B][2]: per-image (h, w) to clip to
+    const float* thresh_img;  // optional device [B]: per-image score floor (>= score_thresh) instead of score_thresh
     float* dense_boxes;       // [B][Rcap*K][4] decoded + clipped boxes
     unsigned long long* keys; // [B][ccap] compacted candidate keys (zeroed by the caller)
     int* cand_count;          // [B] (zeroed by the caller)
@@ -53,7 +54,7 @@ __global__ void box_candidates_kernel(const CandArgs a) {
         if (!all_finite) continue;
         for (int k = 0; k < a.K; ++k) {
             const float p = __fdiv_rn(expf(__fsub_rn(row[k], mx)), sum);
-            bool take = p > a.score_thresh;
+            bool take = p > (a.thresh_img ? a.thresh_img[b] : a.score_thresh);
             // one atomic per (wave, image) instead of one per candidate: thousands of adds to the same 8 counters were 4/5 of the
             // kernel.  Slot order is arbitrary either way (the candidates are sorted by key afterwards).
             while (true) {
@@ -144,6 +145,16 @@ int amp_box_candidates(amp_ctx* ctx, const float* pred, int ld, const float* pro
 int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B,
                              int Rcap, int K, const float reg_weights[4], float score_thresh, int img_h, int img_w, const int* img_hw,
                              float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow) {
+    return amp::box_candidates_run(ctx, pred, ld, proposals, prop_count, B, Rcap, K, reg_weights, score_thresh, img_h, img_w, img_hw, nullptr,
+                                   dense_boxes, keys, ccap, cand_count, overflow);
+}
+
+}  // extern "C"
+
+// thresh_img: optional device [B] per-image score floors (model.hip raises them for an image with more than ccap candidates)
+int amp::box_candidates_run(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B, int Rcap, int K,
+                            const float reg_weights[4], float score_thresh, int img_h, int img_w, const int* img_hw, const float* thresh_img,
+                            float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow) {
     AMP_REQUIRE(ctx && pred && proposals && prop_count && reg_weights && dense_boxes && keys && cand_count && overflow,
                 "amp_box_candidates: null argument");
     AMP_REQUIRE(B >= 1 && Rcap >= 1 && K >= 1 && K <= 255 && ld >= 5 * K + 1, "amp_box_candidates: bad shape");
@@ -154,6 +165,7 @@ int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const floa
     a.wx = reg_weights[0]; a.wy = reg_weights[1]; a.ww = reg_weights[2]; a.wh = reg_weights[3];
     a.scale_clamp = (float)log(1000.0 / 16.0);
     a.score_thresh = score_thresh; a.img_h = (float)img_h; a.img_w = (float)img_w; a.img_hw = img_hw;
+    a.thresh_img = thresh_img;
     a.dense_boxes = dense_boxes; a.keys = keys; a.cand_count = cand_count; a.ccap = ccap; a.overflow = overflow;
     AMP_HIP_CHECK(hipMemsetAsync(keys, 0, (size_t)B * ccap * sizeof(unsigned long long), ctx->stream));
     AMP_HIP_CHECK(hipMemsetAsync(cand_count, 0, (size_t)B * sizeof(int), ctx->stream));
@@ -161,6 +173,8 @@ int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const floa
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }
+
+extern "C" {
 
 int amp_gather_dets(amp_ctx* ctx, int B, int cap, int D, const float* sboxes, const float* sscores, const int* scats,
                     const int* keep_idx, const int* keep_count, float* det_boxes, float* det_scores, int* det_classes,

@@ -34,6 +34,7 @@ void set_error(const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__   // device helpers: absent from the host-only sanitizer build of the RLE codec (tests/sanitize, plain g++)
 // Bijective XCD-aware block remap: blocks b and b+8 share an XCD under the observed
 // round-robin dispatch, so hand each XCD a contiguous chunk of the logical grid
 // (neighbouring tiles share operand panels in that XCD's L2). Speed only, never correctness.
@@ -64,6 +65,7 @@ __device__ __forceinline__ unsigned long long make_sortkey(uint32_t ord_score, i
 }
 __device__ __forceinline__ int sortkey_pos(unsigned long long k) { return (int)(0xffffffu - (uint32_t)((k >> 8) & 0xffffffu)); }
 __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(k & 0xffu); }
+#endif  // __HIPCC__
 
 }  // namespace amp
 
@@ -112,6 +114,9 @@ int comm_wait_done(amp_ctx* ctx);              // compute stream waits (device s
 int comm_agree_flag(amp_ctx* ctx, int* d_flag); // MAX of a device int over the ranks, complete on return
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
                   float* out, int* level_out, int out_split, int in_split = 0);   // out_split / in_split = 1: pooled tensor / feature maps in the split row format
+int box_candidates_run(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B, int Rcap, int K,
+                       const float reg_weights[4], float score_thresh, int img_h, int img_w, const int* img_hw, const float* thresh_img,
+                       float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
 // only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)

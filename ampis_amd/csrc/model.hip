@@ -497,33 +497,78 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(det_boxes, float, (size_t)B * D * 4);
     AMP_ALLOC(det_scores, float, (size_t)B * D);
     AMP_ALLOC(det_classes, int, (size_t)B * D);
+    AMP_ALLOC(d_floor, float, (size_t)B);          // per-image score floors (only used when an image has more than ccap candidates)
     if (!dry) {
         const bool bchain = split_chain(m, {"roi_heads.box_head.fc1", "roi_heads.box_head.fc2"});
         AMP_TRY(amp::roi_align_run(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr, bchain ? 1 : 0, T.feat_split ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1, bchain ? 3 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2, bchain ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
-        AMP_TRY(amp_box_candidates_sized(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
-                                         H, W, T.img_hw, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
-        AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
-        AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
-        AMP_TRY(amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr));
+        auto detect = [&](const float* thresh_img) -> int {      // candidates above the score floor -> order -> per-class NMS -> first D
+            AMP_TRY(amp::box_candidates_run(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
+                                            H, W, T.img_hw, thresh_img, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
+            AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
+            AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
+            return amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr);
+        };
+        AMP_TRY(detect(nullptr));
         tap(m, "box_pooled", pooled, bchain ? 5 : 0, {R, 7, 7, 256});
         tap(m, "box_pred", box_pred, 0, {R, ld_box});
         tap(m, "det_boxes", det_boxes, 0, {B, D, 4});
         tap(m, "det_scores", det_scores, 0, {B, D});
         tap(m, "det_classes", det_classes, 1, {B, D});
         tap(m, "det_count", det_count, 1, {B});
-    }
-
-    // ---------------- sync point: detection counts decide the mask-branch GEMM sizes ----------------
-    int N = B * D;   // dry run: worst case
-    std::vector<int> off(B + 1, 0);
-    if (!dry) {
+        // ---------------- sync point: detection counts decide the mask-branch GEMM sizes ----------------
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts, det_count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (m->h_counts[B + 0]) { amp::set_error("amp_model_infer: more than %d box candidates above SCORE_THRESH_TEST in one image", ccap); return AMP_ERR_NOMEM; }
+        if (m->h_counts[B + 0]) {
+            // An image has more than ccap candidates above SCORE_THRESH_TEST (many classes, a low threshold).  Greedy NMS takes its
+            // decisions in score order, so the detections are decided by a PREFIX of the candidate list: raise that image's score floor
+            // (bisection on the candidate count) until the prefix fits, run the chain again, and the result is the exact one as long as
+            // the prefix still yields D detections.  Only if it does not -- more than ccap candidates and fewer than D of the best
+            // ccap survive NMS -- is the batch refused.
+            std::vector<float> lo(B, c.score_thresh), hi(B, 1.0f), cur(B, c.score_thresh);   // lo: overflows, hi: fits (a floor of 1 keeps nothing)
+            std::vector<int> cnt(B);
+            std::vector<char> raised(B, 0), done(B, 0);
+            for (int it = 0; it < 30; ++it) {
+                AMP_HIP_CHECK(hipMemcpyAsync(d_floor, cur.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+                AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, sizeof(int), ctx->stream));
+                AMP_TRY(amp::box_candidates_run(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
+                                                H, W, T.img_hw, d_floor, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
+                AMP_HIP_CHECK(hipMemcpyAsync(cnt.data(), bcount, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+                AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                bool again = false;
+                for (int b = 0; b < B; ++b) {
+                    if (done[b]) continue;
+                    if (cnt[b] > ccap) { lo[b] = cur[b]; raised[b] = 1; }
+                    else if (!raised[b]) { done[b] = 1; continue; }                 // never overflowed: its floor stays SCORE_THRESH_TEST
+                    else { hi[b] = cur[b]; if (cnt[b] >= ccap * 3 / 4 || hi[b] - lo[b] < 1e-7f) { done[b] = 1; continue; } }
+                    cur[b] = 0.5f * (lo[b] + hi[b]);
+                    again = true;
+                }
+                if (!again) break;
+                if (it == 29) for (int b = 0; b < B; ++b) if (!done[b]) cur[b] = hi[b];     // the last floor known to fit
+            }
+            AMP_HIP_CHECK(hipMemcpyAsync(d_floor, cur.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+            AMP_HIP_CHECK(hipMemsetAsync(m->d_flags, 0, sizeof(int), ctx->stream));
+            AMP_TRY(detect(d_floor));
+            AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts, det_count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (int b = 0; b < B; ++b)
+                if (raised[b] && m->h_counts[b] < D) {
+                    amp::set_error("amp_model_infer: image %d has more than %d box candidates above SCORE_THRESH_TEST and fewer than %d of the best %d survive NMS: "
+                                   "the result would depend on candidates that do not fit (raise SCORE_THRESH_TEST)", b, ccap, D, ccap);
+                    return AMP_ERR_NOMEM;
+                }
+            if (m->h_counts[B + 0]) { amp::set_error("amp_model_infer: box candidates overflowed after the score floor was raised"); return AMP_ERR_STATE; }
+        }
+    }
+
+    int N = B * D;   // dry run: worst case
+    std::vector<int> off(B + 1, 0);
+    if (!dry) {
         for (int b = 0; b < B; ++b) off[b + 1] = off[b] + std::min(m->h_counts[b], D);
         N = off[B];
     }
@@ -1156,17 +1201,25 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     const int R = cfg->max_batch * cfg->post_nms_topk;
     std::vector<int> iota(R);
     for (int i = 0; i < R; ++i) iota[i] = i / cfg->post_nms_topk;
-    (void)hipMalloc(&m->d_batch_iota, (size_t)R * sizeof(int));
-    (void)hipMemcpy(m->d_batch_iota, iota.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice);
-    (void)hipMalloc(&m->d_flags, 4 * sizeof(int));
-    (void)hipMemset(m->d_flags, 0, 4 * sizeof(int));
-    (void)hipHostMalloc(&m->h_counts, (size_t)(cfg->max_batch + 8) * sizeof(int));
     m->h_res_bytes = (size_t)cfg->max_batch * cfg->detections_per_image * 48 + 16 * 256;
-    (void)hipHostMalloc(&m->h_res, m->h_res_bytes);
-    // run-length staging: pinned for the DMA, non-coherent = cacheable for the host that reads it after the stream sync
+    // every small device / pinned allocation is checked: under memory pressure (two contexts per GPU, a re-created training net) a
+    // failed one must surface as AMP_ERR_NOMEM here, not as a fault in the first call that touches the null pointer
+    bool ok = hipMalloc(&m->d_batch_iota, (size_t)R * sizeof(int)) == hipSuccess &&
+              hipMemcpy(m->d_batch_iota, iota.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc(&m->d_flags, 4 * sizeof(int)) == hipSuccess && hipMemset(m->d_flags, 0, 4 * sizeof(int)) == hipSuccess &&
+              hipHostMalloc(&m->h_counts, (size_t)(cfg->max_batch + 8) * sizeof(int)) == hipSuccess &&
+              hipHostMalloc(&m->h_res, m->h_res_bytes) == hipSuccess &&
+              hipHostMalloc(&m->h_small, (size_t)(2 * cfg->max_batch + cfg->max_batch * cfg->detections_per_image + 8) * sizeof(int)) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        amp::set_error("amp_model_create: out of memory allocating the index / flag / pinned staging buffers");
+        amp_model_destroy(m);
+        return AMP_ERR_NOMEM;
+    }
+    // run-length staging: pinned for the DMA, non-coherent = cacheable for the host that reads it after the stream sync (optional:
+    // without it the results go through a pageable vector)
     m->h_pool_counts = (size_t)std::min<unsigned long long>(m->cfg.rle_pool_counts, (unsigned long long)64 << 20);
     if (hipHostMalloc(reinterpret_cast<void**>(&m->h_pool), m->h_pool_counts * 4, hipHostMallocNonCoherent) != hipSuccess) { m->h_pool = nullptr; m->h_pool_counts = 0; (void)hipGetLastError(); }
-    (void)hipHostMalloc(&m->h_small, (size_t)(2 * cfg->max_batch + cfg->max_batch * cfg->detections_per_image + 8) * sizeof(int));
     *out = m;
     return AMP_OK;
 }
@@ -1174,6 +1227,8 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
 void amp_model_destroy(amp_model* m) {
     if (!m) return;
     (void)hipFree(m->parena);
+    (void)hipFree(m->garena);
+    (void)hipFree(m->varena);
     (void)hipFree(m->split_arena);
     (void)hipFree(m->img_stage);
     (void)hipFree(m->ws.base);
@@ -1546,6 +1601,13 @@ int amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_deca
 int amp_model_grad_arena(amp_model* m, float** grads, size_t* nfloats) {
     AMP_REQUIRE(m && grads && nfloats && m->garena, "amp_model_grad_arena: the model was created without cfg.train_enable");
     *grads = m->garena;
+    *nfloats = m->parena_used;
+    return AMP_OK;
+}
+
+int amp_model_momentum_arena(amp_model* m, float** vel_dev, size_t* nfloats) {
+    AMP_REQUIRE(m && vel_dev && nfloats && m->varena, "amp_model_momentum_arena: the model was created without cfg.train_enable");
+    *vel_dev = m->varena;
     *nfloats = m->parena_used;
     return AMP_OK;
 }

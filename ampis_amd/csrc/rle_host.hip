@@ -58,21 +58,26 @@ int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int*
     int m = 0;
     size_t p = 0;
     while (p < len) {
-        long long x = 0;
+        unsigned long long x = 0;
         int k = 0;
         bool more = true;
         while (more) {
             AMP_REQUIRE(p < len, "amp_rle_from_string: truncated counts string");
             const int c = (int)(unsigned char)s[p] - 48;
-            x |= (long long)(c & 0x1f) << (5 * k);
+            AMP_REQUIRE(c >= 0 && c < 64, "amp_rle_from_string: byte 0x%02x at offset %zu is not a counts character", (unsigned)(unsigned char)s[p], p);
+            // a 32-bit run (or its signed delta) needs at most 7 groups of 5 bits; hostile input must not shift past the word (UB)
+            AMP_REQUIRE(k < 8, "amp_rle_from_string: a run of more than 8 groups at offset %zu", p);
+            x |= (unsigned long long)(c & 0x1f) << (5 * k);
             more = (c & 0x20) != 0;
             ++p;
             ++k;
-            if (!more && (c & 0x10)) x |= -1ll << (5 * k);
+            if (!more && (c & 0x10)) x |= ~0ull << (5 * k);      // sign extension
         }
-        if (m > 2) x += (long long)cnts[m - 2];
+        long long v = (long long)x;
+        if (m > 2) v += (long long)cnts[m - 2];
+        AMP_REQUIRE(v >= 0 && v <= 0xffffffffll, "amp_rle_from_string: run %d decodes to %lld (not a 32-bit run length)", m, v);
         AMP_REQUIRE(m < cap, "amp_rle_from_string: more than cap=%d runs", cap);
-        cnts[m++] = (uint32_t)x;
+        cnts[m++] = (uint32_t)v;
     }
     *m_out = m;
     return AMP_OK;

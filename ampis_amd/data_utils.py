@@ -54,87 +54,101 @@ def _imread(path):
     return np.asarray(Image.open(str(path)))
 
 
+def _instance(box, segmentation):
+    """One annotation entry of a dataset dict (single-class: category 0, ampis/data_utils.py:428,474,520)."""
+    from .structures import BoxMode
+    return {"bbox": box, "bbox_mode": BoxMode.XYXY_ABS, "segmentation": segmentation, "category_id": 0}
+
+
+def _ddict(image_id, file_name, annotation_file, hw, mask_format, instances, dataset_class, **extra):
+    """The dataset-dict schema every label format ends in (keys as the reference writes them: ampis/data_utils.py:390-532)."""
+    d = {"file_name": file_name, "annotation_file": annotation_file, "height": int(hw[0]), "width": int(hw[1]), "mask_format": mask_format,
+         "image_id": image_id, "dataset_class": dataset_class}
+    d.update(extra)
+    d["annotations"] = instances
+    d["num_instances"] = len(instances)
+    return d
+
+
+def _label_image_records(fmt, im_root, ann_root, pattern):
+    """'binary' / 'label': one annotation image (or .npy) per micrograph; 'binary' is split into its 8-connected components (the
+    default of skimage.measure.label), 'label' already carries one id per instance.  Yields (image path, annotation path, hw, masks)."""
+    from scipy import ndimage
+    for img_path in sorted(im_root.glob(pattern)):
+        found = list(ann_root.glob("*{}*".format(img_path.stem)))
+        assert len(found) == 1, f"There must be exactly 1 annotation file for, {img_path.name}, but {len(found)} were found"
+        ann = np.load(str(found[0])) if found[0].suffix == ".npy" else _imread(found[0])
+        hw = ann.shape[:2]
+        if fmt == "binary":
+            fg = (ann if ann.ndim == 2 else ann[..., 0]).astype(bool)
+            ann = ndimage.label(fg, structure=np.ones((3, 3), int))[0]
+        ids = np.unique(ann)
+        yield img_path, found[0], hw, [ann == u for u in ids[ids != 0]] if ids.size and ids[0] == 0 else [ann == u for u in ids]
+
+
+def _via2_records(json_path):
+    """VIA 2.x project file: per image the declared size (file attribute 'Size (width, height)', else read from the image) and one
+    polygon per region, vertices moved to pixel centres (+0.5).  Yields (image path, hw, HFW attribute, [(box, polygon)])."""
+    import json
+    from pathlib import Path
+    with open(json_path, "rb") as f:
+        project = json.load(f)
+    img_dir = Path(json_path.parent, project["_via_settings"]["core"]["default_filepath"])
+    for entry in project["_via_img_metadata"].values():
+        img_path = Path(img_dir, entry["filename"])
+        attrs = entry["file_attributes"]
+        declared = attrs.get("Size (width, height)", None)
+        if declared:
+            w, h = (int(v) for v in declared.split(", "))
+        else:
+            h, w = _imread(img_path).shape[:2]
+        regions = []
+        for region in entry["regions"]:
+            xs, ys = region["shape_attributes"]["all_points_x"], region["shape_attributes"]["all_points_y"]
+            outline = np.stack([np.asarray(xs, float) + 0.5, np.asarray(ys, float) + 0.5], axis=1).reshape(-1).tolist()
+            regions.append((np.asarray((np.min(xs), np.min(ys), np.max(xs), np.max(ys))), [outline]))
+        yield img_path, (h, w), attrs.get("HFW", None), regions
+
+
+def _rle_records(json_path):
+    """JSON list of {'file_name', 'segmentations': [COCO RLE]} (counts as str or bytes).  Yields (image path, hw, [rle])."""
+    import json
+    from pathlib import Path
+    with open(json_path, "r") as f:
+        items = json.load(f)
+    for item in items:
+        rles = [{"size": seg["size"], "counts": seg["counts"].encode("utf-8") if isinstance(seg["counts"], str) else seg["counts"]}
+                for seg in item["segmentations"]]
+        yield Path(json_path.parent, Path(item["file_name"])), tuple(rles[0]["size"]), rles
+
+
 def get_ddicts(label_fmt, im_root, ann_root=None, pattern="*", dataset_class=None):
     """Images + single-class instance annotations -> detectron2 dataset dicts. label_fmt: 'binary' | 'label' (annotation images /
     .npy next to the images), 'via2' (VIA 2 JSON; im_root is the JSON path), 'rle' (JSON list of {'file_name','segmentations'})."""
-    import json
     from pathlib import Path
-
-    from .structures import BoxMode
-    cwd = Path()
     im_root = Path(im_root)
     ann_root = Path(ann_root) if ann_root else None
-    ddicts = []
     fmt = label_fmt.lower()
 
-    def rel(p):
+    def rel(path):      # paths relative to the working directory where possible, as the reference stores them
         try:
-            return str(Path(p).relative_to(cwd))
+            return str(Path(path).relative_to(Path()))
         except ValueError:
-            return str(p)
+            return str(path)
 
+    out = []
     if fmt in ("binary", "label"):
-        from scipy import ndimage
-        for idx, p in enumerate(sorted(im_root.glob(pattern))):
-            found = list(ann_root.glob("*{}*".format(p.stem)))
-            n = len(found)
-            assert n == 1, f"There must be exactly 1 annotation file for, {p.name}, but {n} were found"
-            ann_path = found[0]
-            ann = np.load(str(ann_path)) if ann_path.suffix == ".npy" else _imread(ann_path)
-            height, width = ann.shape[:2]
-            ddict = {"file_name": rel(p), "annotation_file": rel(ann_path), "height": height, "width": width, "mask_format": "bitmask",
-                     "image_id": idx, "dataset_class": dataset_class}
-            if fmt == "binary":   # skimage.measure.label default = full (8-) connectivity, labels in raster order
-                ann = ndimage.label(ann.astype(bool) if ann.ndim == 2 else ann[..., 0].astype(bool), structure=np.ones((3, 3), int))[0]
-            unique = np.unique(ann)
-            if unique[0] == 0:
-                unique = unique[1:]
-            annotations = []
-            for u in unique:
-                mask = ann == u
-                annotations.append({"bbox": extract_boxes(mask)[0], "bbox_mode": BoxMode.XYXY_ABS,
-                                    "segmentation": RLE.encode(np.asfortranarray(mask)), "category_id": 0})
-            ddict["annotations"] = annotations
-            ddict["num_instances"] = len(annotations)
-            ddicts.append(ddict)
+        for img, ann_path, hw, masks in _label_image_records(fmt, im_root, ann_root, pattern):
+            inst = [_instance(extract_boxes(m)[0], RLE.encode(np.asfortranarray(m))) for m in masks]
+            out.append(_ddict(len(out), rel(img), rel(ann_path), hw, "bitmask", inst, dataset_class))
     elif fmt == "via2":
-        with open(im_root, "rb") as f:
-            j = json.load(f)
-        img_dir = Path(im_root.parent, j["_via_settings"]["core"]["default_filepath"])
-        for idx, annos in enumerate(j["_via_img_metadata"].values()):
-            filename = Path(img_dir, annos["filename"])
-            size = annos["file_attributes"].get("Size (width, height)", None)
-            if size:
-                width, height = tuple(int(x) for x in size.split(", "))
-            else:
-                height, width = _imread(filename).shape[:2]
-            ddict = {"file_name": rel(filename), "annotation_file": im_root.name, "height": height, "width": width,
-                     "mask_format": "polygon", "image_id": idx, "HFW": annos["file_attributes"].get("HFW", None),
-                     "dataset_class": dataset_class}
-            annotations = []
-            for obj in annos["regions"]:
-                shape = obj["shape_attributes"]
-                px, py = shape["all_points_x"], shape["all_points_y"]
-                poly = [v for x, y in zip(px, py) for v in (x + 0.5, y + 0.5)]
-                annotations.append({"bbox": np.asarray((np.min(px), np.min(py), np.max(px), np.max(py))), "bbox_mode": BoxMode.XYXY_ABS,
-                                    "segmentation": [poly], "category_id": 0})
-            ddict["annotations"] = annotations
-            ddict["num_instances"] = len(annotations)
-            ddicts.append(ddict)
+        for img, hw, hfw, regions in _via2_records(im_root):
+            inst = [_instance(box, poly) for box, poly in regions]
+            out.append(_ddict(len(out), rel(img), im_root.name, hw, "polygon", inst, dataset_class, HFW=hfw))
     elif fmt == "rle":
-        with open(im_root, "r") as f:
-            data = json.load(f)
-        for idx, p in enumerate(data):
-            ann = [{"size": a["size"], "counts": a["counts"].encode("utf-8") if isinstance(a["counts"], str) else a["counts"]}
-                   for a in p["segmentations"]]
-            height, width = ann[0]["size"]
-            ddict = {"file_name": rel(Path(im_root.parent, Path(p["file_name"]))), "annotation_file": str(im_root), "height": height,
-                     "width": width, "mask_format": "bitmask", "image_id": idx, "dataset_class": dataset_class}
-            annotations = [{"bbox": extract_boxes(RLE.decode(m))[0], "bbox_mode": BoxMode.XYXY_ABS, "segmentation": m, "category_id": 0}
-                           for m in ann]
-            ddict["annotations"] = annotations
-            ddict["num_instances"] = len(annotations)
-            ddicts.append(ddict)
+        for img, hw, rles in _rle_records(im_root):
+            inst = [_instance(extract_boxes(RLE.decode(m))[0], m) for m in rles]
+            out.append(_ddict(len(out), rel(img), str(im_root), hw, "bitmask", inst, dataset_class))
     else:
         raise ValueError("label_fmt must be 'binary','label', or 'via2'")
-    return ddicts
+    return out

@@ -145,10 +145,11 @@ class TrainModel:
     """What `trainer.model` is: callable on a batch (list of mapped dicts).  In training mode (the default, and what
     LossEvalHook relies on: ampis/data_utils.py:116) it returns the dict of the five losses as floats."""
 
-    def __init__(self, net, ctx):
+    def __init__(self, net, ctx, ensure=None):
         self.net, self.ctx = net, ctx
         self.training = True
         self._seed = 0
+        self._ensure = ensure          # callable (h, w): makes sure `net` exists and can take a batch of that frame (DefaultTrainer._ensure_net)
 
     def train(self, mode=True):
         self.training = mode
@@ -179,6 +180,8 @@ class TrainModel:
     def __call__(self, batch, backward=False, seed=None):
         assert self.training, "TrainModel is the training-mode surface; use DefaultPredictor for inference"
         imgs, sizes, gt = getattr(batch, "collated", None) or self.collate(batch)
+        if self._ensure is not None:   # a validation batch (LossEvalHook, ampis/data_utils.py:116) may be larger than every training batch so far
+            self._ensure(imgs.shape[1], imgs.shape[2])
         self.net.set_image_sizes(sizes)
         if seed is None:
             self._seed += 1
@@ -210,7 +213,9 @@ class DefaultTrainer:
         self.arch = P.arch_from_cfg(cfg)     # a grouped (ResNeXt) backbone is inference-only: amp_model_create refuses to train it
         self.params = P.init_params(self.num_classes, seed=max(int(cfg.get("SEED", -1)), 0), style="d2", arch=self.arch)
         self._net = None
-        self.model = TrainModel(None, self.ctx)            # net attached lazily (capacity depends on the first batch)
+        self._momentum = None                              # SGD velocity carried over a re-created net / read from a checkpoint
+        self.model = TrainModel(None, self.ctx, ensure=self._ensure_net)
+        self._cap = self._capacity_from_cfg()              # one allocation for everything the loaders can produce
         self._per_rank = int(cfg.SOLVER.IMS_PER_BATCH) // self.world_size
         self.data_loader = build_detection_train_loader(cfg, rank=comm.get_rank(), world_size=self.world_size,
                                                         seed=max(int(cfg.get("SEED", -1)), 0))
@@ -218,13 +223,44 @@ class DefaultTrainer:
         self.register_hooks(self.build_hooks())
 
     # ---- model / weights ----
+    def _capacity_from_cfg(self):
+        """Upper bound (padded h, w) of every frame the train mapper can produce from cfg.DATASETS.TRAIN + TEST (the validation-loss
+        hook maps TEST images with the same augmentation): ResizeShortestEdge of each image's (height, width) for every
+        MIN_SIZE_TRAIN choice, both orientations kept apart.  Falls back to MAX_SIZE_TRAIN x MAX_SIZE_TRAIN when a dataset does not
+        say how large its images are.  Sized once, the net is never re-created mid-run (which would reset nothing any more -- the
+        momentum arena is carried over -- but costs seconds)."""
+        from ..data import DatasetCatalog
+        c = self.cfg
+        mins = c.INPUT.MIN_SIZE_TRAIN
+        mins = [int(mins)] if isinstance(mins, (int, float)) else [int(v) for v in mins]
+        mx = int(c.INPUT.MAX_SIZE_TRAIN)
+        hmax = wmax = 0
+        try:
+            for name in tuple(c.DATASETS.TRAIN) + tuple(c.DATASETS.TEST):
+                for d in DatasetCatalog.get(name):
+                    if "height" in d and "width" in d:
+                        h0, w0 = int(d["height"]), int(d["width"])
+                    elif "image_bgr" in d:
+                        h0, w0 = d["image_bgr"].shape[:2]
+                    else:
+                        raise KeyError("height")
+                    for m_ in mins:
+                        h, w = shortest_edge_size(h0, w0, m_, mx)
+                        hmax, wmax = max(hmax, h), max(wmax, w)
+        except Exception:          # unknown dataset / no sizes: the square bound
+            hmax = wmax = mx
+        pad = lambda v: (int(v) + 31) // 32 * 32
+        return (pad(max(hmax, 32)), pad(max(wmax, 32)))
+
     def _ensure_net(self, h, w):
         hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
-        cap = getattr(self, "_cap", (0, 0))
+        cap = self._cap
         if self._net is not None and hp <= cap[0] and wp <= cap[1]:
             return
         if self._net is not None:
+            logger.warning(f"a {h}x{w} batch exceeds the capacity {cap} derived from cfg: re-creating the net (weights and SGD momentum are carried over)")
             self._sync_params()
+            self._momentum = self._net.momentum()
             self._net.close()
         c = self.cfg
         cap = (max(hp, cap[0]), max(wp, cap[1]))
@@ -234,6 +270,9 @@ class DefaultTrainer:
                              rpn_batch=int(c.MODEL.RPN.BATCH_SIZE_PER_IMAGE), roi_batch=int(c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE),
                              pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD), arch=self.arch)
         self._net.load_params(self.params)
+        if self._momentum is not None:
+            self._net.momentum(self._momentum)
+            self._momentum = None
         self._cap = cap
         self.model.net = self._net
 
@@ -242,27 +281,39 @@ class DefaultTrainer:
             self.params.update(self._net.state_dict())
 
     def resume_or_load(self, resume=True):
-        """resume=False: start from cfg.MODEL.WEIGHTS at iteration 0.  A detectron2:// or http(s) path cannot be fetched here
-        (no network): training then starts from the seeded random initialisation, with a warning."""
+        """detectron2 DefaultTrainer.resume_or_load: resume=True continues from OUTPUT_DIR/last_checkpoint when there is one (weights,
+        iteration, SGD momentum); otherwise (and with resume=False) cfg.MODEL.WEIGHTS is loaded with DetectionCheckpointer semantics
+        -- tensors missing from the file or of another shape (the COCO heads under NUM_CLASSES = 1, everything but the backbone for an
+        ImageNet R-50.pkl) keep their detectron2-style initialisation, with a warning naming them -- and training starts at iteration 0.
+        A detectron2:// or http(s) path cannot be fetched here (no network): training then starts from the initialisation, with a warning."""
         w = str(self.cfg.MODEL.WEIGHTS)
+        resumed = False
         if resume:
             last = os.path.join(self.cfg.OUTPUT_DIR, "last_checkpoint")
             if os.path.isfile(last):
                 w = os.path.join(self.cfg.OUTPUT_DIR, open(last).read().strip())
+                resumed = True
         if w and not w.startswith(("detectron2://", "http://", "https://")):
-            self.params = checkpoint.load_checkpoint(w, self.num_classes, self.arch)
-            if resume:
+            self.params, self.load_report = checkpoint.load_checkpoint(w, self.num_classes, self.arch, init=self.params, strict=resumed, with_report=True)
+            if resumed:
                 it = checkpoint.checkpoint_iteration(w)
                 self.start_iter = self.iter = (it + 1) if it is not None else 0
+                mom = checkpoint.checkpoint_momentum(w).get("arena")
+                if mom is not None:
+                    self._momentum = mom
         elif w:
             logger.warning(f"cfg.MODEL.WEIGHTS={w!r} needs a download; no network: training from the seeded random initialisation")
         if self._net is not None:
             self._net.load_params(self.params)
+            if self._momentum is not None:
+                self._net.momentum(self._momentum)
+                self._momentum = None
 
     def save_checkpoint(self, path):
         self._sync_params()
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        checkpoint.save_checkpoint(path, self.params, iteration=self.iter)
+        mom = {"arena": self._net.momentum()} if self._net is not None else None
+        checkpoint.save_checkpoint(path, self.params, iteration=self.iter, optimizer=mom)
         with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
             f.write(os.path.basename(path))
 

@@ -181,6 +181,20 @@ class MaskRCNN:
         check(lib().amp_model_grad_arena(self._h, C.byref(p), C.byref(n)), "amp_model_grad_arena")
         return p.value, n.value
 
+    def momentum(self, value=None):
+        """Read (value=None -> float32 ndarray) or write the SGD momentum arena; the layout depends only on (classes, backbone)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        check(lib().amp_model_momentum_arena(self._h, C.byref(p), C.byref(n)), "amp_model_momentum_arena")
+        if value is None:
+            out = np.empty(n.value, dtype=np.float32)
+            self.ctx.sync()
+            self.ctx.d2h(out, p.value)
+            return out
+        value = np.ascontiguousarray(value, dtype=np.float32)
+        if value.size != n.value:
+            raise _lib.AmpError(f"momentum arena has {n.value} floats, got {value.size} (different NUM_CLASSES / backbone?)")
+        self.ctx.h2d(p.value, value)
+
     def grad_buckets(self):
         """[(bucket, offset, n)] float ranges of the gradient arena in the order the backward pass completes (and exchanges) them."""
         cap = 512

@@ -353,6 +353,9 @@ int  amp_model_forward_losses(amp_model* m, const uint8_t* imgs_bgr, int imgs_on
 int  amp_model_forward_backward(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
                                 unsigned int seed, float losses_h[5]);
 int  amp_model_grad_arena(amp_model* m, float** grads_dev, size_t* nfloats);
+/* the SGD momentum buffers: one arena with the parameters' offsets (like amp_model_grad_arena).  The layout depends on the model
+ * configuration only (classes, backbone), not on the capacity: a host can carry it over to a re-created model or into a checkpoint. */
+int  amp_model_momentum_arena(amp_model* m, float** vel_dev, size_t* nfloats);
 /* torch.optim.SGD step on every trainable tensor: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
 int  amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale);
 /* Gradient / current value of one tensor, converted back to the torch layout of detectron2's state_dict entry `name` (host). */

@@ -34,6 +34,9 @@ class _StubInstances:
     def __setstate__(self, state):
         self.__dict__.update(state)
 
+    def __getstate__(self):
+        return dict(self.__dict__)
+
 
 def _install_stub():
     for name in ("detectron2", "detectron2.structures", "detectron2.structures.instances"):
@@ -95,6 +98,31 @@ def make_via_subset():
     json.dump({"via": out, "region_counts": counts, "source": "rccohn/AMPIS examples/powder/data/via_2.0.8/*.json"}, open(dst, "w"))
 
 
+def make_result_pickle_subset():
+    """tests/golden/particle_results_subset.pickle: the first image of examples/powder/data/particle-results.pickle cut to its first 12
+    detections, re-pickled with the ORIGINAL class path (detectron2.structures.instances.Instances, state keys _image_size / _fields):
+    the object `InstanceSet.read_from_model_out` receives (ampis/structures.py:359).  Data only."""
+    _install_stub()
+    _StubInstances.__module__ = "detectron2.structures.instances"
+    _StubInstances.__qualname__ = _StubInstances.__name__ = "Instances"
+    with open(os.path.join(REF, FILES[0]), "rb") as f:
+        item = pickle.load(f)[0]
+    inst = item["pred"]["instances"]
+    keep = 12
+    cut = _StubInstances()
+    cut.__dict__.update({"_image_size": tuple(int(v) for v in inst._image_size),
+                         "_fields": {"pred_masks": [dict(size=list(m["size"]), counts=bytes(m["counts"])) for m in inst._fields["pred_masks"][:keep]],
+                                     "pred_boxes": np.asarray(inst._fields["pred_boxes"])[:keep].copy(),
+                                     "scores": np.asarray(inst._fields["scores"])[:keep].copy(),
+                                     "pred_classes": np.asarray(inst._fields["pred_classes"])[:keep].copy()}})
+    out = {"file_name": item["file_name"], "dataset": item["dataset"], "pred": {"instances": cut}}
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "particle_results_subset.pickle")
+    with open(dst, "wb") as f:
+        pickle.dump(out, f, protocol=4)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
     main()
     make_via_subset()
+    make_result_pickle_subset()

@@ -1,0 +1,117 @@
+"""Checkpoint reader with detectron2's DetectionCheckpointer semantics (the reference's workflow: notebook cell 20
+fine-tunes the 80-class COCO zoo model with NUM_CLASSES = 1, and its cfg.MODEL.WEIGHTs typo leaves the caffe2-named ImageNet
+R-50.pkl in effect).  CPU only: the files are synthetic, of the real shapes."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from ampis_amd import checkpoint, params as P
+
+
+def _coco80_pkl(path, seed=7):
+    p = P.init_params(80, seed=seed, style="spread")
+    with open(path, "wb") as f:
+        pickle.dump({"model": {k: v for k, v in p.items()}, "__author__": "Detectron2 Model Zoo"}, f)
+    return p
+
+
+def test_coco_80_class_zoo_checkpoint_into_a_1_class_model(tmp_path, caplog):
+    src = _coco80_pkl(tmp_path / "model_final_f10217.pkl")
+    init = P.init_params(1, seed=3, style="d2")
+    with caplog.at_level("WARNING", logger="ampis_amd"):
+        got, rep = checkpoint.load_checkpoint(tmp_path / "model_final_f10217.pkl", 1, init=init, with_report=True)
+    skipped = {n for n, _, _ in rep["shape_mismatch"]}
+    assert skipped == {"roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.cls_score.bias",
+                       "roi_heads.box_predictor.bbox_pred.weight", "roi_heads.box_predictor.bbox_pred.bias",
+                       "roi_heads.mask_head.predictor.weight", "roi_heads.mask_head.predictor.bias"}
+    assert ("roi_heads.box_predictor.cls_score.weight", (81, 1024), (2, 1024)) in rep["shape_mismatch"]
+    assert rep["missing"] == [] and rep["unexpected"] == [] and rep["source"] == "d2"
+    for name in got:
+        want = init[name] if name in skipped else src[name]
+        assert np.array_equal(got[name], want), name
+    assert got["roi_heads.box_predictor.cls_score.weight"].shape == (2, 1024)
+    assert "Skip loading parameters with a different shape" in caplog.text and "cls_score.weight" in caplog.text
+    with pytest.raises(ValueError):
+        checkpoint.load_checkpoint(tmp_path / "model_final_f10217.pkl", 1, strict=True)
+
+
+def _msra_r50_pkl(path, seed=5):
+    """The blob dict of detectron2://ImageNetPretrained/MSRA/R-50.pkl: caffe2 names, affine-only 'bn' (scale / bias, no statistics)."""
+    rng = np.random.default_rng(seed)
+    blobs = {}
+    def conv(name, cout, cin, k):
+        blobs[name + "_w"] = rng.normal(0, 0.05, (cout, cin, k, k)).astype(np.float32)
+    def bn(name, c):
+        blobs[name + "_bn_s"] = rng.uniform(0.5, 1.5, c).astype(np.float32)
+        blobs[name + "_bn_b"] = rng.normal(0, 0.1, c).astype(np.float32)
+    conv("conv1", 64, 3, 7); bn("res_conv1", 64)
+    cin = 64
+    for si, (nblk, mid, cout) in enumerate(((3, 64, 256), (4, 128, 512), (6, 256, 1024), (3, 512, 2048))):
+        for b in range(nblk):
+            p = f"res{si + 2}_{b}"
+            if b == 0:
+                conv(p + "_branch1", cout, cin, 1); bn(p + "_branch1", cout)
+            conv(p + "_branch2a", mid, cin, 1); bn(p + "_branch2a", mid)
+            conv(p + "_branch2b", mid, mid, 3); bn(p + "_branch2b", mid)
+            conv(p + "_branch2c", cout, mid, 1); bn(p + "_branch2c", cout)
+            cin = cout
+    blobs["fc1000_w"] = rng.normal(0, 0.01, (1000, 2048)).astype(np.float32)
+    blobs["fc1000_b"] = np.zeros(1000, np.float32)
+    blobs["conv1_w_momentum"] = np.zeros((64, 3, 7, 7), np.float32)          # optimizer residue: dropped like detectron2 does
+    with open(path, "wb") as f:
+        pickle.dump(blobs, f)
+    return blobs
+
+
+def test_caffe2_named_imagenet_backbone(tmp_path):
+    blobs = _msra_r50_pkl(tmp_path / "R-50.pkl")
+    init = P.init_params(1, seed=1, style="d2")
+    got, rep = checkpoint.load_checkpoint(tmp_path / "R-50.pkl", 1, init=init, with_report=True)
+    assert rep["source"] == "caffe2" and rep["renamed"] == 161 and rep["shape_mismatch"] == []
+    assert rep["unexpected"] == ["fc1000.bias", "fc1000.weight"]
+    # every backbone weight and its affine came from the file, under detectron2's names
+    assert np.array_equal(got["backbone.bottom_up.stem.conv1.weight"], blobs["conv1_w"])
+    assert np.array_equal(got["backbone.bottom_up.stem.conv1.norm.weight"], blobs["res_conv1_bn_s"])
+    assert np.array_equal(got["backbone.bottom_up.stem.conv1.norm.bias"], blobs["res_conv1_bn_b"])
+    assert np.array_equal(got["backbone.bottom_up.res2.0.shortcut.weight"], blobs["res2_0_branch1_w"])
+    assert np.array_equal(got["backbone.bottom_up.res4.5.conv2.weight"], blobs["res4_5_branch2b_w"])
+    assert np.array_equal(got["backbone.bottom_up.res5.2.conv3.norm.bias"], blobs["res5_2_branch2c_bn_b"])
+    # FrozenBatchNorm2d buffers the file does not have: mean 0, var 1 - eps  ->  scale = weight exactly (params.BN_EPS = 1e-5)
+    rv = got["backbone.bottom_up.res3.1.conv1.norm.running_var"]
+    assert np.all(got["backbone.bottom_up.res3.1.conv1.norm.running_mean"] == 0) and np.all(rv == np.float32(1.0) - np.float32(1e-5))
+    w = got["backbone.bottom_up.res3.1.conv1.norm.weight"]
+    assert np.array_equal((w * (1.0 / np.sqrt(rv + np.float32(1e-5)))).astype(np.float32), w)
+    # everything outside the backbone keeps its initialisation and is reported missing
+    outside = [n for n in init if not n.startswith("backbone.bottom_up.")]
+    assert set(n for n in rep["missing"] if not n.startswith("backbone.bottom_up.")) == set(outside)
+    assert all(np.array_equal(got[n], init[n]) for n in outside)
+    assert all(n.endswith(("running_mean", "running_var")) for n in rep["missing"] if n.startswith("backbone.bottom_up."))
+
+
+def test_c2_name_conversion_table():
+    ren = checkpoint.convert_c2_backbone_names(["conv1_w", "res_conv1_bn_s", "res_conv1_bn_b", "res2_0_branch2a_w", "res2_0_branch2a_bn_s",
+                                                "res3_0_branch1_bn_b", "res4_22_branch2c_w", "res5_1_branch2b_bn_rm", "res5_1_branch2b_bn_riv", "fc1000_b"])
+    assert ren == {"conv1_w": "stem.conv1.weight", "res_conv1_bn_s": "stem.conv1.norm.weight", "res_conv1_bn_b": "stem.conv1.norm.bias",
+                   "res2_0_branch2a_w": "res2.0.conv1.weight", "res2_0_branch2a_bn_s": "res2.0.conv1.norm.weight",
+                   "res3_0_branch1_bn_b": "res3.0.shortcut.norm.bias", "res4_22_branch2c_w": "res4.22.conv3.weight",
+                   "res5_1_branch2b_bn_rm": "res5.1.conv2.norm.running_mean", "res5_1_branch2b_bn_riv": "res5.1.conv2.norm.running_var",
+                   "fc1000_b": "fc1000.bias"}
+
+
+def test_pth_round_trip_with_iteration_and_momentum(tmp_path):
+    p = P.init_params(2, seed=9, style="spread")
+    mom = np.random.default_rng(0).normal(size=1000).astype(np.float32)
+    checkpoint.save_checkpoint(tmp_path / "model_0000041.pth", p, iteration=41, optimizer={"arena": mom})
+    got, rep = checkpoint.load_checkpoint(tmp_path / "model_0000041.pth", 2, strict=True, with_report=True)
+    assert all(np.array_equal(got[k], p[k]) for k in p) and rep["missing"] == [] and rep["unexpected"] == []
+    assert checkpoint.checkpoint_iteration(tmp_path / "model_0000041.pth") == 41
+    assert np.array_equal(checkpoint.checkpoint_momentum(tmp_path / "model_0000041.pth")["arena"], mom)
+    d = torch.load(tmp_path / "model_0000041.pth", weights_only=False)
+    assert set(d) >= {"model", "iteration", "optimizer"}                      # detectron2's checkpoint keys
+
+
+def test_urls_are_refused_without_a_network(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_checkpoint("detectron2://COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x/137849600/model_final_f10217.pkl", 1)

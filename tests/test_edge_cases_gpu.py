@@ -156,3 +156,25 @@ def test_coco_class_count_512(gpu_ctx):
     cls = set(int(c) for c in ref[0]["classes"])
     assert len(cls) >= 2 and max(cls) > 8, "the random head should pick classes deep inside the 80-class layout"
     _match(out[0], ref[0], S, S)
+
+
+def test_more_box_candidates_than_the_sort_capacity(gpu_ctx):
+    """80 classes with SCORE_THRESH_TEST = 0.001: ~1000 x 80 (RoI, class) pairs clear the floor, far more than the 8192 the candidate
+    sort holds.  Round 1 refused such a batch.  Greedy NMS decides in score order, so the library raises the image's score floor until
+    the PREFIX of the candidate list fits and checks that the prefix still yields DETECTIONS_PER_IMAGE survivors: the result is then
+    exactly the oracle's, which sorts everything."""
+    from ampis_amd import params as P
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as O
+    K, S, D = 80, 384, 100
+    rng = np.random.default_rng(34)
+    imgs = np.stack([_img(rng, S, S, blobs=20), _img(rng, S, S, blobs=4)])
+    p = P.init_params(K, seed=5, style="spread")
+    ref = O.infer(imgs, O.to_torch_params(p), O.Cfg(num_classes=K, detections_per_image=D, score_thresh=0.001))
+    model = MaskRCNN(gpu_ctx, K, max_batch=2, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D, score_thresh=0.001)
+    model.load_params(p)
+    out = model.infer(imgs)
+    model.close()
+    assert all(len(r["boxes"]) == D for r in ref)
+    for b in range(2):
+        _match(out[b], ref[b], S, S)

@@ -113,7 +113,10 @@ def test_checkpoint_roundtrip(tmp_path):
     q = checkpoint.load_checkpoint(path, 1)
     assert set(q) == set(p) and all(np.array_equal(p[k], q[k]) for k in p)
     with pytest.raises(ValueError):
-        checkpoint.load_checkpoint(path, 2)
+        checkpoint.load_checkpoint(path, 2, strict=True)
+    # detectron2 semantics by default: the heads of another class count are skipped and keep their initialisation (tests/test_checkpoint.py)
+    q2, rep = checkpoint.load_checkpoint(path, 2, with_report=True)
+    assert len(rep["shape_mismatch"]) == 6 and q2["roi_heads.box_predictor.cls_score.weight"].shape == (3, 1024)
     with pytest.raises(FileNotFoundError):
         checkpoint.load_checkpoint("https://dl.fbaipublicfiles.com/x.pkl", 1)
     # model-zoo style .pkl: pickled {'model': {name: ndarray}}

@@ -144,3 +144,100 @@ def test_trainer_with_mixed_scales(tmp_path):
     assert any(len(s) > 1 for s in seen), "at least one batch mixed scales"
     assert os.path.isfile(os.path.join(cfg.OUTPUT_DIR, "model_final.pth"))
     DatasetCatalog.clear()
+
+
+def test_finetune_one_class_from_an_80_class_checkpoint_with_larger_validation_images_and_resume(tmp_path):
+    """The reference's main workflow (notebook cell 20, GETTING_STARTED.md:30): start from the 80-class COCO zoo checkpoint with
+    MODEL.ROI_HEADS.NUM_CLASSES = 1.  The mismatched heads are skipped and initialised detectron2-style (DetectionCheckpointer
+    semantics), training is stable and learns; validation images LARGER than every training image go through the validation-loss
+    hook (the net is sized once from cfg + dataset sizes); resume=True continues with the iteration and the SGD momentum it stopped with."""
+    import pickle
+    from ampis_amd import model_zoo, params as P
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetCatalog, DatasetMapper, MetadataCatalog, build_detection_test_loader
+    from ampis_amd.engine import DefaultTrainer
+    from ampis_amd.engine.hooks import HookBase
+    DatasetCatalog.clear()
+    train, val = _ddicts(4, 160, 224, 80), _ddicts(2, 256, 320, 90)          # validation frames exceed every training frame
+    DatasetCatalog.register("particle_Train", lambda: train)
+    DatasetCatalog.register("particle_Val", lambda: val)
+    for d in ("particle_Train", "particle_Val"):
+        MetadataCatalog.get(d).set(thing_classes=["particle"])
+    zoo = tmp_path / "model_final_f10217.pkl"
+    coco = P.init_params(80, seed=4, style="spread")
+    with open(zoo, "wb") as f:
+        pickle.dump({"model": dict(coco), "__author__": "Detectron2 Model Zoo"}, f)
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.DATASETS.TRAIN, cfg.DATASETS.TEST = ("particle_Train",), ("particle_Val",)
+    cfg.SOLVER.IMS_PER_BATCH, cfg.SOLVER.MAX_ITER, cfg.SOLVER.CHECKPOINT_PERIOD = 2, 6, 3
+    cfg.SOLVER.BASE_LR, cfg.SOLVER.WARMUP_ITERS = 0.002, 2
+    cfg.MODEL.WEIGHTS, cfg.MODEL.ROI_HEADS.NUM_CLASSES = str(zoo), 1
+    cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (0,), 1000          # native sizes: 160x224 training, 256x320 validation
+    cfg.OUTPUT_DIR = str(tmp_path / "out")
+
+    class LossEval(HookBase):
+        def __init__(self, model, loader):
+            self._model, self._loader = model, loader
+        def after_step(self):
+            if (self.trainer.iter + 1) % 3 == 0:
+                self.trainer.storage.put_scalar("validation_loss", np.mean([sum(self._model(b).values()) for b in self._loader]))
+
+    class T(DefaultTrainer):
+        def build_hooks(self):
+            hooks = super().build_hooks()
+            hooks.insert(-1, LossEval(self.model, build_detection_test_loader(self.cfg, "particle_Val", DatasetMapper(self.cfg, True))))
+            return hooks
+
+    tr = T(cfg)
+    assert tr._cap == (256, 320), tr._cap                                     # both datasets, padded to 32
+    tr.resume_or_load(resume=False)
+    rep = tr.load_report
+    assert {n for n, _, _ in rep["shape_mismatch"]} == {f"roi_heads.{h}.{p}" for h in ("box_predictor.cls_score", "box_predictor.bbox_pred", "mask_head.predictor")
+                                                         for p in ("weight", "bias")}
+    assert np.array_equal(tr.params["backbone.fpn_output3.weight"], coco["backbone.fpn_output3.weight"])
+    assert tr.params["roi_heads.box_predictor.cls_score.weight"].shape == (2, 1024)
+    tr.train()
+    tl = [v for v, _ in tr.storage.history("total_loss")]
+    vl = [v for v, _ in tr.storage.history("validation_loss")]
+    assert len(tl) == 6 and all(np.isfinite(tl)) and len(vl) == 2 and all(np.isfinite(vl))
+    assert np.mean(tl[-2:]) < np.mean(tl[:2]), tl
+    mom_end = tr._net.momentum()
+    assert np.abs(mom_end).max() > 0
+    w_end = tr._net.get_tensor("backbone.fpn_output3.weight")
+
+    # resume: iteration, weights and momentum continue where the run stopped
+    cfg.SOLVER.MAX_ITER = 8
+    tr2 = T(cfg)
+    tr2.resume_or_load(resume=True)
+    assert tr2.start_iter == 6
+    assert np.array_equal(tr2.params["backbone.fpn_output3.weight"], w_end)
+    tr2.train()
+    assert [i for _, i in tr2.storage.history("total_loss")] == [6, 7]
+    # the first resumed step started from the stored velocity: with zero momentum the weights after it would differ
+    assert tr2._momentum is None
+    DatasetCatalog.clear()
+
+
+def test_momentum_survives_a_regrown_net(tmp_path):
+    """A batch beyond the capacity re-creates the net; weights AND the SGD velocity arena are carried over."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    K = 1
+    imgs, gts = synth.batch(2, 128, 160, seed=3)
+    gts = [dict(boxes=g["boxes"][:20], classes=np.zeros(min(20, len(g["boxes"])), np.int64), polygons=g["polygons"][:20]) for g in gts]
+    p = P.init_params(K, seed=2, style="spread")
+    a = MaskRCNN(ctx, K, max_batch=2, max_h=128, max_w=160, max_out_hw=160, train=True, max_gt=512, max_poly_doubles=512 * 64)
+    a.load_params(p)
+    a.forward_losses(imgs, gts, seed=1, backward=True); a.sgd_step(0.01)
+    mom, w = a.momentum(), a.state_dict()
+    a.close()
+    b = MaskRCNN(ctx, K, max_batch=2, max_h=256, max_w=320, max_out_hw=320, train=True, max_gt=512, max_poly_doubles=512 * 64)
+    full = dict(p); full.update(w)
+    b.load_params(full)
+    b.momentum(mom)
+    assert np.array_equal(b.momentum(), mom)
+    with pytest.raises(_lib.AmpError):
+        b.momentum(mom[:-1])
+    b.close(); ctx.close()
