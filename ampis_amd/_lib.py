@@ -162,6 +162,7 @@ def _declare(L):
         "amp_model_sgd_step": ([vp, f, f, f, f], i),
         "amp_model_get_tensor": ([vp, C.c_char_p, i, vp, C.c_size_t], i),
         "amp_roi_align_bwd": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp], i),
+        "amp_roi_align_bwd_batched": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp, i], i),
         "amp_upsample2_bwd": ([vp, vp, vp, i, i, i, i], i),
         "amp_subsample2_bwd": ([vp, vp, vp, i, i, i, i], i),
         "amp_relu_mask": ([vp, vp, vp, C.c_size_t], i),

@@ -8,6 +8,7 @@
 // ordering between the two streams is by HIP events only (no host synchronisation in the data path).
 #include <dlfcn.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <rccl/rccl.h>
 
@@ -174,7 +175,15 @@ int amp_comm_init(amp_ctx* ctx, int rank, int world, const unsigned char* id_h) 
     (void)g_rccl.GetVersion(&c->version);
     ncclUniqueId id;
     memcpy(&id, id_h, sizeof(id));
+    // RCCL prints a version banner ("RCCL version : ...", HIP / ROCm versions, host, library path) on STDOUT when the first
+    // communicator comes up.  A host that owns stdout (bench.py prints exactly one JSON line there) must not get foreign lines on it:
+    // while RCCL initialises, file descriptor 1 points at stderr.
+    fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) (void)dup2(2, 1);
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+    fflush(stdout);
+    if (saved_stdout >= 0) { (void)dup2(saved_stdout, 1); (void)close(saved_stdout); }
     if (r != ncclSuccess) {
         amp::set_error("amp_comm_init: ncclCommInitRank(rank %d of %d, device %d) -> %s", rank, world, ctx->device, g_rccl.GetErrorString(r));
         delete c;

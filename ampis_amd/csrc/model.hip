@@ -951,7 +951,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext));
             std::swap(dcur, dnext);
         }
-        AMP_TRY(amp_roi_align_bwd(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur));
+        AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur, B));
     } else if (!dry) {
         for (const char* key : {"roi_heads.mask_head.predictor", "roi_heads.mask_head.deconv", "roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2",
                                 "roi_heads.mask_head.mask_fcn3", "roi_heads.mask_head.mask_fcn4"}) {
@@ -979,7 +979,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false));
         AMP_TRY(bgrad(c1, d_fc1, R, false));
         AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
-        AMP_TRY(amp_roi_align_bwd(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled));
+        AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled, B));
     }
     AMP_TRY(issue_bucket(m, 1));
 

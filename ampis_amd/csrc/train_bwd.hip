@@ -125,6 +125,154 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const RoiBwdArgs a) 
     }
 }
 
+// ---- deterministic RoIAlign backward: owner computes ------------------------------------------------------------------------
+// roi_align_bwd_kernel scatters with float atomics: 4.8 ms of a 100 ms training step at the memory-side atomic rate, and the sum
+// order of overlapping RoIs -- hence the low bits of every FPN / backbone gradient -- changes from run to run.  Here every 4 x 4
+// tile of a gradient map belongs to ONE wave, which walks the RoIs in index order (those of its image and level whose footprint
+// meets the tile), inside a RoI the bins in (ph, pw) order, and adds  g[bin] / count * WY[row] * WX[col]  (the separable tap weights
+// of roi_align_bwd_kernel) into 16 x 4 accumulators per lane -- registers, statically indexed, lane = 4 consecutive channels --
+// and finally adds them to the map with plain loads and stores.  No atomics, a fixed order per cell: bitwise reproducible, and
+// faster (the atomics were the bound).  Pass 1 (roi_bwd_meta_kernel) computes each RoI's level, image and footprint once.
+struct RoiKey { int b_lv; unsigned int ybox, xbox; };          // image << 2 | level; y0 | y1 << 16 (y1 < y0: contributes nothing); x likewise
+struct RoiPar { int gh, gw; float sw, sh, bw, bh, inv; int pad; };
+struct RoiBwdTileArgs {
+    float* dfeat[4];
+    int fh[4], fw[4], tiles_x[4], tile_off[5];   // tile_off[l]: first flat tile index of level l (B * tiles_y * tiles_x each)
+    float scale[4];
+    const float* rois;
+    const int* batch_idx;
+    const float* dout;
+    RoiKey* key;
+    RoiPar* par;
+    int* range;                                  // [B] first RoI of image b, then [B] one past its last (a tile scans only its image's RoIs)
+    int R, P, B;
+};
+
+__global__ void roi_bwd_meta_kernel(const RoiBwdTileArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.R) return;
+    const float x1 = a.rois[4 * r], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+    const int lv = assign_level_b(x1, y1, x2, y2);
+    const int b = a.batch_idx ? a.batch_idx[r] : 0;
+    const int H = a.fh[lv], W = a.fw[lv];
+    const float sc = a.scale[lv];
+    RoiPar m;
+    m.sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f); m.sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+    const float rw = __fsub_rn(__fsub_rn(__fmul_rn(x2, sc), 0.5f), m.sw), rh = __fsub_rn(__fsub_rn(__fmul_rn(y2, sc), 0.5f), m.sh);
+    m.bh = __fdiv_rn(rh, (float)a.P); m.bw = __fdiv_rn(rw, (float)a.P);
+    m.gh = (int)ceilf(m.bh); m.gw = (int)ceilf(m.bw);
+    m.inv = (m.gh > 0 && m.gw > 0) ? __fdiv_rn(1.0f, (float)(m.gh * m.gw)) : 0.f;
+    m.pad = 0;
+    // rows / columns any tap can touch (samples lie inside [s, s + r]; a tap is floor(v) or floor(v) + 1, clamped to the map)
+    int y0 = max(0, (int)floorf(m.sh)), yl = min(H - 1, (int)floorf(__fadd_rn(m.sh, rh)) + 1);
+    int x0 = max(0, (int)floorf(m.sw)), xl = min(W - 1, (int)floorf(__fadd_rn(m.sw, rw)) + 1);
+    if (!(m.gh > 0 && m.gw > 0) || !(rh > 0.f) || !(rw > 0.f) || yl < y0 || xl < x0 || b < 0 || b >= a.B) { y0 = 1; yl = 0; x0 = 1; xl = 0; }
+    RoiKey k;
+    k.b_lv = (b << 2) | lv;
+    k.ybox = (unsigned int)y0 | ((unsigned int)yl << 16);
+    k.xbox = (unsigned int)x0 | ((unsigned int)xl << 16);
+    a.key[r] = k;
+    a.par[r] = m;
+    if (b >= 0 && b < a.B) { atomicMin(&a.range[b], r); atomicMax(&a.range[a.B + b], r + 1); }
+}
+
+// separable tap weight of one axis: sum over the bin's samples of (1 - frac) where the sample's lower tap is `mine` plus frac where
+// its upper tap is (the same loop as roi_align_bwd_kernel's `axis`)
+__device__ __forceinline__ float roi_axis_weight(int n_samp, float start, float binsz, int pidx, int extent, int mine) {
+    float wsum = 0.f;
+    for (int i = 0; i < n_samp; ++i) {
+        float v = __fadd_rn(__fadd_rn(start, __fmul_rn((float)pidx, binsz)), __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), binsz), (float)n_samp));
+        if (v < -1.0f || v > (float)extent) continue;
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= extent - 1) { lo = hi = extent - 1; v = (float)lo; } else hi = lo + 1;
+        const float l = __fsub_rn(v, (float)lo), h = __fsub_rn(1.0f, l);
+        if (lo == mine) wsum = __fadd_rn(wsum, h);
+        if (hi == mine) wsum = __fadd_rn(wsum, l);
+    }
+    return wsum;
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTileArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.tile_off[4]) return;
+    int lv = 0;
+    while (lv < 3 && tile >= a.tile_off[lv + 1]) ++lv;
+    const int H = a.fh[lv], W = a.fw[lv];
+    const int tx_n = a.tiles_x[lv], ty_n = (H + 3) >> 2;
+    int t = tile - a.tile_off[lv];
+    const int b = t / (ty_n * tx_n);
+    t -= b * ty_n * tx_n;
+    const int ty0 = (t / tx_n) * 4, tx0 = (t % tx_n) * 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool any = false;
+    const int l3 = lane & 3;
+    const int want = (b << 2) | lv;
+    const int r_end = a.range[a.B + b];
+    for (int r0 = a.range[b]; r0 < r_end; r0 += 64) {          // the RoIs of this tile's image (a.range), 64 per trip
+        const int r = r0 + lane;
+        bool hit = false;
+        if (r < r_end) {
+            const RoiKey k = a.key[r];
+            const int y0 = (int)(k.ybox & 0xffffu), yl = (int)(k.ybox >> 16), x0 = (int)(k.xbox & 0xffffu), xl = (int)(k.xbox >> 16);
+            hit = k.b_lv == want && y0 <= ty0 + 3 && yl >= ty0 && x0 <= tx0 + 3 && xl >= tx0;
+        }
+        unsigned long long pend = __ballot(hit);
+        while (pend) {                                             // ascending RoI index: the order of every cell's sum
+            const int rr = r0 + __builtin_ctzll(pend);
+            pend &= pend - 1;
+            const RoiPar pr = a.par[rr];                           // same address in every lane
+            const int gh = pr.gh, gw = pr.gw;
+            const float sh = pr.sh, sw = pr.sw, bh = pr.bh, bw = pr.bw, inv = pr.inv;
+            // bins whose taps can reach the tile (conservative by one bin on each side; a bin that does not gets zero weights)
+            const int ph_lo = max(0, (int)floorf(__fdiv_rn((float)(ty0 - 1) - sh, bh)) - 1), ph_hi = min(a.P - 1, (int)floorf(__fdiv_rn((float)(ty0 + 4) - sh, bh)) + 1);
+            const int pw_lo = max(0, (int)floorf(__fdiv_rn((float)(tx0 - 1) - sw, bw)) - 1), pw_hi = min(a.P - 1, (int)floorf(__fdiv_rn((float)(tx0 + 4) - sw, bw)) + 1);
+            for (int ph = ph_lo; ph <= ph_hi; ++ph) {
+                const float wy = roi_axis_weight(gh, sh, bh, ph, H, ty0 + l3);         // lane k & 3 = row ty0 + k
+                if (__ballot(wy != 0.f) == 0ull) continue;
+                for (int pw = pw_lo; pw <= pw_hi; ++pw) {
+                    const float wx = roi_axis_weight(gw, sw, bw, pw, W, tx0 + l3);
+                    if (__ballot(wx != 0.f) == 0ull) continue;
+                    f32x4 gv = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)(rr * a.P + ph) * a.P + pw) * 256 + 4 * lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[e] = __fmul_rn(gv[e], inv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float wyr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wy), r));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float w = __fmul_rn(wyr, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx), c)));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[r][c][e] = __fadd_rn(acc[r][c][e], __fmul_rn(w, gv[e]));
+                        }
+                    }
+                    any = true;
+                }
+            }
+        }
+    }
+    if (!any) return;
+    float* f = a.dfeat[lv] + (size_t)b * H * W * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int y = ty0 + r, x = tx0 + c;
+            if (y < H && x < W) {
+                f32x4* p = reinterpret_cast<f32x4*>(f + ((size_t)y * W + x) * 256) + lane;
+                f32x4 v = *p;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], acc[r][c][e]);
+                *p = v;
+            }
+        }
+}
+
 // d_coarse[b,y,x,:] += sum of the 2x2 fine cells (backward of nearest x2 upsampling in the FPN top-down path)
 __global__ void upsample2_bwd_kernel(const float* __restrict__ dfine, float* __restrict__ dcoarse, int B, int Hc, int Wc, int C4) {
     const size_t total = (size_t)B * Hc * Wc * C4;
@@ -228,17 +376,66 @@ inline unsigned grid_for(size_t total) { return (unsigned)std::min<size_t>(std::
 
 }  // namespace
 
+static int g_roi_bwd_atomics = 0;     // tests: 1 = the float-atomic kernel
+extern "C" void amp_debug_set_roi_bwd_atomics(int v) { g_roi_bwd_atomics = v; }
+
 extern "C" {
 
 int amp_roi_align_bwd(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
                       const int* batch_idx, int R, int P, const float* dout) {
     AMP_REQUIRE(ctx && dfeat && fh && fw && stride && rois && dout, "amp_roi_align_bwd: null argument");
     if (R == 0) return AMP_OK;
-    RoiBwdArgs a;
-    for (int l = 0; l < 4; ++l) { a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l]; }
-    a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.C = C;
-    const long long nbins = (long long)R * P * P;
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((unsigned)std::min<long long>((nbins + 3) / 4, 65536)), dim3(256), 0, ctx->stream, a);
+    return amp_roi_align_bwd_batched(ctx, dfeat, fh, fw, stride, C, rois, batch_idx, R, P, dout, 0);     // B = 0: derived from batch_idx
+}
+
+int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
+                              const int* batch_idx, int R, int P, const float* dout, int B) {
+    AMP_REQUIRE(ctx && dfeat && fh && fw && stride && rois && dout, "amp_roi_align_bwd_batched: null argument");
+    if (R == 0) return AMP_OK;
+    static const bool env_atomics = getenv("AMP_ROI_BWD_ATOMICS") != nullptr;
+    if (C != 256 || env_atomics || g_roi_bwd_atomics) {     // other widths, or the round-1 kernel for comparison: float atomics
+        RoiBwdArgs a;
+        for (int l = 0; l < 4; ++l) { a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l]; }
+        a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.C = C;
+        const long long nbins = (long long)R * P * P;
+        hipLaunchKernelGGL(roi_align_bwd_kernel, dim3((unsigned)std::min<long long>((nbins + 3) / 4, 65536)), dim3(256), 0, ctx->stream, a);
+        AMP_HIP_CHECK(hipGetLastError());
+        return AMP_OK;
+    }
+    if (B <= 0) {        // images = 1 + the largest batch index (one small read-back; callers that know B pass it)
+        B = 1;
+        if (batch_idx) {
+            std::vector<int> hb(R);
+            AMP_HIP_CHECK(hipMemcpyAsync(hb.data(), batch_idx, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (int v : hb) B = std::max(B, v + 1);
+        }
+    }
+    const size_t need = (size_t)R * (sizeof(RoiKey) + sizeof(RoiPar)) + (size_t)2 * B * sizeof(int) + 64;
+    if (ctx->topk_bytes < need) {       // the context's scratch buffer (shared with amp_rpn_topk; stream order makes the reuse safe)
+        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->topk_scratch) AMP_HIP_CHECK(hipFree(ctx->topk_scratch));
+        ctx->topk_scratch = nullptr; ctx->topk_bytes = 0;
+        AMP_HIP_CHECK(hipMalloc(&ctx->topk_scratch, need));
+        ctx->topk_bytes = need;
+    }
+    RoiBwdTileArgs a;
+    int off = 0;
+    for (int l = 0; l < 4; ++l) {
+        a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l];
+        a.tiles_x[l] = (fw[l] + 3) / 4;
+        a.tile_off[l] = off;
+        off += B * ((fh[l] + 3) / 4) * a.tiles_x[l];
+    }
+    a.tile_off[4] = off;
+    a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.B = B;
+    a.par = reinterpret_cast<RoiPar*>(ctx->topk_scratch);                      // 32-B entries first (alignment), then keys, then ranges
+    a.key = reinterpret_cast<RoiKey*>(a.par + R);
+    a.range = reinterpret_cast<int*>(a.key + R);
+    AMP_HIP_CHECK(hipMemsetAsync(a.range, 0x7f, (size_t)B * sizeof(int), ctx->stream));          // starts: a huge index (atomicMin target)
+    AMP_HIP_CHECK(hipMemsetAsync(a.range + B, 0, (size_t)B * sizeof(int), ctx->stream));         // ends: 0 (atomicMax target)
+    hipLaunchKernelGGL(roi_bwd_meta_kernel, dim3(amp::cdiv(R, 256)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(roi_align_bwd_tile_kernel, dim3(amp::cdiv(off, 4)), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

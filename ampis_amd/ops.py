@@ -228,6 +228,17 @@ def roi_align(ctx, feats, rois, batch_idx, P, fmt=0):
     return out, lvl
 
 
+def roi_align_bwd(ctx, dfeats, strides, rois, batch_idx, P, dout, B=0):
+    """dfeats[l] [B,h,w,256] += RoIAlign-backward(dout [R,P,P,256]) (amp_roi_align_bwd_batched; B = 0: derived from batch_idx)."""
+    import ctypes as C_
+    ptrs = (C_.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
+    fh = (C_.c_int * 4)(*[f.shape[1] for f in dfeats])
+    fw = (C_.c_int * 4)(*[f.shape[2] for f in dfeats])
+    st = (C_.c_int * 4)(*strides)
+    check(lib().amp_roi_align_bwd_batched(ctx.handle, ptrs, fh, fw, st, dfeats[0].shape[3], ptr(_f32c(rois)), ptr(batch_idx), rois.shape[0], P,
+                                          ptr(_f32c(dout)), int(B)), "amp_roi_align_bwd_batched")
+
+
 def box_candidates(ctx, pred, proposals, prop_count, K, score_thresh, img_h, img_w, weights=(10., 10., 5., 5.), ccap=8192):
     B, Rcap, _ = proposals.shape
     dev = pred.device

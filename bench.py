@@ -130,7 +130,7 @@ def pmc_traffic(kernel_keys):
     """HBM bytes per launch of the first of `kernel_keys` found in the committed PMC summaries (profiles/rNN/pmc_summary*.json)."""
     import glob
     for d in PROFILE_DIRS:
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")), reverse=True):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")), key=os.path.getmtime, reverse=True):
             try:
                 k = json.load(open(f))["kernels"]
             except Exception:
@@ -233,7 +233,7 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
     wg_ms, wg_fl, wg_n = prof["ms"][2], prof["flops"][2], prof["launches"][2]
     ach = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     kname = "wgrad_f16x3_kernel" if f16 else "wgrad_mfma_kernel"
-    traffic, traffic_src, traffic_key = pmc_traffic([k for k in ("wgrad_f16x3_kernel<1>", "wgrad_f16x3_kernel", "wgrad_mfma_kernel") if k.startswith(kname)])
+    traffic, traffic_src, traffic_key = pmc_traffic([kname])
     conv_ms = prof["ms"][0] + prof["ms"][1]
     out = {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
            "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
@@ -449,7 +449,7 @@ def main(args):
 
     out = None
     if rank == 0:
-        keys = ["conv_glds_kernel<256,F16>", "conv_f16x3_kernel<256>", "conv_f16x3_kernel<128>"] if mode == "f16x3" else ["conv_glds_kernel<128>"]
+        keys = ["conv_split_kernel<128x256>", "conv_glds_kernel<256>[f16x3, both operands pre-split]", "conv_f16x3_kernel<256>"] if mode == "f16x3" else ["conv_glds_kernel<128>"]
         traffic, traffic_src, traffic_key = pmc_traffic(keys)   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
         ms_per_step = elapsed / args.steps * 1e3
         value = world * BATCH * args.steps / elapsed

@@ -147,9 +147,13 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
-/* dfeat[level] += RoIAlign-backward(dout [R,P,P,C]) (float atomics: reproducible to fp32 rounding, not bitwise) */
+/* dfeat[level] += RoIAlign-backward(dout [R,P,P,C]).  C == 256: owner-computes, no atomics -- every 4x4 tile of a gradient map is
+ * summed by one wave over the RoIs in index order: bitwise reproducible.  Other C: float atomics (reproducible to fp32 rounding).
+ * _batched: B = number of images (maps are [B,h,w,C]); amp_roi_align_bwd derives it from batch_idx (one small read-back). */
 int amp_roi_align_bwd(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
                       const int* batch_idx, int R, int P, const float* dout);
+int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
+                              const int* batch_idx, int R, int P, const float* dout, int B);
 int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C);   /* dcoarse += 2x2 sums */
 int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, int W, int C);           /* dx[::2, ::2] += dy */
 int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n);                                  /* g *= (act > 0) */

@@ -91,3 +91,86 @@ def test_colsum(gpu_ctx):
     out = ops.colsum(gpu_ctx, dy.to(DEV))
     torch.cuda.synchronize()
     assert torch.allclose(out.cpu(), dy.double().sum(0).float(), rtol=1e-5, atol=1e-3)
+
+
+def _bwd_setup(seed, sizes):
+    from oracle import maskrcnn as M
+    g = torch.Generator().manual_seed(seed)
+    B = 2
+    feats = [torch.zeros(B, h, w, 256) for h, w in sizes]
+    R = 90
+    img_h, img_w = sizes[0][0] * 4, sizes[0][1] * 4
+    ctr = torch.rand(R, 2, generator=g) * torch.tensor([float(img_w), float(img_h)])
+    size = torch.exp(torch.rand(R, 2, generator=g) * 5.5 + 1.0)
+    rois = torch.cat([ctr - size / 2, ctr + size / 2], 1).float()
+    rois[0] = torch.tensor([-50.0, -40.0, 30.0, 20.0])                 # sticks out top-left
+    rois[1] = torch.tensor([img_w - 20.0, img_h - 30.0, img_w + 60.0, img_h + 40.0])
+    rois[2] = torch.tensor([5.0, 5.0, 5.0, 25.0])                      # zero width: no gradient
+    bidx = (torch.arange(R) % B).int()
+    lv = M.assign_levels(rois)                                          # 0 .. 3 = p2 .. p5
+    return feats, rois, bidx, lv, B
+
+
+@pytest.mark.parametrize("P,sizes", [(7, [(32, 40), (16, 20), (8, 10), (4, 5)]), (14, [(30, 37), (15, 19), (8, 10), (4, 5)])])
+def test_roi_align_backward_owner_computes(gpu_ctx, P, sizes):
+    """amp_roi_align_bwd(_batched) -- every 4x4 tile of a gradient map summed by one wave over the RoIs in index order -- against
+    torch autograd of the oracle's differentiable RoIAlign, against the float-atomic kernel it replaces, and against itself: two runs
+    are bitwise identical (map sizes that are not multiples of the tile, boxes outside the map, an empty box)."""
+    from ampis_amd import ops, _lib
+    from oracle import train as T
+    feats, rois, bidx, lv, B = _bwd_setup(3 + P, sizes)
+    g = torch.Generator().manual_seed(99)
+    dout = torch.randn(rois.shape[0], P, P, 256, generator=g)
+    strides = (4, 8, 16, 32)
+    # reference: autograd through roi_align_torch, RoI by RoI (level and image as the forward assigns them)
+    ref = [torch.zeros(B, 256, h, w, requires_grad=True) for h, w in sizes]
+    loss = 0
+    for r in range(rois.shape[0]):
+        l, b = int(lv[r]), int(bidx[r])
+        out = T.roi_align_torch(ref[l][b], rois[r:r + 1], P, 1.0 / strides[l])          # [1, C, P, P]
+        loss = loss + (out[0] * dout[r].permute(2, 0, 1)).sum()
+    loss.backward()
+    runs = {}
+    for tag, atomics in (("tile", 0), ("tile2", 0), ("atomic", 1)):
+        _lib.lib().amp_debug_set_roi_bwd_atomics(atomics)
+        try:
+            d = [torch.zeros_like(f).to(DEV) for f in feats]
+            ops.roi_align_bwd(gpu_ctx, d, strides, rois.to(DEV), bidx.to(DEV), P, dout.to(DEV), B=B if tag != "tile2" else 0)
+            torch.cuda.synchronize()
+            runs[tag] = [x.cpu() for x in d]
+        finally:
+            _lib.lib().amp_debug_set_roi_bwd_atomics(0)
+    for l in range(4):
+        want = ref[l].grad.permute(0, 2, 3, 1)
+        scale = max(float(want.abs().max()), 1e-6)
+        assert float((runs["tile"][l] - want).abs().max()) <= 2e-5 * scale, l
+        assert float((runs["atomic"][l] - want).abs().max()) <= 2e-5 * scale, l
+        assert torch.equal(runs["tile"][l], runs["tile2"][l]), f"level {l}: not bitwise reproducible"
+    assert any(float(r.abs().max()) > 0 for r in runs["tile"])
+
+
+def test_training_step_is_bitwise_reproducible(gpu_ctx):
+    """With the RoIAlign backward free of atomics every kernel of a training step sums in a fixed order: the same batch, weights and
+    seed give the same losses and bit-identical gradients for EVERY trainable tensor, run after run."""
+    from ampis_amd import params as P, synth
+    from ampis_amd.model import MaskRCNN
+    K, B, H, W = 2, 2, 192, 256
+    imgs, gts = synth.batch(B, H, W, seed=9)
+    gts = [dict(boxes=g["boxes"][:40], classes=g["classes"][:40], polygons=g["polygons"][:40]) for g in gts]
+    npp = P.init_params(K, seed=2, style="spread")
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=2048, max_poly_doubles=2048 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2"))]
+    grads = []
+    for rep in range(3):
+        L = m.forward_losses(imgs, gts, seed=3, backward=True)
+        ptr, n = m.grad_arena()
+        arena = np.empty(n, dtype=np.float32)
+        gpu_ctx.sync()
+        gpu_ctx.d2h(arena, ptr)
+        grads.append((L, arena))
+    m.close()
+    for L, a in grads[1:]:
+        assert L == grads[0][0]
+        assert np.array_equal(a, grads[0][1]), f"{int((a != grads[0][1]).sum())} of {a.size} gradient values differ between runs"
+    assert np.abs(grads[0][1]).max() > 0 and len(names) > 50

@@ -8,7 +8,12 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --train-steps 0 --x101-steps 0 --no-two-pipelines"
+MODE=${2:-infer}    # infer: the headline workload; train: the training step (wgrad / dgrad kernels)
+if [ "$MODE" = train ]; then
+  BENCH="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 6 --train-warmup 2 --x101-steps 0 --no-two-pipelines --no-host-inclusive"
+else
+  BENCH="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --train-steps 0 --x101-steps 0 --no-two-pipelines --no-host-inclusive"
+fi
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats_bench.log 2>&1 || { echo "stats run failed"; tail -5 $OUT/stats_bench.log; exit 1; }
 grep '^{' $OUT/stats_bench.log > $OUT/bench_line_under_rocprof.json
 echo "stats done"

@@ -15,18 +15,24 @@ def short(name):
         args = [t.strip() for t in m.group(2).split(",")]
         if m.group(1) == "conv_glds_kernel":      # <BN, STEM, EPI, F16>
             tag = ("[stem]" if len(args) > 1 and args[1] == "true" else "") + ("[f16x3, both operands pre-split]" if len(args) > 3 and args[3] == "true" else "")
+        elif m.group(1) == "conv_split_kernel":   # <BM, BN, EPI>: both operands pre-split, 3-buffer ring
+            return f"conv_split_kernel<{args[0]}x{args[1]}>"
         elif m.group(1) == "conv_f16x3_kernel":   # <BN, EPI, STEM, SCALED>
             tag = ("[stem]" if len(args) > 2 and args[2] == "true" else "") + ("[scaled input]" if len(args) > 3 and args[3] == "true" else "")
         else:
             tag = ""
         return f"{m.group(1)}<{args[0]}>{tag}"
+    m = re.search(r"(wgrad_\w+_kernel)<([^>]*)>", name)
+    if m:
+        return m.group(1)
     m = re.search(r"::(\w+_kernel)", name)
     return m.group(1) if m else name.split("(")[0][-40:]
 
 
+prefix = sys.argv[4] if len(sys.argv) > 4 else "bench"          # "train" for the training-step profile
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
-shutil.copy(stats, os.path.join(dst, f"bench_kernel_stats{suffix}.csv"))
-shutil.copy(os.path.join(src, "bench_line_under_rocprof.json"), os.path.join(dst, f"bench_line_under_rocprof{suffix}.json"))
+shutil.copy(stats, os.path.join(dst, f"{prefix}_kernel_stats{suffix}.csv"))
+shutil.copy(os.path.join(src, "bench_line_under_rocprof.json"), os.path.join(dst, f"{prefix}_line_under_rocprof{suffix}.json"))
 # kernel time per short name from the trace of the stats run
 dur = defaultdict(float); cnt = defaultdict(int)
 for r in csv.DictReader(open(glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))[0])):
@@ -61,6 +67,7 @@ for k in sorted(ctr, key=lambda k: -dur.get(k, 0)):
         act = ctr[k]["GRBM_GUI_ACTIVE"] / n[k]["GRBM_GUI_ACTIVE"]
         e["mfma_util"] = round(busy / (act / 8 * 1024), 4)
     out["kernels"][k] = e
-json.dump(out, open(os.path.join(dst, f"pmc_summary{suffix}.json"), "w"), indent=1)
+out["command"] = out["command"] if prefix == "bench" else out["command"].replace("--train-steps 0", "--steps 2 --warmup 1 --train-steps 6 --train-warmup 2")
+json.dump(out, open(os.path.join(dst, f"pmc_summary{'_train' if prefix != 'bench' else ''}{suffix}.json"), "w"), indent=1)
 for k, e in out["kernels"].items():
     print(k, e)
