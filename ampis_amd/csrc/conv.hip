@@ -53,6 +53,7 @@ struct ConvArgs {
     int pred_K;
     float* prob;            // [B][2Ho][2Wo] mask probabilities
     int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
+    int stagger;            // conv_split_kernel: the two halves of the workgroup ping-pong between loading and multiplying (0: lockstep; EXPERIMENT switch AMP_STAGGER)
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
@@ -227,26 +228,40 @@ __device__ __forceinline__ void conv_epilogue_generic_rows(const ConvArgs& a, fl
 // (Shape: the 16x16x32 MFMA does the flops of the 32x32x16 one in the same cycles with the same LDS bytes, but on random operands
 // the chip holds a higher clock under it -- MI355X_MICROARCH.md -- measured here: +2..9 % on the 3x3 / fc layers.)
 template <int MB, int NB>
-__device__ __forceinline__ void f16x3_step16(const float* As, const float* Bs, int fo_hi, int fo_lo, f32x4 (&acc)[MB][NB], f32x4 (&acx)[MB][NB]) {
+struct F16x3Frags {
     f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+};
+template <int MB, int NB>
+__device__ __forceinline__ void f16x3_load16(const float* As, const float* Bs, int fo_hi, int fo_lo, F16x3Frags<MB, NB>& f) {
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_hi);
-        al[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_lo);
+        f.ah[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_hi);
+        f.al[i] = *reinterpret_cast<const f16x8*>(As + i * 16 * BK + fo_lo);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_hi);
-        bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_lo);
+        f.bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_hi);
+        f.bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_lo);
     }
+}
+template <int MB, int NB>
+__device__ __forceinline__ void f16x3_mfma16(const F16x3Frags<MB, NB>& f, f32x4 (&acc)[MB][NB], f32x4 (&acx)[MB][NB]) {
+    // per accumulator the order is lo'*hi, hi*lo' (cross sums), hi*hi; consecutive MFMAs never share an accumulator (NB apart)
 #pragma unroll
-    for (int i = 0; i < MB; ++i)
+    for (int i = 0; i < MB; ++i) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acx[i][j], 0, 0, 0);
-            acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acx[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bh[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bl[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+    }
+}
+template <int MB, int NB>
+__device__ __forceinline__ void f16x3_step16(const float* As, const float* Bs, int fo_hi, int fo_lo, f32x4 (&acc)[MB][NB], f32x4 (&acx)[MB][NB]) {
+    F16x3Frags<MB, NB> f;
+    f16x3_load16<MB, NB>(As, Bs, fo_hi, fo_lo, f);
+    f16x3_mfma16<MB, NB>(f, acc, acx);
 }
 
 // Fast epilogue for the layouts the model actually uses (Cout % 4 == 0): same LDS transposition and the same arithmetic as
@@ -928,6 +943,16 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
 // streams (MI355X_MICROARCH.md, cost cell "ldsdma-fill"), so with one tile in flight every step ended in a stall on its own
 // prefetch; with two in flight the request has two steps to land.  3 x 48 KB = 144 KB of the CU's 160 KB.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef AMP_STAMP
+// Lab build only (make EXTRA=-DAMP_STAMP): in-kernel phase timing of conv_split_kernel -- cycles per wave slot and phase, summed over
+// all workgroups: [wave][0] wait+barrier, [1] DMA issue, [2] fragment reads (issue + return), [3] MFMA issue, [4] whole loop.
+__device__ unsigned long long g_stamp[8 * 8];
+#define STAMP_T(var) const long long var = clock64()
+#define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#else
+#define STAMP_T(var)
+#define STAMP_ADD(slot, t0, t1)
+#endif
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kernel(const ConvArgs a, const unsigned int x_bytes,
                                                                                     const unsigned int w_bytes) {
@@ -1035,23 +1060,83 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     stage(0);
     if (a.nsteps > 1) stage(1);
     int cur = 0, nxt = 2;                      // ring positions of the tile being computed / staged
-    for (int step = 0; step < a.nsteps; ++step) {
-        // tile `step` has landed once all but the youngest tile's requests of this wave are done (LDS-DMA counts in vmcnt, in order)
-        if (step + 1 < a.nsteps) __builtin_amdgcn_s_waitcnt(0x0F70 | NDMA);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto open_step = [&](int step) {
+        // tile `step` has landed once all but the youngest tile's requests of this wave are done (LDS-DMA counts in vmcnt, in order);
+        // lgkmcnt(0): this wave's fragment reads of tile step-1 have returned (the staggered half issues them last in its step)
+        if (step + 1 < a.nsteps) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
         // Bare s_barrier: __syncthreads() is fence + barrier, and the workgroup-release fence waits for vmcnt(0) -- it would drain the
         // very requests this ring keeps in flight.  Nothing a fence orders is needed here: the tiles are written by LDS-DMA (covered by
-        // the vmcnt above) and read by ds_read whose data the MFMAs of the previous step have already consumed.  The empty asm
-        // statements keep the compiler from moving LDS accesses across the barrier.
+        // the vmcnt above) and read by ds_read whose data has returned (lgkmcnt above).  The empty asm statements keep the compiler
+        // from moving LDS accesses across the barrier.
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's share of tile `step` is in LDS; everyone is done with tile step-1
         asm volatile("" ::: "memory");
-        if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
-        f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
-                             fo16_hi, fo16_lo, acc, acx);
+    };
+    auto advance = [&]() {
         cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
         nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+    };
+    // Ping-pong between the two waves of a SIMD (MI355X_MICROARCH.md, "Two waves per SIMD"): waves w and w + NW/2 share a SIMD, and run
+    // in lockstep they first both issue LDS-DMA and fragment reads (matrix pipe idle) and then both issue MFMAs (pipe contended) -- the
+    // in-kernel stamps (tools/stamp_conv.py) gave 2400-2540 cycles per K-step against 1536 of MFMA work.  So the second half of the
+    // workgroup runs its MFMAs one step late: a K-step has two halves separated by a second barrier; in the first the early half
+    // stages tile s+2 and reads the fragments of tile s while the late half multiplies the fragments of tile s-1 it holds in registers;
+    // in the second the early half multiplies tile s while the late half stages and reads.  The multiplying half runs at raised priority.
+    // Same tiles, same sums per accumulator in the same order -- bit-identical results (1930-2010 cycles per K-step; +5..14 % per layer).
+    F16x3Frags<MB, NB> fr;
+#ifdef AMP_STAMP
+    long long st_acc[5] = {0, 0, 0, 0, 0};
+    const long long st_begin = clock64();
+#endif
+    const float* As0 = lds + (wm * WTM + l15) * BK;
+    const float* Bs0 = lds + BM * BK + (wn * WTN + l15) * BK;
+    const bool pp = a.stagger != 0;
+    if (!pp || wave < NW / 2) {
+        for (int step = 0; step < a.nsteps; ++step) {
+            STAMP_T(t0);
+            open_step(step);
+            STAMP_T(t1);
+            if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
+            STAMP_T(t2);
+            f16x3_load16<MB, NB>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t3);
+            if (pp) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            f16x3_mfma16<MB, NB>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(2, t2, t3); STAMP_ADD(3, t3, t4);
+            advance();
+        }
+    } else {
+        for (int step = 0; step < a.nsteps; ++step) {
+            STAMP_T(t0);
+            open_step(step);
+            STAMP_T(t1);
+            __builtin_amdgcn_s_setprio(1);
+            if (step > 0) f16x3_mfma16<MB, NB>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            STAMP_T(t2);
+            if (step + 2 < a.nsteps) stage(nxt);
+            STAMP_T(t3);
+            f16x3_load16<MB, NB>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(3, t1, t2); STAMP_ADD(1, t2, t3); STAMP_ADD(2, t3, t4);
+            advance();
+        }
+        f16x3_mfma16<MB, NB>(fr, acc, acx);
     }
+#ifdef AMP_STAMP
+    st_acc[4] = clock64() - st_begin;
+    if (lane == 0)
+        for (int q = 0; q < 5; ++q) atomicAdd(&g_stamp[wave * 8 + q], (unsigned long long)st_acc[q]);
+#endif
     __syncthreads();                           // all operand reads done: the epilogue re-uses the buffers as its staging tile
 
 #pragma unroll
@@ -1357,6 +1442,15 @@ static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles wher
 extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
 static int g_split_ring = getenv("AMP_SPLIT_RING") ? atoi(getenv("AMP_SPLIT_RING")) : 1;    // EXPERIMENT switch: the 3-buffer conv_split_kernel for pre-split inputs (0: the 2-buffer conv_glds_kernel<.., F16>)
 extern "C" void amp_debug_set_split_ring(int v) { g_split_ring = v; }
+#ifdef AMP_STAMP
+extern "C" int amp_debug_read_stamps(unsigned long long* out) {     // 64 values; zeroes the device counters
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    unsigned long long z[64] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
+static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
+extern "C" void amp_debug_set_stagger(int v) { g_stagger = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
 extern "C" void amp_debug_set_conv_generic_epilogue(int on) { g_conv_generic_epi = on; }
 static int g_conv_ablate = 0;   // tools/bench_conv_ablate.py: timing variants of the register-staged kernel
@@ -1532,6 +1626,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     const bool x_is_split = (fmt & 1) != 0;
     a.y_split = (fmt & 2) ? 1 : 0;
     a.res_split = (fmt & 4) ? 1 : 0;
+    a.stagger = g_stagger;
     a.pred_w = a.pred_b = nullptr; a.pred_cls = nullptr; a.pred_K = 0; a.prob = nullptr;
     if (fuse) {     // the mask head's deconv with ReLU + predictor + sigmoid in its epilogue (conv_epilogue_predict)
         AMP_REQUIRE(x_is_split && d->out_mode == 1 && a.Cout == 1024 && a.KH == 1 && a.KW == 1 && a.relu && !res && !mask && !scale && g_split_ring,

@@ -1,0 +1,42 @@
+"""Lab: in-kernel phase timing of conv_split_kernel (library built with `make EXTRA=-DAMP_STAMP`, see conv.hip g_stamp).
+usage (GPU box): AMP_STAGGER=0|1 python tools/stamp_conv.py [layer ...]"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ampis_amd import ops, _lib
+
+LAYERS = {"res4.3x3": (8, 64, 64, 256, 256, 3, 1), "fpn.out.p2": (8, 256, 256, 256, 256, 3, 1), "fc1": (1, 1, 8000, 12544, 1024, 1, 0),
+          "fpn.lat.p2": (8, 256, 256, 256, 256, 1, 0), "res4.1x1c": (8, 64, 64, 256, 1024, 1, 0)}
+
+def main():
+    ctx = ops.torch_context(0)
+    L = _lib.lib()
+    buf = (ctypes.c_ulonglong * 64)()
+    for name in (sys.argv[1:] or list(LAYERS)):
+        B, H, W, Cin, Cout, k, p = LAYERS[name]
+        x = ops.split_rows(ctx, torch.randn(B, H, W, Cin, device="cuda:0"))
+        w = torch.randn(Cout, k, k, Cin, device="cuda:0") * 0.05
+        sc = torch.ones(Cout, device="cuda:0"); sh = torch.zeros(Cout, device="cuda:0")
+        kw = dict(stride=1, pad=p, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+        for _ in range(2):
+            ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+        torch.cuda.synchronize()
+        assert L.amp_debug_read_stamps(buf) == 0
+        n = 4
+        ctx.timer_start()
+        for _ in range(n):
+            ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+        ms = ctx.timer_stop() / n
+        torch.cuda.synchronize()
+        assert L.amp_debug_read_stamps(buf) == 0
+        M = B * H * W
+        nsteps = k * k * Cin // 32
+        nwg = ((M + 127) // 128) * (Cout // 256)
+        per = nwg * n * nsteps               # (wave slot, step) samples behind every counter
+        print(f"{name}: {ms:.3f} ms, {2.0 * M * Cout * k * k * Cin / ms / 1e9:.0f} TFLOP/s, {nsteps} steps, {nwg} workgroups; cycles per step and wave:")
+        print("   wave   wait+barrier   dma-issue   frag-reads   mfma-issue   | sum    loop/steps")
+        for wv in range(8):
+            v = [buf[wv * 8 + q] / per for q in range(5)]
+            print(f"   {wv}      {v[0]:9.0f}   {v[1]:9.0f}   {v[2]:9.0f}   {v[3]:9.0f}      | {sum(v[:4]):6.0f}  {v[4]:6.0f}")
+
+main()
