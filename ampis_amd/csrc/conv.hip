@@ -22,6 +22,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float LO_SCALE = 2048.0f;      // AMP_CONV_F16X3: lo' = (x - hi) * 2^11 (see conv_f16x3_kernel)
@@ -53,6 +54,7 @@ struct ConvArgs {
     int pred_K;
     float* prob;            // [B][2Ho][2Wo] mask probabilities
     int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
+    int direct_epi;         // conv_split_kernel: split rows written straight from the accumulators (0: staged through LDS; EXPERIMENT switch AMP_DIRECT_EPI)
     int stagger;            // conv_split_kernel: the two halves of the workgroup ping-pong between loading and multiplying (0: lockstep; EXPERIMENT switch AMP_STAGGER)
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
@@ -244,17 +246,29 @@ __device__ __forceinline__ void f16x3_load16(const float* As, const float* Bs, i
         f.bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo_lo);
     }
 }
-template <int MB, int NB>
+// SWAP = true: the weights are the MFMA's A operand (rows) and the activations its B operand (columns): the same exact products
+// summed in the same order into acc[i][j] / acx[i][j] (i: 16 tile rows m, j: 16 channels n), but a lane now holds, per block, FOUR
+// CHANNELS (4 lq + e) of ONE tile row (l15) instead of four rows of one channel -- what conv_epilogue_direct needs.
+template <int MB, int NB, bool SWAP = false>
 __device__ __forceinline__ void f16x3_mfma16(const F16x3Frags<MB, NB>& f, f32x4 (&acc)[MB][NB], f32x4 (&acx)[MB][NB]) {
     // per accumulator the order is lo'*hi, hi*lo' (cross sums), hi*hi; consecutive MFMAs never share an accumulator (NB apart)
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
+        if (SWAP) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bh[j], acx[i][j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bh[j], f.al[i], acx[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bl[j], acx[i][j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bl[j], f.ah[i], acx[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.al[i], f.bh[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bl[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        }
     }
 }
 template <int MB, int NB>
@@ -403,6 +417,110 @@ __device__ __forceinline__ void conv_epilogue_rows8(const ConvArgs& a, float* st
         }
         if (CHECK && bad) atomicOr(a.range_flag, 1);
     }
+}
+
+// ---- epilogues of conv_split_kernel (role-swapped MFMA, see f16x3_mfma16<.., SWAP = true>) ---------------------------------------
+// Channel order inside a wave's 64 channels: LDS weight row w = 16 j + 4 q + e (block j, MFMA row 4 q + e) holds channel
+// swap_channel(w) = 32 (j >> 1) + 8 q + 4 (j & 1) + e, so that lane (l15, lq = q) owns, per tile row, channels [8 lq, 8 lq + 8) of
+// each of the two 32-channel groups: 16 B of hi halves and 16 B of lo' halves per group in the split row format.
+__device__ __forceinline__ int swap_channel(int w) {
+    const int j = w >> 4, q = (w >> 2) & 3, e = w & 3;
+    return 32 * (j >> 1) + 8 * q + 4 * (j & 1) + e;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Straight from the accumulators to split rows -- no LDS staging (the staged epilogue moves 128 KB per tile through ds_write_b32 at
+// 64 B/clk: ~2000 cycles, plus the read-back) and packed arithmetic: per pair of outputs v_pk_mul/add (affine), 2 v_max (ReLU),
+// v_cvt_pk_f16_f32 (hi), v_pk_mul (x 2^11), v_pk_fma (hi * -2^11 + o * 2^11: the exact difference, already scaled), v_cvt_pk (lo').
+// Same values as conv_epilogue_rows8, bit for bit: o - hi and the scaling by 2^11 are exact in fp32, so the fused form rounds once,
+// where the unfused one did not round at all.  Range check: s = fma(v, 0, s) stays 0 unless an accumulator is inf or NaN.
+// out_mode 0, split output, no mask; residual none or in the split format (res_mode 1: same row; 2: the coarser level's row).
+template <bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[4][4], int lane, int mw0, int nw0) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const bool has_res = a.res_mode != 0;
+    f32x2 sc[2][4], sh[2][4];
+    size_t colb[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int n = nw0 + 32 * g + 8 * lq;
+        colb[g] = (size_t)(n >> 5) * 128 + (size_t)(n & 31) * 2;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            sc[g][p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
+            sh[g][p] = a.shift ? f32x2{a.shift[n + 2 * p], a.shift[n + 2 * p + 1]} : f32x2{0.f, 0.f};
+        }
+    }
+    f32x2 chk = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mrow = mw0 + i * 16 + l15;
+        const bool mv = mrow < a.M;
+        const unsigned int m = min((unsigned int)mrow, (unsigned int)(a.M - 1));
+        const size_t yrow = (size_t)m * a.Cout;
+        size_t rrow = yrow;
+        if (SPATIAL && a.res_mode == 2) {
+            const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            rrow = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout;
+        }
+        f16x8 rh[2], rl[2];
+        if (has_res) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const char* rb = reinterpret_cast<const char*>(a.res + rrow) + colb[g];
+                rh[g] = *reinterpret_cast<const f16x8*>(rb);
+                rl[g] = *reinterpret_cast<const f16x8*>(rb + 64);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x4& blk = acc[i][2 * g + (p >> 1)];
+                const f32x2 v = {blk[2 * (p & 1)], blk[2 * (p & 1) + 1]};
+                if (CHECK) chk = __builtin_elementwise_fma(v, f32x2{0.f, 0.f}, chk);
+                f32x2 o = v * sc[g][p] + sh[g][p];
+                if (has_res) {
+                    const f32x2 r1 = {(float)rh[g][2 * p], (float)rh[g][2 * p + 1]};
+                    const f32x2 r2 = {(float)rl[g][2 * p], (float)rl[g][2 * p + 1]};
+                    o = o + (r1 + r2 * (1.0f / LO_SCALE));
+                }
+                if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
+                const f16x2 h = __builtin_convertvector(o, f16x2);
+                const f32x2 hf = {(float)h[0], (float)h[1]};
+                const f32x2 l = __builtin_elementwise_fma(hf, f32x2{-LO_SCALE, -LO_SCALE}, o * LO_SCALE);
+                const f16x2 lh = __builtin_convertvector(l, f16x2);
+                hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+                lo[2 * p] = lh[0]; lo[2 * p + 1] = lh[1];
+            }
+            if (mv) {
+                char* base = reinterpret_cast<char*>(a.y + yrow) + colb[g];
+                *reinterpret_cast<f16x8*>(base) = hi;
+                *reinterpret_cast<f16x8*>(base + 64) = lo;
+            }
+        }
+    }
+    if (CHECK && (!(chk[0] == 0.f) || !(chk[1] == 0.f))) atomicOr(a.range_flag, 1);
+}
+
+// The staged epilogues (fp32 output, mask, scatter modes) behind the role-swapped MFMA: only the staging indices differ.
+template <int WTM, int WTN, bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_swapped(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int mw0, int nw0) {
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int SLD = WTN + 4;
+    float* stage = lds + wave * (WTM * SLD);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(stage + (i * 16 + l15) * SLD + 32 * (j >> 1) + 8 * lq + 4 * (j & 1)) = acc[i][j];
+    if (a.y_split && !a.mask && a.out_mode == 0) conv_epilogue_rows8<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
+    else conv_epilogue_rows<WTM, WTN, SPATIAL, CHECK>(a, stage, lane, mw0, nw0);
 }
 
 // rows of a wave's staged [WTM][WTN] tile -> affine, residual, ReLU, mask -> y (fp32 or split rows)
@@ -879,11 +997,10 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
     float* stage = lds + wave * (WTM * SLD);
     float* red = lds + 8 * (WTM * SLD);                 // [4 N-waves][128 rows] partial sums (2 KiB behind the staging tiles)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)                          // role-swapped accumulators: lane = (tile row l15, channels swap_channel(16 j + 4 lq + e))
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) stage[(i * 16 + 4 * lq + e) * SLD + j * 16 + l15] = acc[i][j][e];
+            *reinterpret_cast<f32x4*>(stage + (i * 16 + l15) * SLD + 32 * (j >> 1) + 8 * lq + 4 * (j & 1)) = acc[i][j];
     __builtin_amdgcn_wave_barrier();
     const int tap = n0 >> 8;                            // Cout = 4 * 256: the tile's N range is one tap
     const int co = wn * WTN + l15 * 4;                  // this lane's 4 output channels
@@ -945,7 +1062,8 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
 // ------------------------------------------------------------------------------------------------------------------
 #ifdef AMP_STAMP
 // Lab build only (make EXTRA=-DAMP_STAMP): in-kernel phase timing of conv_split_kernel -- cycles per wave slot and phase, summed over
-// all workgroups: [wave][0] wait+barrier, [1] DMA issue, [2] fragment reads (issue + return), [3] MFMA issue, [4] whole loop.
+// all workgroups: [wave][0] wait+barrier, [1] DMA issue, [2] fragment reads (issue + return), [3] MFMA issue, [4] whole loop,
+// [5] kernel entry -> loop, [6] loop end -> epilogue stores issued, [7] loop end -> past the final barrier.
 __device__ unsigned long long g_stamp[8 * 8];
 #define STAMP_T(var) const long long var = clock64()
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
@@ -970,6 +1088,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
     static_assert(GA >= 1 && GB >= 1 && NDMA < 16, "tile / wave split");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+#ifdef AMP_STAMP
+    const long long st_entry = clock64();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1010,8 +1131,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     unsigned int b_voff[GB];
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
-        const int r = wave * (BN / NW) + 8 * g + srow;
-        const int n = n0 + r;
+        const int r = wave * (BN / NW) + 8 * g + srow;               // LDS row; its weight row follows swap_channel (see conv_epilogue_direct)
+        const int n = n0 + (r & ~63) + swap_channel(r & 63);
         b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
     unsigned int a_voff[GA];
@@ -1086,7 +1207,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     // Same tiles, same sums per accumulator in the same order -- bit-identical results (1930-2010 cycles per K-step; +5..14 % per layer).
     F16x3Frags<MB, NB> fr;
 #ifdef AMP_STAMP
-    long long st_acc[5] = {0, 0, 0, 0, 0};
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long st_begin = clock64();
 #endif
     const float* As0 = lds + (wm * WTM + l15) * BK;
@@ -1104,7 +1225,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             STAMP_T(t3);
             if (pp) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
-            f16x3_mfma16<MB, NB>(fr, acc, acx);
+            f16x3_mfma16<MB, NB, true>(fr, acc, acx);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t4);
@@ -1117,7 +1238,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             open_step(step);
             STAMP_T(t1);
             __builtin_amdgcn_s_setprio(1);
-            if (step > 0) f16x3_mfma16<MB, NB>(fr, acc, acx);
+            if (step > 0) f16x3_mfma16<MB, NB, true>(fr, acc, acx);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1130,14 +1251,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             STAMP_ADD(0, t0, t1); STAMP_ADD(3, t1, t2); STAMP_ADD(1, t2, t3); STAMP_ADD(2, t3, t4);
             advance();
         }
-        f16x3_mfma16<MB, NB>(fr, acc, acx);
+        f16x3_mfma16<MB, NB, true>(fr, acc, acx);
     }
 #ifdef AMP_STAMP
     st_acc[4] = clock64() - st_begin;
-    if (lane == 0)
-        for (int q = 0; q < 5; ++q) atomicAdd(&g_stamp[wave * 8 + q], (unsigned long long)st_acc[q]);
+    st_acc[5] = st_begin - st_entry;
+    const long long st_loop_end = clock64();
 #endif
     __syncthreads();                           // all operand reads done: the epilogue re-uses the buffers as its staging tile
+#ifdef AMP_STAMP
+    st_acc[7] = clock64() - st_loop_end;
+#endif
 
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -1149,7 +1273,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     if constexpr (BM == 128 && BN == 256 && EPI == 2) {
         if (a.out_mode == 3) { conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0); return; }
     }
-    conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+    if (a.y_split && !a.mask && a.out_mode == 0 && (a.res_mode == 0 || a.res_split) && a.direct_epi)
+        conv_epilogue_direct<EPI == 2, true>(a, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
+    else
+        conv_epilogue_swapped<WTM, WTN, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+#ifdef AMP_STAMP
+    st_acc[6] = clock64() - st_loop_end;
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_stamp[wave * 8 + q], (unsigned long long)st_acc[q]);
+#endif
 }
 
 
@@ -1449,6 +1581,8 @@ extern "C" int amp_debug_read_stamps(unsigned long long* out) {     // 64 values
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif
+static int g_direct_epi = getenv("AMP_DIRECT_EPI") ? atoi(getenv("AMP_DIRECT_EPI")) : 1;
+extern "C" void amp_debug_set_direct_epi(int v) { g_direct_epi = v; }
 static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
 extern "C" void amp_debug_set_stagger(int v) { g_stagger = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
@@ -1627,6 +1761,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     a.y_split = (fmt & 2) ? 1 : 0;
     a.res_split = (fmt & 4) ? 1 : 0;
     a.stagger = g_stagger;
+    a.direct_epi = g_direct_epi;
     a.pred_w = a.pred_b = nullptr; a.pred_cls = nullptr; a.pred_K = 0; a.prob = nullptr;
     if (fuse) {     // the mask head's deconv with ReLU + predictor + sigmoid in its epilogue (conv_epilogue_predict)
         AMP_REQUIRE(x_is_split && d->out_mode == 1 && a.Cout == 1024 && a.KH == 1 && a.KW == 1 && a.relu && !res && !mask && !scale && g_split_ring,

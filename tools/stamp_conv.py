@@ -6,7 +6,8 @@ import torch
 from ampis_amd import ops, _lib
 
 LAYERS = {"res4.3x3": (8, 64, 64, 256, 256, 3, 1), "fpn.out.p2": (8, 256, 256, 256, 256, 3, 1), "fc1": (1, 1, 8000, 12544, 1024, 1, 0),
-          "fpn.lat.p2": (8, 256, 256, 256, 256, 1, 0), "res4.1x1c": (8, 64, 64, 256, 1024, 1, 0)}
+          "fpn.lat.p2": (8, 256, 256, 256, 256, 1, 0), "res4.1x1c": (8, 64, 64, 256, 1024, 1, 0),
+          "res2.1x1c": (8, 256, 256, 64, 256, 1, 0), "res3.1x1c": (8, 128, 128, 128, 512, 1, 0), "res4.3x3": (8, 64, 64, 256, 256, 3, 1)}
 
 def main():
     ctx = ops.torch_context(0)
@@ -37,6 +38,7 @@ def main():
         print("   wave   wait+barrier   dma-issue   frag-reads   mfma-issue   | sum    loop/steps")
         for wv in range(8):
             v = [buf[wv * 8 + q] / per for q in range(5)]
-            print(f"   {wv}      {v[0]:9.0f}   {v[1]:9.0f}   {v[2]:9.0f}   {v[3]:9.0f}      | {sum(v[:4]):6.0f}  {v[4]:6.0f}")
+            pro, epi = buf[wv * 8 + 5] / (nwg * n), buf[wv * 8 + 6] / (nwg * n)
+            print(f"   {wv}      {v[0]:9.0f}   {v[1]:9.0f}   {v[2]:9.0f}   {v[3]:9.0f}      | {sum(v[:4]):6.0f}  {v[4]:6.0f}   per workgroup: prologue {pro:7.0f}  loop {v[4] * nsteps:8.0f}  epilogue {epi:7.0f} (of which final barrier {buf[wv * 8 + 7] / (nwg * n):6.0f})")
 
 main()
