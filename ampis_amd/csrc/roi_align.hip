@@ -26,6 +26,7 @@ struct RoiArgs {
     int R, P, C;
     int out_split;          // 1: write the AMP_CONV_F16X3 operand format (per 32 channels 64 B of f16 hi halves + 64 B of lo' halves)
     int in_split;           // 1: the feature maps are in that format (the trunk's native activation format in AMP_CONV_F16X3 inference)
+    int share_taps;         // roi_align_split_kernel: keep a sample row's taps in registers (EXPERIMENT switch AMP_ROI_SHARE)
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -434,6 +435,7 @@ __device__ __forceinline__ void load_tap8(const float* row, int c8, float (&v)[8
 }
 
 __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
+    const bool g_share = a.share_taps != 0;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int half = lane >> 5, c8 = lane & 31;                 // C == 256: 32 lanes x 8 channels
@@ -471,6 +473,11 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
             int ylo = (int)y, yhi;
             if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
             const float ly = __fsub_rn(y, (float)ylo), hy = __fsub_rn(1.0f, ly);
+            // The samples of a row are less than one cell apart (gw = ceil(bin width)), so consecutive samples use the same cell pair or
+            // the next one: the four taps stay in registers and only the columns that changed are fetched (the kernel is bound by the
+            // 64 B/clk of the CU's vector L1, not by HBM or arithmetic: tools/bench_roi.py).  Same values, same operations, same order.
+            int cxlo = -2, cxhi = -2;
+            float v1[8], v2[8], v3[8], v4[8];
             for (int ix = 0; ix < gw; ++ix) {
                 float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
                 const bool bad = ybad || (x < -1.0f) || (x > (float)W);
@@ -480,11 +487,21 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
                 if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
                 const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
                 const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
-                float v1[8], v2[8], v3[8], v4[8];
-                load_tap8(fb + ((size_t)ylo * W + xlo) * a.C, c8, v1);
-                load_tap8(fb + ((size_t)ylo * W + xhi) * a.C, c8, v2);
-                load_tap8(fb + ((size_t)yhi * W + xlo) * a.C, c8, v3);
-                load_tap8(fb + ((size_t)yhi * W + xhi) * a.C, c8, v4);
+                if (g_share && xlo == cxhi && xlo != cxlo) {               // advanced by one cell: the right column becomes the left one
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v1[e] = v2[e]; v3[e] = v4[e]; }
+                    cxlo = xlo;
+                }
+                if (!g_share || xlo != cxlo) {
+                    load_tap8(fb + ((size_t)ylo * W + xlo) * a.C, c8, v1);
+                    load_tap8(fb + ((size_t)yhi * W + xlo) * a.C, c8, v3);
+                    cxlo = xlo;
+                }
+                if (!g_share || xhi != cxhi) {
+                    load_tap8(fb + ((size_t)ylo * W + xhi) * a.C, c8, v2);
+                    load_tap8(fb + ((size_t)yhi * W + xhi) * a.C, c8, v4);
+                    cxhi = xhi;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
@@ -516,6 +533,7 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
 
 }  // namespace
 
+static int g_roi_share = getenv("AMP_ROI_SHARE") ? atoi(getenv("AMP_ROI_SHARE")) : 1;
 static int g_roi_lanes = getenv("AMP_ROI_LANES") ? atoi(getenv("AMP_ROI_LANES")) : 1;   // 1: lane-parallel sample parameters (default); 0: the reference kernel (every lane computes every sample's parameters); 3: one workgroup per bin row, cells staged in LDS (slower, see roi_align_rows_kernel)
 extern "C" void amp_debug_set_roi_lanes(int v) { g_roi_lanes = v; }
 
@@ -549,7 +567,7 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
         a.scale[l] = 1.0f / (float)f->stride[l];
     }
     a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
-    a.R = R; a.P = P; a.C = f->C; a.out_split = out_split; a.in_split = in_split;
+    a.R = R; a.P = P; a.C = f->C; a.out_split = out_split; a.in_split = in_split; a.share_taps = g_roi_share;
     const long long nbins = (long long)R * P * P;
     long long g = (nbins + 3) / 4;
     if (g > 65536) g = 65536;
