@@ -1218,9 +1218,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             STAMP_T(t0);
             open_step(step);
             STAMP_T(t1);
-            if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
-            STAMP_T(t2);
+            // fragment reads first: they return while the DMA requests are being issued (~75 cycles each), not in front of the MFMAs
             f16x3_load16<MB, NB>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t2);
+            if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
             __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t3);
             if (pp) __builtin_amdgcn_s_barrier();
@@ -1229,7 +1231,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t4);
-            STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(2, t2, t3); STAMP_ADD(3, t3, t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(1, t2, t3); STAMP_ADD(3, t3, t4);
             advance();
         }
     } else {
@@ -1243,12 +1245,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             STAMP_T(t2);
-            if (step + 2 < a.nsteps) stage(nxt);
-            STAMP_T(t3);
             f16x3_load16<MB, NB>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
             __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t3);
+            if (step + 2 < a.nsteps) stage(nxt);
+            __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t4);
-            STAMP_ADD(0, t0, t1); STAMP_ADD(3, t1, t2); STAMP_ADD(1, t2, t3); STAMP_ADD(2, t3, t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(3, t1, t2); STAMP_ADD(2, t2, t3); STAMP_ADD(1, t3, t4);
             advance();
         }
         f16x3_mfma16<MB, NB, true>(fr, acc, acx);
