@@ -471,8 +471,9 @@ def main(args):
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"
                                       + (f"; barrier / max-over-ranks on RCCL {rccl[2]} through the C ABI" if rccl else "")},
             "roofline": {"bound": "mfma",
-                         "kernel": ("wide f16x3 tiles: conv_glds_kernel<256|128,F16> / conv_f16x3_kernel<256|128> (implicit-GEMM conv on v_mfma_f32_32x32x16_f16, "
-                                    "3 MFMAs per product, 128x256x32 8-wave / 128x128x32 4-wave tiles, LDS-DMA operands)") if mode == "f16x3" else
+                         "kernel": ("wide f16x3 tiles: conv_split_kernel<128x256 | 256x128> (+ conv_glds_kernel<128,F16>): implicit-GEMM conv on "
+                                    "v_mfma_f32_16x16x32_f16, 3 MFMAs per product, both operands pre-split and staged by LDS-DMA through a ring of "
+                                    "three 48-KB tiles, the two waves of a SIMD ping-pong between loading and multiplying") if mode == "f16x3" else
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "peak_is": ("f16 dense MFMA peak 2500 / 3 MFMAs per algorithmic product" if mode == "f16x3" else "fp32 dense MFMA peak"),
