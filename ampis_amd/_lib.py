@@ -55,7 +55,8 @@ class Dets(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("n", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
                 ("scores", C.POINTER(C.c_float)), ("classes", C.POINTER(C.c_int)),
                 ("rle_off", C.POINTER(C.c_ulonglong)), ("rle_len", C.POINTER(C.c_int)),
-                ("rle_counts", C.POINTER(C.c_uint32)), ("out_h", C.POINTER(C.c_int)), ("out_w", C.POINTER(C.c_int))]
+                ("rle_counts", C.POINTER(C.c_uint32)), ("out_h", C.POINTER(C.c_int)), ("out_w", C.POINTER(C.c_int)),
+                ("rle_str", C.c_void_p), ("rle_str_off", C.POINTER(C.c_ulonglong)), ("rle_str_len", C.POINTER(C.c_int))]
 
 
 _lib = None

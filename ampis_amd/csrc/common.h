@@ -112,6 +112,8 @@ int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const si
 int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete on the compute stream (exposed-time reference)
 int comm_wait_done(amp_ctx* ctx);              // compute stream waits (device side) for every collective issued so far
 int comm_agree_flag(amp_ctx* ctx, int* d_flag); // MAX of a device int over the ranks, complete on return
+int rle_strings_run(amp_ctx* ctx, const unsigned int* pool, const unsigned long long* off, const int* len, int n, char* str,
+                    unsigned long long cap, unsigned long long* str_off, int* str_len, unsigned long long* total);
 int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const int* batch_idx, const int* roi_count, int R, int P,
                   float* out, int* level_out, int out_split, int in_split = 0);   // out_split / in_split = 1: pooled tensor / feature maps in the split row format
 int box_candidates_run(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B, int Rcap, int K,

@@ -87,6 +87,11 @@ struct amp_model {
     uint32_t* h_pool = nullptr;         // pinned, host-cacheable: the run lengths of one call land here by DMA and are handed out in place
     size_t h_pool_counts = 0;
     const uint32_t* r_pool_ptr = nullptr;
+    int rle_mode = 0;                   // amp_model_set_rle_output: 0 run lengths, 1 counts strings (encoded on the device), 2 both
+    char* h_str = nullptr;              // pinned: the counts strings of one call
+    size_t h_str_bytes = 0;
+    std::vector<unsigned long long> r_str_off;
+    std::vector<int> r_str_len;
     std::vector<int> r_out_h, r_out_w;
     float last_stage_ms[8];
     // ---- training ----
@@ -593,9 +598,14 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(o_off, unsigned long long, (size_t)std::max(N, 1));
     AMP_ALLOC(o_len, int, (size_t)std::max(N, 1));
     AMP_ALLOC(pool_used, unsigned long long, 2);      // [0] run lengths (read back), [1] position scratch
+    AMP_ALLOC(o_soff, unsigned long long, (size_t)std::max(N, 1));   // counts strings (rle_mode != 0): offset / length per detection, bytes in all
+    AMP_ALLOC(o_slen, int, (size_t)std::max(N, 1));
+    AMP_ALLOC(str_total, unsigned long long, 1);
     const size_t res1 = ws.off;
     AMP_ALLOC(rle_pool, unsigned int, (size_t)c.rle_pool_counts);
     AMP_ALLOC(pos_pool, unsigned int, (size_t)c.rle_pool_counts);
+    const unsigned long long str_cap = (unsigned long long)c.rle_pool_counts * 4;      // bytes: a run needs 1-7 characters, 1.3 on average
+    AMP_ALLOC(str_pool, char, (size_t)str_cap);
     if (dry) return AMP_OK;
     AMP_REQUIRE(res1 - res0 <= m->h_res_bytes, "amp_model_infer: result staging too small");
 
@@ -636,6 +646,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(amp_paste_rle_sized(ctx, mprob, m_boxes, m_batch, N, d_out_hw, d_out_hw + B, max_hw, H, W, T.img_hw, c.mask_threshold, o_boxes,
                               o_valid, rle_pool, (unsigned long long)c.rle_pool_counts, pool_used, o_off, o_len, m->d_flags + 1,
                               pos_pool, (unsigned long long)c.rle_pool_counts, pool_used + 1));
+        if (m->rle_mode) AMP_TRY(amp::rle_strings_run(ctx, rle_pool, o_off, o_len, N, str_pool, str_cap, o_soff, o_slen, str_total));
         tap(m, "mask_prob", mprob, 0, {N, 28, 28});
         tap(m, "mask_rois", m_boxes, 0, {N, 4});
     }
@@ -645,6 +656,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     auto host_of = [&](const void* dev) { return hres + ((const char*)dev - (ws.base + res0)); };
     const float* hb = nullptr; const float* hs = nullptr; const int* hv = nullptr; const int* hc = nullptr; const int* hl = nullptr;
     const unsigned long long* ho = nullptr;
+    const unsigned long long* hso = nullptr; const int* hsl = nullptr;
     if (N > 0) {
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_res, ws.base + res0, res1 - res0, hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -652,9 +664,22 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         if (m->h_counts[B + 1]) { amp::set_error("amp_model_infer: RLE pool (%zu counts) exhausted; raise cfg.rle_pool_counts", (size_t)c.rle_pool_counts); return AMP_ERR_NOMEM; }
         hb = (const float*)host_of(o_boxes); hs = (const float*)host_of(m_scores); hc = (const int*)host_of(m_classes);
         hv = (const int*)host_of(o_valid); hl = (const int*)host_of(o_len); ho = (const unsigned long long*)host_of(o_off);
+        hso = (const unsigned long long*)host_of(o_soff); hsl = (const int*)host_of(o_slen);
         const unsigned long long used = *(const unsigned long long*)host_of(pool_used);
+        const unsigned long long sbytes = m->rle_mode ? *(const unsigned long long*)host_of(str_total) : 0ull;
+        if (m->rle_mode) {
+            if (sbytes > str_cap || sbytes > m->h_str_bytes) {
+                amp::set_error("amp_model_infer: the counts strings need %llu bytes, the string pool holds %llu; raise cfg.rle_pool_counts", sbytes,
+                               std::min<unsigned long long>(str_cap, m->h_str_bytes));
+                return AMP_ERR_NOMEM;
+            }
+            if (sbytes) AMP_HIP_CHECK(hipMemcpyAsync(m->h_str, str_pool, (size_t)sbytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
         // the pool holds run lengths only (positions live in their own scratch pool): the used prefix is exactly what the caller gets
-        if (m->h_pool && used <= m->h_pool_counts) {
+        if (m->rle_mode == 1) {
+            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // strings only: the run lengths stay on the device
+            m->r_pool_ptr = nullptr;
+        } else if (m->h_pool && used <= m->h_pool_counts) {
             // DMA into host-cacheable pinned memory and hand that out: a pageable destination made the runtime stage the bytes and
             // the CPU copy them once more while the GPU sat idle (0.3 ms per step for 2.5 MB)
             if (used) AMP_HIP_CHECK(hipMemcpyAsync(m->h_pool, rle_pool, (size_t)used * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -676,6 +701,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     m->r_classes.assign((size_t)B * D, -1);
     m->r_rle_off.assign((size_t)B * D, 0ull);
     m->r_rle_len.assign((size_t)B * D, 0);
+    m->r_str_off.assign((size_t)B * D, 0ull);
+    m->r_str_len.assign((size_t)B * D, 0);
     for (int b = 0; b < B; ++b) {
         int n = 0;
         for (int i = off[b]; i < off[b + 1]; ++i) {
@@ -686,6 +713,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
             m->r_classes[o] = hc[i];
             m->r_rle_off[o] = ho[i];
             m->r_rle_len[o] = hl[i];
+            if (m->rle_mode) { m->r_str_off[o] = hso[i]; m->r_str_len[o] = hsl[i]; }
             ++n;
         }
         m->r_n[b] = n;
@@ -1201,7 +1229,7 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
     const int R = cfg->max_batch * cfg->post_nms_topk;
     std::vector<int> iota(R);
     for (int i = 0; i < R; ++i) iota[i] = i / cfg->post_nms_topk;
-    m->h_res_bytes = (size_t)cfg->max_batch * cfg->detections_per_image * 48 + 16 * 256;
+    m->h_res_bytes = (size_t)cfg->max_batch * cfg->detections_per_image * 64 + 20 * 256;
     // every small device / pinned allocation is checked: under memory pressure (two contexts per GPU, a re-created training net) a
     // failed one must surface as AMP_ERR_NOMEM here, not as a fault in the first call that touches the null pointer
     bool ok = hipMalloc(&m->d_batch_iota, (size_t)R * sizeof(int)) == hipSuccess &&
@@ -1238,10 +1266,25 @@ void amp_model_destroy(amp_model* m) {
     (void)hipHostFree(m->h_small);
     (void)hipHostFree(m->h_res);
     if (m->h_pool) (void)hipHostFree(m->h_pool);
+    if (m->h_str) (void)hipHostFree(m->h_str);
     delete m;
 }
 
 size_t amp_model_workspace_bytes(amp_model* m) { return m ? m->ws.cap : 0; }
+
+int amp_model_set_rle_output(amp_model* m, int mode) {
+    AMP_REQUIRE(m && mode >= 0 && mode <= 2, "amp_model_set_rle_output: mode is AMP_RLE_COUNTS (0), AMP_RLE_STRINGS (1) or AMP_RLE_BOTH (2)");
+    if (mode != 0 && !m->h_str) {
+        m->h_str_bytes = (size_t)std::min<unsigned long long>((unsigned long long)m->cfg.rle_pool_counts * 4, (unsigned long long)256 << 20);
+        if (hipHostMalloc(reinterpret_cast<void**>(&m->h_str), m->h_str_bytes, hipHostMallocNonCoherent) != hipSuccess) {
+            m->h_str = nullptr; m->h_str_bytes = 0; (void)hipGetLastError();
+            amp::set_error("amp_model_set_rle_output: cannot pin %zu bytes for the counts strings", m->h_str_bytes);
+            return AMP_ERR_NOMEM;
+        }
+    }
+    m->rle_mode = mode;
+    return AMP_OK;
+}
 
 int amp_model_num_tensors(amp_model* m) { return m ? (int)m->expected.size() : 0; }
 const char* amp_model_tensor_name(amp_model* m, int i) {
@@ -1571,6 +1614,9 @@ int amp_model_infer(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int
     out->rle_counts = m->r_pool_ptr;
     out->out_h = m->r_out_h.data();
     out->out_w = m->r_out_w.data();
+    out->rle_str = m->rle_mode ? m->h_str : nullptr;
+    out->rle_str_off = m->rle_mode ? m->r_str_off.data() : nullptr;
+    out->rle_str_len = m->rle_mode ? m->r_str_len.data() : nullptr;
     return AMP_OK;
 }
 

@@ -39,6 +39,9 @@ class PackedGt:
                          pxy.ctypes.data_as(C.POINTER(C.c_double)))
 
 
+RLE_COUNTS, RLE_STRINGS, RLE_BOTH = 0, 1, 2
+
+
 class MaskRCNN:
     def __init__(self, ctx, num_classes, max_batch=1, max_h=1344, max_w=1344, max_out_hw=4096,
                  detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
@@ -119,27 +122,42 @@ class MaskRCNN:
         """Returns a list (one per image) of dict(boxes f32[N,4], scores f32[N], classes i64[N],
         masks = list of COCO RLE dicts {'size':[h,w], 'counts': bytes}) -- the content compress_pred produces
         (ampis/data_utils.py:275-278). rle='counts' keeps the uncompressed uint32 run lengths instead."""
+        self.set_rle_output(RLE_COUNTS if rle == "counts" else RLE_STRINGS)
         d = self.infer_raw(images, out_sizes, device_ptr, shape)
         B, D = d.B, d.D
         n = np.ctypeslib.as_array(d.n, (B,)).copy()
         boxes = np.ctypeslib.as_array(d.boxes, (B, D, 4))
         scores = np.ctypeslib.as_array(d.scores, (B, D))
         classes = np.ctypeslib.as_array(d.classes, (B, D))
-        off = np.ctypeslib.as_array(d.rle_off, (B, D))
-        ln = np.ctypeslib.as_array(d.rle_len, (B, D))
-        total = int((off[ln > 0] + ln[ln > 0]).max()) if (ln > 0).any() else 0
-        pool = np.ctypeslib.as_array(d.rle_counts, (total,)) if total > 0 else np.zeros(1, dtype=np.uint32)
+        if rle == "counts":
+            off = np.ctypeslib.as_array(d.rle_off, (B, D))
+            ln = np.ctypeslib.as_array(d.rle_len, (B, D))
+            total = int((off[ln > 0] + ln[ln > 0]).max()) if (ln > 0).any() else 0
+            pool = np.ctypeslib.as_array(d.rle_counts, (total,)) if total > 0 else np.zeros(1, dtype=np.uint32)
+        else:       # the counts strings were encoded on the device (amp_model_set_rle_output): one bytes object, sliced per mask
+            soff = np.ctypeslib.as_array(d.rle_str_off, (B, D))
+            slen = np.ctypeslib.as_array(d.rle_str_len, (B, D))
+            total = int((soff + slen.astype(np.uint64)).max()) if B * D else 0
+            raw = C.string_at(d.rle_str, total) if total > 0 else b""
         out = []
         for b in range(B):
             k = int(n[b])
             h, w = int(d.out_h[b]), int(d.out_w[b])
             if rle == "counts":
                 masks = [{"size": [h, w], "counts": pool[int(off[b, i]): int(off[b, i]) + int(ln[b, i])].copy()} for i in range(k)]
-            else:       # one C call per image: a ctypes round trip per mask cost 3 ms of a 9 ms DefaultPredictor call at 400 masks
-                masks = [{"size": [h, w], "counts": c} for c in _rle.counts_to_strings(pool, off[b, :k], ln[b, :k])]
+            else:
+                so, sl = soff[b, :k].tolist(), slen[b, :k].tolist()
+                masks = [{"size": [h, w], "counts": raw[so[i]: so[i] + sl[i]]} for i in range(k)]
             out.append(dict(boxes=boxes[b, :k].copy(), scores=scores[b, :k].copy(),
                             classes=classes[b, :k].astype(np.int64), masks=masks, image_size=(h, w)))
         return out
+
+    def set_rle_output(self, mode):
+        """What infer_raw's Dets carries for the masks: RLE_COUNTS (uint32 run lengths, default), RLE_STRINGS (COCO counts strings encoded
+        on the device; the run lengths stay there) or RLE_BOTH."""
+        if getattr(self, "_rle_mode", RLE_COUNTS) != mode:
+            check(lib().amp_model_set_rle_output(self._h, int(mode)), "amp_model_set_rle_output")
+            self._rle_mode = mode
 
     LOSS_NAMES = ("loss_cls", "loss_box_reg", "loss_mask", "loss_rpn_cls", "loss_rpn_loc")
 

@@ -231,7 +231,7 @@ def roi_align(ctx, feats, rois, batch_idx, P, fmt=0):
 def roi_align_bwd(ctx, dfeats, strides, rois, batch_idx, P, dout, B=0):
     """dfeats[l] [B,h,w,256] += RoIAlign-backward(dout [R,P,P,256]) (amp_roi_align_bwd_batched; B = 0: derived from batch_idx)."""
     import ctypes as C_
-    ptrs = (C_.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
+    ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in dfeats])
     fh = (C_.c_int * 4)(*[f.shape[1] for f in dfeats])
     fw = (C_.c_int * 4)(*[f.shape[2] for f in dfeats])
     st = (C_.c_int * 4)(*strides)
@@ -270,3 +270,28 @@ def paste_rle(ctx, prob, det_boxes, det_batch, out_h, out_w, in_h, in_w, thresho
     off_h, ln_h = off.cpu().numpy(), ln.cpu().numpy()
     runs = [pool_h[int(o): int(o) + int(l)].copy() for o, l in zip(off_h, ln_h)]
     return ob, valid, runs
+
+
+def rle_strings_device(ctx, pool, off, ln):
+    """COCO counts strings of many masks, encoded on the device (amp_rle_strings_device): pool uint32 run lengths (int32 / uint32 tensor on
+    the device), mask i = pool[off[i] : off[i] + ln[i]].  Returns the list of bytes objects."""
+    import torch
+    n = int(off.numel())
+    dev = pool.device
+    off = off.to(dev).to(torch.int64).contiguous()
+    ln = ln.to(dev).to(torch.int32).contiguous()
+    pool = pool.contiguous()
+    cap = 7 * int(pool.numel()) + 8
+    buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    soff = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    slen = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(lib().amp_rle_strings_device(ctx.handle, C.c_void_p(pool.data_ptr()), C.c_void_p(off.data_ptr()), C.c_void_p(ln.data_ptr()), n,
+                                       C.c_void_p(buf.data_ptr()), C.c_ulonglong(cap), C.c_void_p(soff.data_ptr()),
+                                       C.c_void_p(slen.data_ptr()), C.c_void_p(total.data_ptr())), "amp_rle_strings_device")
+    torch.cuda.synchronize()
+    t = int(total.item())
+    assert t <= cap
+    raw = bytes(buf[:t].cpu().numpy().tobytes())
+    so, sl = soff.cpu().tolist(), slen.cpu().tolist()
+    return [raw[so[i]: so[i] + sl[i]] for i in range(n)]

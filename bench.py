@@ -3,7 +3,7 @@
 python bench.py --gpus N --steps K --warmup W       (N > 1: one rank per GPU -- started by torch.distributed.run, or by bench.py itself when RANK is not set)
 
 A step = one pass of the hot path (amp_model_infer: preprocess -> backbone -> FPN -> RPN -> proposals -> box head ->
-detections -> mask head -> paste -> RLE counts on the host) over one batch of 8 images that is already resident in HBM.
+detections -> mask head -> paste -> RLE counts strings on the host) over one batch of 8 images that is already resident in HBM.
 Image-parallel replicas: every rank runs the same per-GPU batch, no data-path collective ("weak" scaling); RCCL (through the C ABI) is only
 used for the barrier and the max-over-ranks of the elapsed time.  Prints ONE JSON line on rank 0.
 """
@@ -66,7 +66,7 @@ import numpy as np
 import torch
 
 from ampis_amd import _lib, params as P, synth
-from ampis_amd.model import MaskRCNN
+from ampis_amd.model import MaskRCNN, RLE_STRINGS
 
 BATCH, SIZE, K, DETS = 8, 1024, 2, 200
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -271,6 +271,7 @@ def two_pipelines_leg(local_rank, dev, rank, world, steps, ranks, params, imgs):
         c = _lib.Context(local_rank)
         m = MaskRCNN(c, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
         m.load_params(params)
+        m.set_rle_output(RLE_STRINGS)
         d = c.malloc(imgs.nbytes)
         c.h2d(d, imgs)
         ctxs.append(c); models.append(m); bufs.append(d)
@@ -340,6 +341,7 @@ def x101_leg(ctx, dev, rank, world, steps, ranks):
     p = P.init_params(K, seed=0, style="spread", arch="X101")
     p["backbone.bottom_up.stem.conv1.weight"] = p["backbone.bottom_up.stem.conv1.weight"] * np.float32(57.0)   # seeded stem assumes unit std
     model.load_params(p)
+    model.set_rle_output(RLE_STRINGS)
     del p
     imgs, _ = synth.batch(XB, S, S, first_index=2000 + rank * XB)
     d_imgs = ctx.malloc(imgs.nbytes)
@@ -398,6 +400,7 @@ def main(args):
     model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     params = P.init_params(K, seed=0, style="spread")
     model.load_params(params)
+    model.set_rle_output(RLE_STRINGS)      # masks come back as COCO counts strings, encoded on the device (what compress_pred stores)
     log(f"workspace {model.workspace_bytes / 2**30:.2f} GiB; weights loaded; generating {BATCH} micrographs")
     imgs, _ = synth.batch(BATCH, SIZE, SIZE, first_index=rank * BATCH)
     d_imgs = ctx.malloc(imgs.nbytes)
@@ -465,7 +468,7 @@ def main(args):
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: R50-FPN inference, batch=8 synthetic 1024x1024 micrographs per GPU, "
                                    "K=2, 1000 proposals/img, TEST.DETECTIONS_PER_IMAGE=200, seeded random-init weights, "
-                                   "outputs boxes+scores+classes+COCO-RLE counts on host",
+                                   "outputs on the host: boxes, scores, classes and every mask as its COCO compressed-RLE counts string (encoded on the device)",
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"

@@ -271,6 +271,10 @@ int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t
 /* n lists out of one pool (list i = pool[off[i] .. +len[i])) -> n strings back to back; string i = out[str_off[i] .. str_off[i+1]) */
 int amp_rle_to_strings(const uint32_t* pool, const unsigned long long* off, const int* len, int n, char* out, size_t cap,
                        size_t* str_off /* [n+1] */);
+/* Device op behind AMP_RLE_STRINGS (all pointers are device pointers): mask i = pool[off[i] .. off[i] + len[i]) -> its counts string at
+ * str[str_off[i] .. str_off[i] + str_len[i]); *total = bytes needed (> cap: the tail was not written). maskApi.c rleToString, restated. */
+int amp_rle_strings_device(amp_ctx* ctx, const uint32_t* pool, const unsigned long long* off, const int* len, int n, char* str,
+                           unsigned long long cap, unsigned long long* str_off, int* str_len, unsigned long long* total);
 int amp_rle_from_string(const char* s, size_t len, uint32_t* cnts, int cap, int* m_out);
 int amp_rle_encode(const uint8_t* mask_colmajor, int h, int w, uint32_t* cnts, int cap, int* m_out);
 int amp_rle_decode(const uint32_t* cnts, int m, int h, int w, uint8_t* mask_colmajor);
@@ -332,9 +336,18 @@ typedef struct amp_dets {
     const int* classes;              /* [B,D] */
     const unsigned long long* rle_off; /* [B,D] offset of the mask's run lengths in rle_counts */
     const int* rle_len;              /* [B,D] number of runs (column-major, first run counts zeros) */
-    const uint32_t* rle_counts;
+    const uint32_t* rle_counts;      /* NULL under AMP_RLE_STRINGS */
     const int* out_h; const int* out_w; /* [B] mask size */
+    /* amp_model_set_rle_output(m, AMP_RLE_STRINGS | AMP_RLE_BOTH): the masks as COCO compressed-RLE "counts" strings, encoded on the
+     * device -- the bytes pycocotools' mask.encode()["counts"] holds, what compress_pred stores (ampis/data_utils.py:275). NULL otherwise. */
+    const char* rle_str;             /* string of detection (b, i) = rle_str[rle_str_off[b*D+i] .. + rle_str_len[b*D+i]) (no terminator) */
+    const unsigned long long* rle_str_off; /* [B,D] */
+    const int* rle_str_len;          /* [B,D] */
 } amp_dets;
+enum { AMP_RLE_COUNTS = 0, AMP_RLE_STRINGS = 1, AMP_RLE_BOTH = 2 };
+/* What amp_model_infer hands back for the masks (default AMP_RLE_COUNTS: uint32 run lengths). With AMP_RLE_STRINGS the run lengths
+ * never leave the device: 3-4x fewer bytes over PCIe and no host-side encoding (replaces the pycocotools call of data_utils.py:275). */
+int  amp_model_set_rle_output(amp_model* m, int mode);
 int  amp_model_cfg_default(amp_model_cfg* cfg);
 int  amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out);
 void amp_model_destroy(amp_model* m);
