@@ -194,7 +194,10 @@ constexpr int wreg(int cols) { return cols / 2 * WPITCH + 128; }
 constexpr int WOP = 2 * wreg(128);          // bytes of a 128-column operand tile
 
 // (An 8-wave variant with a 256-channel dY tile -- 24 instead of 32 split values per lane and step -- ran at the same speed.)
-template <int SC>   // SC 0: no operand scaling, 1: dY * scale, 2: X * scale
+// XS = true: X is stored in the split hi|lo' row format (the trunk's native activation format; same row offsets as fp32): a lane
+// fetches the 4 B of hi halves and the 4 B of lo' halves of its channel pair and hands them to the tile as they are -- no split
+// arithmetic for that operand (the halves are what the in-kernel split of the fp32 value would produce: same MFMA inputs, same sums).
+template <int SC, bool XS = false>   // SC 0: no operand scaling, 1: dY * scale, 2: X * scale
 __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, const float scale, const float out_scale, int* range_flag) {
     constexpr int REG = wreg(128);
     constexpr int STAGE = 2 * WOP;
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
 
     const int pcol = 2 * lane;                     // tile column pair of this lane
     const unsigned int p_voff = (n0 + pcol < a.N) ? (unsigned int)((n0 + pcol) * 4) : OOB;   // N even: a pair is all-in or all-out
-    const unsigned int q_lane = (unsigned int)((c0 + 2 * lane) * 4);
+    const int qc = c0 + 2 * lane;                  // this lane's channel pair of X
+    const unsigned int q_lane = XS ? (unsigned int)((qc >> 5) * 128 + (qc & 31) * 2) : (unsigned int)(qc * 4);
     const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * mg;   // wave-uniform: scalar loads
 
     unsigned int qt[8];                // X-row byte offsets of the step fetched next
@@ -238,8 +242,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
         for (int r = 0; r < 8; ++r)
             rp[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);   // past the tensor: zero fill
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            rq[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (int)(qt[r] + q_lane), 0, 0);             // 0x80000000 + lane part: zero fill
+        for (int r = 0; r < 8; ++r) {
+            if (XS) {
+                rq[r][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (int)(qt[r] + q_lane), 0, 0);        // hi halves of the pair
+                rq[r][1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (int)(qt[r] + q_lane + 64), 0, 0);   // lo' halves
+            } else {
+                rq[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_x, (int)(qt[r] + q_lane), 0, 0);         // 0x80000000 + lane part: zero fill
+            }
+        }
     };
     auto commit = [&](int buf) {
         unsigned char* P = lds + buf * STAGE + lane * WPITCH + mg * 16;
@@ -261,12 +271,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
             f16x8 qh, ql;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const unsigned int qu = rq[r][q];
-                float y = __builtin_bit_cast(float, qu);
-                if (SC == 2) y *= scale;
-                const _Float16 h = (_Float16)y;
-                qh[r] = h;
-                ql[r] = (_Float16)((y - (float)h) * LO_SCALE);
+                if (XS) {
+                    const unsigned int hu = rq[r][0], lu = rq[r][1];
+                    qh[r] = __builtin_bit_cast(_Float16, (unsigned short)(q ? (hu >> 16) : (hu & 0xffffu)));
+                    ql[r] = __builtin_bit_cast(_Float16, (unsigned short)(q ? (lu >> 16) : (lu & 0xffffu)));
+                } else {
+                    const unsigned int qu = rq[r][q];
+                    float y = __builtin_bit_cast(float, qu);
+                    if (SC == 2) y *= scale;
+                    const _Float16 h = (_Float16)y;
+                    qh[r] = h;
+                    ql[r] = (_Float16)((y - (float)h) * LO_SCALE);
+                }
             }
             *reinterpret_cast<f16x8*>(Q + q * REG) = qh;
             *reinterpret_cast<f16x8*>(Q + q * REG + 64) = ql;
@@ -343,9 +359,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     if (bad && range_flag) *range_flag = 1;
 }
 
-void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag) {
+void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag, int x_split = 0) {
     const int sh = dy_shift ? dy_shift : x_shift;
     const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);     // exact powers of two
+    if (x_split) {
+        if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+        else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+        return;
+    }
     if (dy_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<1>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
     else if (x_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
     else hipLaunchKernelGGL(wgrad_f16x3_kernel<0>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
@@ -501,7 +522,14 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
 
 int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                             float* grad, int accumulate, int dy_shift, int x_shift) {
+    return amp_conv2d_wgrad_fmt(ctx, d, x, dy, scale, scratch, grad, accumulate, dy_shift, x_shift, 0);
+}
+
+int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
+                         float* grad, int accumulate, int dy_shift, int x_shift, int x_split) {
     AMP_REQUIRE(ctx && d && x && dy && scratch && grad, "amp_conv2d_wgrad: null argument");
+    AMP_REQUIRE(!x_split || (ctx->conv_mode == AMP_CONV_F16X3 && x_shift == 0 && d->Cin % 32 == 0),
+                "amp_conv2d_wgrad_fmt: a split-format x needs AMP_CONV_F16X3, no x shift and Cin %% 32 == 0");
     AMP_REQUIRE(dy_shift >= 0 && dy_shift <= 24 && x_shift >= 0 && x_shift <= 24 && (dy_shift == 0 || x_shift == 0),
                 "amp_conv2d_wgrad: shifts must be in [0, 24] and at most one of them non-zero");
     AMP_REQUIRE(d->Cin % TC == 0, "amp_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, TC);
@@ -543,7 +571,7 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
         }
     }
     if (ctx->conv_mode == AMP_CONV_F16X3) {
-        launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag);   // the fp32 kernel needs no shift
+        launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag, x_split);   // the fp32 kernel needs no shift
     } else {
         hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
     }

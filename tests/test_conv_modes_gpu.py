@@ -163,6 +163,26 @@ WGRAD_CASES = [
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_reads_split_activations_bit_identically(gpu_ctx, case):
+    """amp_conv2d_wgrad_fmt(x_split = 1): the activation stored in the trunk's split row format gives the SAME weight gradient, bit for
+    bit, as the fp32 activation split inside the kernel (the halves are the same numbers)."""
+    from ampis_amd import ops
+    B, H, W, Cin, Cout, k, s, p, mag, shift = case
+    if Cin % 32:
+        pytest.skip("split rows need Cin % 32 == 0")
+    g = torch.Generator().manual_seed(3 * Cin + k + Cout)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 3).clamp_(min=0).cuda()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = (torch.randn(B, Ho, Wo, Cout, generator=g) * mag).cuda()
+    want = ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift)
+    xs = ops.split_rows(gpu_ctx, x)
+    got = ops.conv2d_wgrad(gpu_ctx, xs, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift, x_split=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert not gpu_ctx.conv_range_flag()
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
 def test_wgrad_f16x3_is_at_least_as_accurate_as_fp32_mfma(gpu_ctx, case):
     from ampis_amd import ops
     B, H, W, Cin, Cout, k, s, p, mag, shift = case

@@ -34,14 +34,18 @@ def main():
         Ho = (H + 2 * p - k) // s + 1; Wo = (W + 2 * p - k) // s + 1
         dy = torch.randn(B, Ho, Wo, Cout, device=d)
         flops = 2.0 * B * Ho * Wo * Cout * k * k * Cin
+        xs = bool(os.environ.get("AMP_SPLIT_IN")) and Cin % 32 == 0      # x stored in the split row format (amp_conv2d_wgrad_fmt)
+        if xs:
+            x = ops.split_rows(ctx, x)
+            name += " [x split]"
         g = None
         for _ in range(2):
-            g = ops.conv2d_wgrad(ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, grad=g)
+            g = ops.conv2d_wgrad(ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, grad=g, dy_shift=16, x_split=xs)
         torch.cuda.synchronize()
         n = 5
         ctx.timer_start()
         for _ in range(n):
-            ops.conv2d_wgrad(ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, grad=g)
+            ops.conv2d_wgrad(ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, grad=g, dy_shift=16, x_split=xs)
         ms = ctx.timer_stop() / n
         tot += ms
         print(f"{name:18s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  (M={B*Ho*Wo}, N={Cout}, K'={k*k*Cin})", flush=True)
