@@ -424,3 +424,25 @@ def test_roi_align_reads_and_writes_the_split_format(gpu_ctx, C, P):
     if C % 32 == 0:
         got_s, _ = ops.roi_align(gpu_ctx, fs, rois, bidx, P, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
         assert torch.equal(got_s, ops.split_rows(gpu_ctx, ref))
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 256, 256, 3, 1, False), (8, 64, 64, 256, 1024, 1, 0, True), (3, 96, 97, 128, 128, 3, 1, False),
+                                   (8, 128, 128, 64, 256, 1, 0, True)])
+def test_ring_kernel_repeats_bit_for_bit(gpu_ctx, shape):
+    """Race screen of the LDS-DMA ring / ping-pong kernel (tools/race_screen.py is the long version with a noisy neighbour): the
+    arithmetic is deterministic, so a tile read before its DMA landed or restaged before its last reader shows as a launch that does
+    not reproduce the first one."""
+    from ampis_amd import ops
+    B, H, W, Cin, Cout, k, p, res = shape
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = ops.split_rows(gpu_ctx, torch.randn(B, H, W, Cin, generator=g).cuda())
+    w = (torch.randn(Cout, k, k, Cin, generator=g) * 0.05).cuda()
+    sc, sh = torch.rand(Cout, generator=g).cuda() + 0.5, torch.randn(Cout, generator=g).cuda()
+    kw = dict(stride=1, pad=p, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+    if res:
+        kw.update(res=ops.split_rows(gpu_ctx, torch.randn(B, H, W, Cout, generator=g).cuda()), res_mode=1, fmt=kw["fmt"] | ops.FMT_RES_SPLIT)
+    first = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw).clone()
+    for _ in range(40):
+        y = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int32), first.view(torch.int32))

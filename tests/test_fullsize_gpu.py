@@ -121,3 +121,26 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx):
     d_hip, d_ref = dist(out[5]["boxes"]), dist(r32)
     print(f"worst box distance from the exact-convolution oracle: HIP {d_hip:.2e} px, fp32 oracle {d_ref:.2e} px")
     assert d_hip <= max(1e-3, 1.5 * d_ref), (d_hip, d_ref)
+
+
+def test_inference_repeats_bit_for_bit():
+    """The whole hot path at the bench's size is deterministic: ten runs of the same batch give the same boxes, scores, classes and
+    counts strings, byte for byte (a race in any LDS-DMA kernel, an atomic in a reduction or an order-dependent selection would show)."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    B, S, D = 4, 1024, 100
+    m = MaskRCNN(ctx, 2, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+    m.load_params(P.init_params(2, seed=0, style="spread"))
+    imgs, _ = synth.batch(B, S, S, first_index=40)
+    first = None
+    for it in range(10):
+        out = m.infer(imgs)
+        sig = [(o["boxes"].tobytes(), o["scores"].tobytes(), o["classes"].tobytes(), tuple(mm["counts"] for mm in o["masks"])) for o in out]
+        if first is None:
+            first = sig
+            assert sum(len(o["masks"]) for o in out) > 50
+        else:
+            assert sig == first, f"run {it} differs from run 0"
+    m.close()
+    ctx.close()

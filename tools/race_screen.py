@@ -1,0 +1,69 @@
+"""Race screen of the LDS-DMA ring / ping-pong kernel (conv_split_kernel): the arithmetic is deterministic, so every repetition of a
+launch must reproduce the first one BIT FOR BIT; an LDS tile read before its DMA landed, or restaged before its last reader, shows up
+as a rare mismatch that comes and goes with timing (cdna_hip_programming.md: "place reads by the vmcnt/barrier count, never by clean
+runs" -- this is the clean-runs half of that check, the count half is in the kernel's comments).  Timing is perturbed on purpose: a
+second context streams memory and runs other convs on its own HIP stream while the screened launches repeat.
+usage (GPU box): python tools/race_screen.py [repetitions]"""
+import os, sys, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ampis_amd import ops, _lib
+
+SHAPES = [
+    # name, B, H, W, Cin, Cout, k, pad, residual
+    ("3x3 256->256 @64 (72 steps, one round)", 8, 64, 64, 256, 256, 3, 1, False),
+    ("3x3 256->256 @128 (4 rounds)", 8, 128, 128, 256, 256, 3, 1, False),
+    ("1x1 256->1024 @64 + residual (8 steps)", 8, 64, 64, 256, 1024, 1, 0, True),
+    ("1x1 64->256 @128 + residual (2 steps)", 8, 128, 128, 64, 256, 1, 0, True),
+    ("3x3 128->128 @96 (256x128 tiles, ragged M)", 3, 96, 97, 128, 128, 3, 1, False),
+    ("fc 12544->1024, 999 rows (392 steps, ragged)", 1, 1, 999, 12544, 1024, 1, 0, False),
+    ("1x1 32->256 @64 (one step)", 4, 64, 64, 32, 256, 1, 0, False),
+]
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    ctx = ops.torch_context(0)
+    stop = threading.Event()
+
+    def noise():      # a second context on its own stream: memory streams + convs of other shapes, to move the timing around
+        c2 = _lib.Context(0)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            a = torch.randn(64 << 20, device="cuda:0")
+            while not stop.is_set():
+                a.mul_(1.0001)
+                torch.cuda.current_stream().synchronize()
+        c2.close()
+
+    th = threading.Thread(target=noise)
+    th.start()
+    bad = 0
+    try:
+        for name, B, H, W, Cin, Cout, k, p, res in SHAPES:
+            g = torch.Generator().manual_seed(Cin + Cout + k)
+            x = ops.split_rows(ctx, torch.randn(B, H, W, Cin, generator=g).cuda())
+            w = (torch.randn(Cout, k, k, Cin, generator=g) * 0.05).cuda()
+            sc = torch.rand(Cout, generator=g).cuda() + 0.5
+            sh = torch.randn(Cout, generator=g).cuda()
+            kw = dict(stride=1, pad=p, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+            if res:
+                kw.update(res=ops.split_rows(ctx, torch.randn(B, H, W, Cout, generator=g).cuda()), res_mode=1, fmt=kw["fmt"] | ops.FMT_RES_SPLIT)
+            first = ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw).clone()
+            torch.cuda.synchronize()
+            mism = 0
+            for _ in range(reps):
+                y = ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+                torch.cuda.synchronize()
+                if not torch.equal(y.view(torch.int32), first.view(torch.int32)):
+                    mism += 1
+            print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
+            bad += mism
+    finally:
+        stop.set()
+        th.join()
+    print("RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} mismatching launches)")
+    sys.exit(0 if bad == 0 else 1)
+
+
+main()
