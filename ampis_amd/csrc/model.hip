@@ -911,16 +911,25 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(cs_scratch, float, (size_t)4 << 20);   // ceil(M/512) * N floats of the largest bias-gradient reduction
     auto GW = [&](const ConvW& cw) { return m->garena + (cw.w - m->parena); };
     auto GB = [&](const ConvW& cw) { return m->garena + (cw.shift - m->parena); };
-    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc) -> int {
+    auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
+        return amp_colsum(ctx, dy, (int)M_, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0);
+    };
+    // weight gradient; bias = true: the bias gradient (column sums of dy) as well -- summed on the side by the AMP_CONV_F16X3 kernel from the
+    // dy tiles it stages anyway, by a separate amp_colsum pass over dy on the fp32 MFMA
+    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc, bool bias = false) -> int {
         amp_conv_desc d;
         d.B = B_; d.H = H_; d.W = W_; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw; d.stride = stride; d.pad = pad;
         d.relu = 0; d.res_mode = 0; d.out_mode = 0;
         AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
+        static const bool no_fused_bias = getenv("AMP_NO_FUSED_BIAS") != nullptr;      // EXPERIMENT switch
+        const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias;
         // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
-        return amp_conv2d_wgrad_scaled(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0);
-    };
-    auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
-        return amp_colsum(ctx, dy, (int)M_, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0);
+        AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, 0, fused ? GB(cw) : nullptr, acc ? 1 : 0));
+        if (bias && !fused) {
+            const int Ho_ = (H_ + 2 * pad - cw.kh) / stride + 1, Wo_ = (W_ + 2 * pad - cw.kw) / stride + 1;
+            return bgrad(cw, dy, (long long)B_ * Ho_ * Wo_, acc);
+        }
+        return AMP_OK;
     };
     // dx = conv(dy, flipped/transposed/scaled w) (+ res) (* mask>0); dy is [B_,Hy,Wy,cw.cout]
     auto dgrad = [&](const ConvW& cw, const float* dy, int B_, int Hy, int Wy, int fwd_pad, const float* res, const float* mask, float* dx) -> int {
@@ -951,8 +960,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(dbd_t, float, 256);
     if (!dry && N > 0) {
         const ConvW& cp = CONV("roi_heads.mask_head.predictor");
-        AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false));
-        AMP_TRY(bgrad(cp, d_mlogits, (long long)N * 784, false));
+        AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false, true));
         AMP_TRY(amp_small_k_dgrad(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, (size_t)N * 784));
         const ConvW& cd = CONV("roi_heads.mask_head.deconv");
         {   // weight gradient in [ci][tap][co] form, then transposed into the forward layout [(tap,co)][ci]
@@ -974,8 +982,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         for (int i = 4; i >= 1; --i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
             const ConvW& cf = CONV(key.c_str());
-            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false));
-            AMP_TRY(bgrad(cf, dcur, (long long)N * 196, false));
+            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, true));
             AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext));
             std::swap(dcur, dnext);
         }
@@ -996,16 +1003,13 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(d_pooled, float, (size_t)R * 49 * 256);
     if (!dry) {
         const ConvW& cb = CONV("roi_heads.box_predictor");
-        AMP_TRY(wgrad(cb, fc2, 1, 1, R, 1, 0, d_box_pred, false));
-        AMP_TRY(bgrad(cb, d_box_pred, R, false));
+        AMP_TRY(wgrad(cb, fc2, 1, 1, R, 1, 0, d_box_pred, false, true));
         AMP_TRY(dgrad(cb, d_box_pred, 1, 1, R, 0, nullptr, fc2, d_fc2));
         const ConvW& c2 = CONV("roi_heads.box_head.fc2");
-        AMP_TRY(wgrad(c2, fc1, 1, 1, R, 1, 0, d_fc2, false));
-        AMP_TRY(bgrad(c2, d_fc2, R, false));
+        AMP_TRY(wgrad(c2, fc1, 1, 1, R, 1, 0, d_fc2, false, true));
         AMP_TRY(dgrad(c2, d_fc2, 1, 1, R, 0, nullptr, fc1, d_fc1));
         const ConvW& c1 = CONV("roi_heads.box_head.fc1");
-        AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false));
-        AMP_TRY(bgrad(c1, d_fc1, R, false));
+        AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false, true));
         AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
         AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled, B));
     }
@@ -1017,11 +1021,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         if (dry) continue;
         const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
         const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
-        AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0));
-        AMP_TRY(bgrad(cpred, d_rpn_pred[l], (long long)B * T.fh[l] * T.fw[l], l > 0));
+        AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0, true));
         AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t));
-        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0));
-        AMP_TRY(bgrad(cconv, d_t, (long long)B * T.fh[l] * T.fw[l], l > 0));
+        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0, true));
         AMP_TRY(dgrad(cconv, d_t, B, T.fh[l], T.fw[l], 1, d_feat[l], nullptr, d_feat[l]));   // accumulate in place
     }
     AMP_TRY(issue_bucket(m, 2));
@@ -1041,8 +1043,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const std::string ln = "backbone.fpn_lateral" + std::to_string(l), on = "backbone.fpn_output" + std::to_string(l);
         const ConvW& co = CONV(on.c_str());
         const ConvW& cl = CONV(ln.c_str());
-        AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false));
-        AMP_TRY(bgrad(co, d_feat[s_], (long long)B * fh_ * fw_, false));
+        AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false, true));
         AMP_TRY(dgrad(co, d_feat[s_], B, fh_, fw_, 1, d_lat_prev, nullptr, d_lat));      // + top-down share from the finer level
         if (l < 5) {
             AMP_HIP_CHECK(hipMemsetAsync(d_lat_next, 0, (size_t)B * T.fh[s_ + 1] * T.fw[s_ + 1] * 256 * 4, ctx->stream));
@@ -1050,8 +1051,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         const float* res_in = nullptr;   // input of the lateral conv = output of stage s_
         for (auto& ba : m->blocks) if (ba.stage == s_) res_in = ba.out;
-        AMP_TRY(wgrad(cl, res_in, B, fh_, fw_, 1, 0, d_lat, false));
-        AMP_TRY(bgrad(cl, d_lat, (long long)B * fh_ * fw_, false));
+        AMP_TRY(wgrad(cl, res_in, B, fh_, fw_, 1, 0, d_lat, false, true));
         if (l >= 3) AMP_TRY(dgrad(cl, d_lat, B, fh_, fw_, 0, nullptr, nullptr, d_res[s_]));
         d_lat_prev = d_lat_next;
     }

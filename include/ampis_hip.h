@@ -143,9 +143,11 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
  * |operand * 2^shift| >= 65504 raises amp_conv_range_flag(). amp_conv2d_wgrad == shifts 0. */
 int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                             float* grad, int accumulate, int dy_shift, int x_shift);
-/* The same with x in the split hi|lo' row format (AMP_FMT_X_SPLIT; written by amp_conv2d_nhwc_fmt / the native trunk): x_split = 1. */
+/* The same with x in the split hi|lo' row format (AMP_FMT_X_SPLIT; written by amp_conv2d_nhwc_fmt / the native trunk): x_split = 1;
+ * bias_grad != NULL (AMP_CONV_F16X3 only): bias_grad[n] (= or +=) sum over the pixels of dy[.][n], summed on the side by the MFMA kernel
+ * from the dy tiles it stages anyway (replaces a separate amp_colsum pass over dy). */
 int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
-                            float* grad, int accumulate, int dy_shift, int x_shift, int x_split);
+                            float* grad, int accumulate, int dy_shift, int x_shift, int x_split, float* bias_grad, int bias_accumulate);
 /* out[n] (= or +=) sum_m dy[m][n]; N % 4 == 0; scratch >= ceil(M/512)*N floats */
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */

@@ -183,6 +183,33 @@ def test_wgrad_reads_split_activations_bit_identically(gpu_ctx, case):
 
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_fused_bias_gradient(gpu_ctx, case):
+    """amp_conv2d_wgrad_fmt(bias_grad): the column sums of dy the MFMA kernel adds up on the side equal an fp64 sum to fp32 accuracy,
+    accumulate when asked, repeat bit for bit, and leave the weight gradient untouched."""
+    from ampis_amd import ops
+    B, H, W, Cin, Cout, k, s, p, mag, shift = case
+    g = torch.Generator().manual_seed(11 * Cin + k + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).clamp_(min=0).cuda()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = (torch.randn(B, Ho, Wo, Cout, generator=g) * mag + 0.1 * mag).cuda()
+    want_w = ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift)
+    b = torch.full((Cout,), 7.0, device="cuda:0")
+    got_w = ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift, bias_grad=b)
+    torch.cuda.synchronize()
+    assert torch.equal(got_w, want_w)
+    ref = dy.double().sum((0, 1, 2))
+    err = (b.double() - ref).abs().max().item()
+    assert err <= 2e-6 * dy.double().abs().sum((0, 1, 2)).max().item() + 1e-30, err
+    b2 = b.clone()
+    ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift, bias_grad=b2, bias_accumulate=True)
+    b3 = torch.zeros_like(b)
+    ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=shift, bias_grad=b3)
+    torch.cuda.synchronize()
+    assert torch.equal(b3, b), "bitwise reproducible"
+    assert torch.equal(b2, b + b)
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
 def test_wgrad_f16x3_is_at_least_as_accurate_as_fp32_mfma(gpu_ctx, case):
     from ampis_amd import ops
     B, H, W, Cin, Cout, k, s, p, mag, shift = case
