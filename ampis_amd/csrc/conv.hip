@@ -54,6 +54,7 @@ struct ConvArgs {
     int pred_K;
     float* prob;            // [B][2Ho][2Wo] mask probabilities
     int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
+    int mask_split;         // 1: the ReLU mask tensor (training: the forward activation) is in that format (AMP_FMT_MASK_SPLIT)
     int direct_epi;         // conv_split_kernel: split rows written straight from the accumulators (0: staged through LDS; EXPERIMENT switch AMP_DIRECT_EPI)
     int stagger;            // conv_split_kernel: the two halves of the workgroup ping-pong between loading and multiplying (0: lockstep; EXPERIMENT switch AMP_STAGGER)
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
@@ -201,7 +202,13 @@ __device__ __forceinline__ void conv_epilogue_generic_rows(const ConvArgs& a, fl
             if (a.relu) t = fmaxf(t, 0.f);
             o[q] = t;
         }
-        if (a.mask) {
+        if (a.mask && a.mask_split) {                  // the gating activation in the split row format (Cout % 32 == 0, out_mode 0)
+            const char* mb = reinterpret_cast<const char*>(a.mask + (yoff[it] - (size_t)n)) + (n >> 5) * 128 + (n & 31) * 2;
+            const f16x4 mh = *reinterpret_cast<const f16x4*>(mb);
+            const f16x4 ml = *reinterpret_cast<const f16x4*>(mb + 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = __fadd_rn((float)mh[q], __fmul_rn((float)ml[q], 1.0f / LO_SCALE)) > 0.f ? o[q] : 0.f;
+        } else if (a.mask) {
             if (vec) {
                 const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + yoff[it]);
 #pragma unroll
@@ -599,7 +606,19 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, float* sta
             for (int it = 0; it < NIT; ++it)
                 if (mv[it]) rres[it] = *reinterpret_cast<const f32x4*>(a.res + roff[it]);
         }
-        if (has_mask) {
+        if (has_mask && a.mask_split) {
+            // the activation whose sign gates the gradient lives in the split row format (training on the native trunk): decoded like a
+            // split residual; hi + lo' * 2^-11 > 0 exactly when the stored activation was (down to 2^-35, below which both halves are 0)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (mv[it]) {
+                    const char* mb = reinterpret_cast<const char*>(a.mask + (yoff[it] - (size_t)n)) + (n >> 5) * 128 + (n & 31) * 2;
+                    const f16x4 mh = *reinterpret_cast<const f16x4*>(mb);
+                    const f16x4 ml = *reinterpret_cast<const f16x4*>(mb + 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mk[it][q] = __fadd_rn((float)mh[q], __fmul_rn((float)ml[q], 1.0f / LO_SCALE));
+                }
+        } else if (has_mask) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (mv[it]) mk[it] = *reinterpret_cast<const f32x4*>(a.mask + yoff[it]);
@@ -1763,6 +1782,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     const bool x_is_split = (fmt & 1) != 0;
     a.y_split = (fmt & 2) ? 1 : 0;
     a.res_split = (fmt & 4) ? 1 : 0;
+    a.mask_split = (fmt & 8) ? 1 : 0;
     a.stagger = g_stagger;
     a.direct_epi = g_direct_epi;
     a.pred_w = a.pred_b = nullptr; a.pred_cls = nullptr; a.pred_K = 0; a.prob = nullptr;
@@ -1773,6 +1793,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         a.out_mode = 3;
         a.pred_w = fuse->pred_w; a.pred_b = fuse->pred_b; a.pred_cls = fuse->cls; a.pred_K = fuse->K; a.prob = fuse->prob;
     }
+    AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
     AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && in_shift == 0 && glds),

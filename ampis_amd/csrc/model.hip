@@ -98,6 +98,8 @@ struct amp_model {
     float* garena = nullptr;            // gradients, same offsets as parena
     float* varena = nullptr;            // SGD momentum buffers, same offsets
     bool saving = false;                // run_trunk keeps every activation the backward pass needs
+    bool acts_split = false;            // ... and kept them in the split row format (training on the native trunk, AMP_CONV_F16X3)
+    bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
     struct BlockAct { std::string key; float *x_in, *t1, *t2, *sc, *out; int in_h, in_w, oh, ow, cin, mid, cout, stride, stage; bool has_sc; };
     std::vector<BlockAct> blocks;
     float* lat[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -270,7 +272,10 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     // residual / FPN top-down adds and RoIAlign decode it exactly (hi + lo' * 2^-11).  A conv that cannot read the format (grouped
     // 3x3 of ResNeXt, weights beyond the fp16 range) gets an fp32 input from its producer.  Training keeps fp32 activations: the
     // backward kernels read them.
-    const bool native = !dry && !m->saving && split_chain(m, {});
+    // Training (m->saving): the saved activations stay in the format too when EVERY trunk conv reads it (R50 / R101) -- the backward
+    // kernels take them as they are (wgrad x_split, AMP_FMT_MASK_SPLIT, amp_relu_mask_split) -- otherwise the trunk keeps fp32.
+    static const bool train_native = getenv("AMP_NO_TRAIN_NATIVE") == nullptr;      // EXPERIMENT switch
+    bool native = !dry && split_chain(m, {}) && (!m->saving || train_native);
     auto reads_split = [&](const std::string& key) {
         if (!native) return false;
         auto it = m->conv.find(key);
@@ -281,8 +286,10 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         for (auto& kv : m->conv) {
             const std::string& k = kv.first;
             const bool trunk = k.rfind("backbone.", 0) == 0 || k.rfind("proposal_generator.", 0) == 0;
-            if (trunk && k != "backbone.bottom_up.stem.conv1" && kv.second.groups == 1 && !reads_split(k)) native_all = false;
+            if (trunk && k != "backbone.bottom_up.stem.conv1" && (kv.second.groups != 1 ? m->saving : !reads_split(k))) native_all = false;
         }
+    if (m->saving && !native_all) native = false;     // (reads_split follows: everything fp32)
+    m->acts_split = m->saving && native_all;
     const int SPL = 5;                 // tap dtype of a split tensor
     auto FMT = [](bool x_split, bool y_split, bool res_split) { return (x_split ? 1 : 0) | (y_split ? 2 : 0) | (res_split ? 4 : 0); };
 
@@ -721,6 +728,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     return AMP_OK;
 }
 
+int refresh_split_weights(amp_model* m);
+
 // Training-mode forward + losses. With ws.dry nothing is launched (workspace sizing only).
 int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const amp_gt* gt, unsigned int seed, float losses[5], bool backward) {
     Bump& ws = m->ws;
@@ -732,6 +741,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     Trunk T;
     struct ModeGuard { amp_ctx* c; int mode; ~ModeGuard() { c->conv_mode = mode; } } mode_guard{m->ctx, m->ctx->conv_mode};
     m->saving = backward;
+    // the forward trunk of a training step runs on pre-split operands like inference: refresh the weights' split copies (stale since the
+    // last SGD step) once here instead of splitting every layer's weights inside its own launch
+    if (!dry && backward && m->split_stale && m->ctx->conv_mode == AMP_CONV_F16X3 && getenv("AMP_NO_TRAIN_NATIVE") == nullptr) AMP_TRY(refresh_split_weights(m));
     const int trunk_status = run_trunk(m, imgs_d, B, H, W, T);
     m->saving = false;
     AMP_TRY(trunk_status);
@@ -808,8 +820,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         for (int i = 0; i < R; ++i) iota[i] = i / RB;
         AMP_HIP_CHECK(hipMemcpyAsync(roi_batch_idx, iota.data(), (size_t)R * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // iota is a temporary
-        AMP_TRY(amp::roi_align_run(ctx, &T.ff, rois, roi_batch_idx, nullptr, R, 7, pooled, nullptr, 0, T.feat_split ? 1 : 0));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1));
+        // heads of a training step on the native trunk (HS): the pooled tensors and the mask head's hidden activations are stored in the
+        // split row format as well (their convolutions stage pre-split operands; wgrad / the ReLU masks of the backward pass read the format)
+        const bool HS = backward && m->acts_split && CONV("roi_heads.box_head.fc1").w_split != nullptr;
+        AMP_TRY(amp::roi_align_run(ctx, &T.ff, rois, roi_batch_idx, nullptr, R, 7, pooled, nullptr, HS ? 1 : 0, T.feat_split ? 1 : 0));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc1"), pooled, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc1, HS ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_head.fc2"), fc1, 1, 1, R, 1, 0, true, 0, nullptr, 0, fc2));
         AMP_TRY(launch_conv(m, CONV("roi_heads.box_predictor"), fc2, 1, 1, R, 1, 0, false, 0, nullptr, 0, box_pred));
         // counts decide the normalisers and the mask-branch sizes
@@ -870,10 +885,13 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_HIP_CHECK(hipMemcpyAsync(m_cls, hc.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m_poly, hp.data(), (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // hb/hc/hp are temporaries
-        AMP_TRY(amp::roi_align_run(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr, 0, T.feat_split ? 1 : 0));
+        const bool MS = backward && m->acts_split && split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2",
+                                                                      "roi_heads.mask_head.mask_fcn3", "roi_heads.mask_head.mask_fcn4"});
+        m->mask_acts_split = MS;          // macts[0..3] split, macts[4] (the deconv's input: an operand of ITS weight gradient) fp32
+        AMP_TRY(amp::roi_align_run(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr, MS ? 1 : 0, T.feat_split ? 1 : 0));
         for (int i = 1; i <= 4; ++i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
-            AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i]));
+            AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i], MS ? (i < 4 ? 3 : 1) : 0));
         }
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
@@ -916,7 +934,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     };
     // weight gradient; bias = true: the bias gradient (column sums of dy) as well -- summed on the side by the AMP_CONV_F16X3 kernel from the
     // dy tiles it stages anyway, by a separate amp_colsum pass over dy on the fp32 MFMA
-    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc, bool bias = false) -> int {
+    const bool AS = m->acts_split;      // the trunk's saved activations are in the split row format
+    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc, bool bias = false, bool x_split = false) -> int {
         amp_conv_desc d;
         d.B = B_; d.H = H_; d.W = W_; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw; d.stride = stride; d.pad = pad;
         d.relu = 0; d.res_mode = 0; d.out_mode = 0;
@@ -924,7 +943,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         static const bool no_fused_bias = getenv("AMP_NO_FUSED_BIAS") != nullptr;      // EXPERIMENT switch
         const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias;
         // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
-        AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, 0, fused ? GB(cw) : nullptr, acc ? 1 : 0));
+        AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, x_split ? 1 : 0, fused ? GB(cw) : nullptr, acc ? 1 : 0));
         if (bias && !fused) {
             const int Ho_ = (H_ + 2 * pad - cw.kh) / stride + 1, Wo_ = (W_ + 2 * pad - cw.kw) / stride + 1;
             return bgrad(cw, dy, (long long)B_ * Ho_ * Wo_, acc);
@@ -932,7 +951,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         return AMP_OK;
     };
     // dx = conv(dy, flipped/transposed/scaled w) (+ res) (* mask>0); dy is [B_,Hy,Wy,cw.cout]
-    auto dgrad = [&](const ConvW& cw, const float* dy, int B_, int Hy, int Wy, int fwd_pad, const float* res, const float* mask, float* dx) -> int {
+    auto dgrad = [&](const ConvW& cw, const float* dy, int B_, int Hy, int Wy, int fwd_pad, const float* res, const float* mask, float* dx, bool mask_split = false) -> int {
         AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
         AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
         amp_conv_desc d;
@@ -940,7 +959,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
         // data gradient on the context's arithmetic; AMP_CONV_F16X3 splits dy * 2^16 (gradients of 1e-9..1e-4 would sit in the f16
         // subnormals)
-        return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16);
+        return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
     };
 
     // ---- gradient buffers of the FPN outputs p2..p6 ----
@@ -982,8 +1001,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         for (int i = 4; i >= 1; --i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
             const ConvW& cf = CONV(key.c_str());
-            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, true));
-            AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext));
+            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, true, m->mask_acts_split));
+            AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext, m->mask_acts_split));
             std::swap(dcur, dnext);
         }
         AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur, B));
@@ -1009,7 +1028,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(wgrad(c2, fc1, 1, 1, R, 1, 0, d_fc2, false, true));
         AMP_TRY(dgrad(c2, d_fc2, 1, 1, R, 0, nullptr, fc1, d_fc1));
         const ConvW& c1 = CONV("roi_heads.box_head.fc1");
-        AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false, true));
+        AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false, true, AS && c1.w_split != nullptr));
         AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
         AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled, B));
     }
@@ -1021,9 +1040,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         if (dry) continue;
         const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
         const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
-        AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0, true));
-        AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t));
-        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0, true));
+        AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0, true, AS));
+        AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t, AS));
+        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0, true, AS));
         AMP_TRY(dgrad(cconv, d_t, B, T.fh[l], T.fw[l], 1, d_feat[l], nullptr, d_feat[l]));   // accumulate in place
     }
     AMP_TRY(issue_bucket(m, 2));
@@ -1043,7 +1062,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const std::string ln = "backbone.fpn_lateral" + std::to_string(l), on = "backbone.fpn_output" + std::to_string(l);
         const ConvW& co = CONV(on.c_str());
         const ConvW& cl = CONV(ln.c_str());
-        AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false, true));
+        AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false, true, AS));
         AMP_TRY(dgrad(co, d_feat[s_], B, fh_, fw_, 1, d_lat_prev, nullptr, d_lat));      // + top-down share from the finer level
         if (l < 5) {
             AMP_HIP_CHECK(hipMemsetAsync(d_lat_next, 0, (size_t)B * T.fh[s_ + 1] * T.fw[s_ + 1] * 256 * 4, ctx->stream));
@@ -1051,7 +1070,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         const float* res_in = nullptr;   // input of the lateral conv = output of stage s_
         for (auto& ba : m->blocks) if (ba.stage == s_) res_in = ba.out;
-        AMP_TRY(wgrad(cl, res_in, B, fh_, fw_, 1, 0, d_lat, false, true));
+        AMP_TRY(wgrad(cl, res_in, B, fh_, fw_, 1, 0, d_lat, false, true, AS));
         if (l >= 3) AMP_TRY(dgrad(cl, d_lat, B, fh_, fw_, 0, nullptr, nullptr, d_res[s_]));
         d_lat_prev = d_lat_next;
     }
@@ -1086,22 +1105,22 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         const size_t out_elems = (size_t)B * ba.oh * ba.ow * ba.cout;
         // d(pre-activation) = d(out) * (out > 0); inside a stage the previous iteration's input-gradient conv has applied it already
-        if (!dcur_masked) AMP_TRY(amp_relu_mask(ctx, dcur, ba.out, out_elems));
+        if (!dcur_masked) AMP_TRY(AS ? amp_relu_mask_split(ctx, dcur, ba.out, out_elems, ba.cout) : amp_relu_mask(ctx, dcur, ba.out, out_elems));
         dcur_masked = false;
         const ConvW& c3 = CONV((ba.key + ".conv3").c_str());
         const ConvW& c2 = CONV((ba.key + ".conv2").c_str());
         const ConvW& c1 = CONV((ba.key + ".conv1").c_str());
         AMP_ALLOC(d_t2, float, (size_t)B * ba.oh * ba.ow * ba.mid);
         AMP_ALLOC(d_t1, float, (size_t)B * ba.oh * ba.ow * ba.mid);
-        AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false));
-        AMP_TRY(dgrad(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2));
-        AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false));
-        AMP_TRY(dgrad(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1));
-        AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false));
+        AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false, false, AS));
+        AMP_TRY(dgrad(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2, AS));
+        AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false, false, AS));
+        AMP_TRY(dgrad(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1, AS));
+        AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false, false, AS));
         const bool need_dx = !(ba.stage == 1 && ba.has_sc);   // the input of res3.0 is the frozen res2 output
         if (ba.has_sc) {
             const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
-            AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false));
+            AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false, false, AS));
             if (need_dx) {
                 AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
                 AMP_ALLOC(tmp_in, float, (size_t)B * ba.oh * ba.ow * ba.cin);
@@ -1115,7 +1134,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_ALLOC(d_in, float, out_elems);
             // + identity shortcut, times the ReLU mask of the block below (its output IS this block's input)
             const bool fuse = bi > 0 && m->blocks[bi - 1].out == ba.x_in;
-            AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in));
+            AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in, AS));
             dcur = d_in;
             dcur_masked = fuse;
         }

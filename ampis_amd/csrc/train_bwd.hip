@@ -326,6 +326,23 @@ __global__ void relu_mask_kernel(float* __restrict__ g, const float* __restrict_
     }
 }
 
+// the same with act in the split hi|lo' row format (C channels per row, C % 32 == 0): positive iff one of its halves is non-zero
+typedef _Float16 rm_f16x4 __attribute__((ext_vector_type(4)));
+__global__ void relu_mask_split_kernel(float* __restrict__ g, const float* __restrict__ act, size_t n4, int C4) {
+    f32x4* gg = reinterpret_cast<f32x4*>(g);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const char* mb = reinterpret_cast<const char*>(act + row * (size_t)C4 * 4) + (c >> 5) * 128 + (c & 31) * 2;
+        const rm_f16x4 mh = *reinterpret_cast<const rm_f16x4*>(mb);
+        const rm_f16x4 ml = *reinterpret_cast<const rm_f16x4*>(mb + 64);
+        f32x4 v = gg[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((float)mh[q] + (float)ml[q] * (1.0f / 2048.0f)) > 0.f ? v[q] : 0.f;
+        gg[i] = v;
+    }
+}
+
 // dx[p][c] = (sum_k dl[p][k] * w[k][c]) * (act[p][c] > 0)     (mask predictor 1x1 conv, K <= 8 classes padded to ld)
 __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K, const float* __restrict__ w, int C,
                                      const float* __restrict__ act, float* __restrict__ dx, size_t npix) {
@@ -459,6 +476,13 @@ int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, i
 int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n) {
     AMP_REQUIRE(ctx && g && act && n % 4 == 0, "amp_relu_mask: bad argument");
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ctx->stream, g, act, n / 4);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n, int C) {
+    AMP_REQUIRE(ctx && g && act_split && C > 0 && C % 32 == 0 && n % (size_t)C == 0, "amp_relu_mask_split: bad argument (C %% 32 != 0?)");
+    hipLaunchKernelGGL(relu_mask_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ctx->stream, g, act_split, n / 4, C / 4);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -384,22 +384,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     if (bad && range_flag) *range_flag = 1;
 }
 
+template <bool XS, bool BIAS>
+void launch_wgrad_f16x3_v(const WgradArgs& a, int blocks, int dy_shift, int x_shift, float sc, float osc, hipStream_t st, int* flag) {
+    if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else if (x_shift && !XS) hipLaunchKernelGGL((wgrad_f16x3_kernel<2, false, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+}
 void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag, int x_split = 0) {
     const int sh = dy_shift ? dy_shift : x_shift;
     const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);     // exact powers of two
-    if (a.bias_partial && !x_split && x_shift == 0) {
-        if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-        else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-        return;
-    }
-    if (x_split) {
-        if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-        else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-        return;
-    }
-    if (dy_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<1>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-    else if (x_shift) hipLaunchKernelGGL(wgrad_f16x3_kernel<2>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-    else hipLaunchKernelGGL(wgrad_f16x3_kernel<0>, dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    const bool bias = a.bias_partial != nullptr;
+    if (x_split) { if (bias) launch_wgrad_f16x3_v<true, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<true, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
+    else { if (bias) launch_wgrad_f16x3_v<false, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<false, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
 }
 
 // rowtab[tap][m] = byte offset of the input pixel that output pixel m sees through tap (ky,kx), or 0x80000000 (outside the image, or
@@ -565,8 +561,7 @@ int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x
 int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                          float* grad, int accumulate, int dy_shift, int x_shift, int x_split, float* bias_grad, int bias_accumulate) {
     AMP_REQUIRE(ctx && d && x && dy && scratch && grad, "amp_conv2d_wgrad: null argument");
-    AMP_REQUIRE(!bias_grad || (ctx->conv_mode == AMP_CONV_F16X3 && !x_split && x_shift == 0),
-                "amp_conv2d_wgrad_fmt: the fused bias gradient needs AMP_CONV_F16X3, fp32 x and no x shift (use amp_colsum)");
+    AMP_REQUIRE(!bias_grad || ctx->conv_mode == AMP_CONV_F16X3, "amp_conv2d_wgrad_fmt: the fused bias gradient needs AMP_CONV_F16X3 (use amp_colsum)");
     AMP_REQUIRE(!x_split || (ctx->conv_mode == AMP_CONV_F16X3 && x_shift == 0 && d->Cin % 32 == 0),
                 "amp_conv2d_wgrad_fmt: a split-format x needs AMP_CONV_F16X3, no x shift and Cin %% 32 == 0");
     AMP_REQUIRE(dy_shift >= 0 && dy_shift <= 24 && x_shift >= 0 && x_shift <= 24 && (dy_shift == 0 || x_shift == 0),

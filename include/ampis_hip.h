@@ -127,7 +127,7 @@ int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, con
  * (64 B) followed by 32 f16 halves of lo' = (x - hi) * 2^11 (64 B).  amp_split_weights makes it from fp32 rows, amp_unsplit_rows
  * reads it back (hi + lo' * 2^-11, exact in fp32); a convolution can take its input and its residual in it and write its output in
  * it (fmt bits below), which changes the data path (both operands staged by LDS-DMA, no split in the kernel), not the arithmetic. */
-enum { AMP_FMT_X_SPLIT = 1, AMP_FMT_Y_SPLIT = 2, AMP_FMT_RES_SPLIT = 4 };
+enum { AMP_FMT_X_SPLIT = 1, AMP_FMT_Y_SPLIT = 2, AMP_FMT_RES_SPLIT = 4, AMP_FMT_MASK_SPLIT = 8 };
 int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                         const float* res, float* y, int fmt);
 int amp_unsplit_rows(amp_ctx* ctx, const float* x_split, long long rows, int C, float* out);
@@ -161,7 +161,9 @@ int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[
                               const int* batch_idx, int R, int P, const float* dout, int B);
 int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C);   /* dcoarse += 2x2 sums */
 int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, int W, int C);           /* dx[::2, ::2] += dy */
-int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n);                                  /* g *= (act > 0) */
+int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n);
+/* The same with the activation in the split hi|lo' row format ([.., C] rows, C % 32 == 0). */
+int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n, int C);                                  /* g *= (act > 0) */
 int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx, size_t npix);
 int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate);
 /* torch.optim.SGD: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
