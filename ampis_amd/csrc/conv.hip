@@ -442,11 +442,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // v_cvt_pk_f16_f32 (hi), v_pk_mul (x 2^11), v_pk_fma (hi * -2^11 + o * 2^11: the exact difference, already scaled), v_cvt_pk (lo').
 // Same values as conv_epilogue_rows8, bit for bit: o - hi and the scaling by 2^11 are exact in fp32, so the fused form rounds once,
 // where the unfused one did not round at all.  Range check: s = fma(v, 0, s) stays 0 unless an accumulator is inf or NaN.
-// out_mode 0, split output, no mask; residual none or in the split format (res_mode 1: same row; 2: the coarser level's row).
+// out_mode 0, split output; residual none or in the split format (res_mode 1: same row; 2: the coarser level's row); ReLU mask
+// (training: the data gradient gated by the forward activation) none or in the split format.
 template <bool SPATIAL, bool CHECK>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[4][4], int lane, int mw0, int nw0) {
     const int l15 = lane & 15, lq = lane >> 4;
-    const bool has_res = a.res_mode != 0;
+    const bool has_res = a.res_mode != 0, has_mask = a.mask != nullptr;
     f32x2 sc[2][4], sh[2][4];
     size_t colb[2];
 #pragma unroll
@@ -474,13 +475,21 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
             const unsigned int ox = rem - oy * (unsigned int)a.Wo;
             rrow = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout;
         }
-        f16x8 rh[2], rl[2];
+        f16x8 rh[2], rl[2], mh[2], ml[2];
         if (has_res) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const char* rb = reinterpret_cast<const char*>(a.res + rrow) + colb[g];
                 rh[g] = *reinterpret_cast<const f16x8*>(rb);
                 rl[g] = *reinterpret_cast<const f16x8*>(rb + 64);
+            }
+        }
+        if (has_mask) {                                  // the gating activation (training), split rows indexed like y
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const char* mb = reinterpret_cast<const char*>(a.mask + yrow) + colb[g];
+                mh[g] = *reinterpret_cast<const f16x8*>(mb);
+                ml[g] = *reinterpret_cast<const f16x8*>(mb + 64);
             }
         }
 #pragma unroll
@@ -498,6 +507,11 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
                     o = o + (r1 + r2 * (1.0f / LO_SCALE));
                 }
                 if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
+                if (has_mask) {
+                    const f32x2 mk = f32x2{(float)mh[g][2 * p], (float)mh[g][2 * p + 1]} + f32x2{(float)ml[g][2 * p], (float)ml[g][2 * p + 1]} * (1.0f / LO_SCALE);
+                    o[0] = mk[0] > 0.f ? o[0] : 0.f;
+                    o[1] = mk[1] > 0.f ? o[1] : 0.f;
+                }
                 const f16x2 h = __builtin_convertvector(o, f16x2);
                 const f32x2 hf = {(float)h[0], (float)h[1]};
                 const f32x2 l = __builtin_elementwise_fma(hf, f32x2{-LO_SCALE, -LO_SCALE}, o * LO_SCALE);
@@ -1295,7 +1309,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
     if constexpr (BM == 128 && BN == 256 && EPI == 2) {
         if (a.out_mode == 3) { conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0); return; }
     }
-    if (a.y_split && !a.mask && a.out_mode == 0 && (a.res_mode == 0 || a.res_split) && a.direct_epi)
+    if (a.y_split && (!a.mask || a.mask_split) && a.out_mode == 0 && (a.res_mode == 0 || a.res_split) && a.direct_epi)
         conv_epilogue_direct<EPI == 2, true>(a, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
     else
         conv_epilogue_swapped<WTM, WTN, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);

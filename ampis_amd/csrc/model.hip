@@ -935,15 +935,15 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // weight gradient; bias = true: the bias gradient (column sums of dy) as well -- summed on the side by the AMP_CONV_F16X3 kernel from the
     // dy tiles it stages anyway, by a separate amp_colsum pass over dy on the fp32 MFMA
     const bool AS = m->acts_split;      // the trunk's saved activations are in the split row format
-    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc, bool bias = false, bool x_split = false) -> int {
+    auto wgrad = [&](const ConvW& cw, const float* x, int B_, int H_, int W_, int stride, int pad, const float* dy, bool acc, bool bias = false, int xfmt = 0) -> int {   // xfmt: 1 = x split, 2 = dy split and scaled by 2^16
         amp_conv_desc d;
         d.B = B_; d.H = H_; d.W = W_; d.Cin = cw.cin; d.Cout = cw.cout; d.KH = cw.kh; d.KW = cw.kw; d.stride = stride; d.pad = pad;
         d.relu = 0; d.res_mode = 0; d.out_mode = 0;
         AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
         static const bool no_fused_bias = getenv("AMP_NO_FUSED_BIAS") != nullptr;      // EXPERIMENT switch
-        const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias;
+        const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias && !(xfmt & 2);
         // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
-        AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, x_split ? 1 : 0, fused ? GB(cw) : nullptr, acc ? 1 : 0));
+        AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, xfmt, fused ? GB(cw) : nullptr, acc ? 1 : 0));
         if (bias && !fused) {
             const int Ho_ = (H_ + 2 * pad - cw.kh) / stride + 1, Wo_ = (W_ + 2 * pad - cw.kw) / stride + 1;
             return bgrad(cw, dy, (long long)B_ * Ho_ * Wo_, acc);
@@ -960,6 +960,19 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         // data gradient on the context's arithmetic; AMP_CONV_F16X3 splits dy * 2^16 (gradients of 1e-9..1e-4 would sit in the f16
         // subnormals)
         return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
+    };
+    // The backbone's chain on SCALED SPLIT gradients (GS): a gradient tensor is kept as the split rows of d * 2^16, so its data-gradient
+    // convolution stages both operands by LDS-DMA on the ring kernel (no split, no scaling: the scale rides through the linear chain),
+    // residual and ReLU mask come in the split format, and the weight-gradient kernel passes the halves through (xfmt 3).
+    static const bool no_gs = getenv("AMP_NO_SPLIT_GRADS") != nullptr;      // EXPERIMENT switch
+    const bool GS = AS && !no_gs && ctx->conv_mode == AMP_CONV_F16X3;
+    auto dgrad_s = [&](const ConvW& cw, const float* dy_s, int B_, int Hy, int Wy, int fwd_pad, const float* res_s, const float* mask_s, float* dx_s) -> int {
+        AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
+        AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
+        amp_conv_desc d;
+        d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
+        d.relu = 0; d.res_mode = res_s ? 1 : 0; d.out_mode = 0;
+        return amp::conv_run(ctx, &d, 1, dy_s, wt_scratch, nullptr, 0, nullptr, nullptr, res_s, mask_s, dx_s, 0, 1 | 2 | (res_s ? 4 : 0) | (mask_s ? 8 : 0));
     };
 
     // ---- gradient buffers of the FPN outputs p2..p6 ----
@@ -1085,6 +1098,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         int hh = ((H + 31) / 32 * 32) / 4, ww = ((W + 31) / 32 * 32) / 4;
         for (int s_ = 1; s_ < 4; ++s_) {
             hh = (hh - 1) / 2 + 1; ww = (ww - 1) / 2 + 1;
+            { AMP_ALLOC(r0, float, (size_t)B * hh * ww * kOut[s_]); (void)r0; }     // the stage's entry gradient as a scaled split tensor
             for (int b_ = 0; b_ < m->nblk[s_]; ++b_) {
                 AMP_ALLOC(r1, float, (size_t)B * hh * ww * m->mid[s_]);
                 AMP_ALLOC(r2, float, (size_t)B * hh * ww * m->mid[s_]);
@@ -1104,20 +1118,56 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             dcur_masked = false;
         }
         const size_t out_elems = (size_t)B * ba.oh * ba.ow * ba.cout;
-        // d(pre-activation) = d(out) * (out > 0); inside a stage the previous iteration's input-gradient conv has applied it already
-        if (!dcur_masked) AMP_TRY(AS ? amp_relu_mask_split(ctx, dcur, ba.out, out_elems, ba.cout) : amp_relu_mask(ctx, dcur, ba.out, out_elems));
-        dcur_masked = false;
         const ConvW& c3 = CONV((ba.key + ".conv3").c_str());
         const ConvW& c2 = CONV((ba.key + ".conv2").c_str());
         const ConvW& c1 = CONV((ba.key + ".conv1").c_str());
         AMP_ALLOC(d_t2, float, (size_t)B * ba.oh * ba.ow * ba.mid);
         AMP_ALLOC(d_t1, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+        const bool need_dx = !(ba.stage == 1 && ba.has_sc);   // the input of res3.0 is the frozen res2 output
+        if (GS) {
+            // every gradient of the chain below is a scaled split tensor (see dgrad_s)
+            if (last_of_stage) {
+                AMP_ALLOC(dcur_s, float, out_elems);
+                AMP_TRY(amp_relu_mask_to_split(ctx, dcur, ba.out, dcur_s, out_elems, ba.cout, 16));
+                dcur = dcur_s;
+            } else if (!dcur_masked) {
+                amp::set_error("backward: a block whose input is not the previous block's output is not expected inside a stage");
+                return AMP_ERR_STATE;
+            }
+            dcur_masked = false;
+            AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false, false, 3));
+            AMP_TRY(dgrad_s(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2));
+            AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false, false, 3));
+            AMP_TRY(dgrad_s(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1));
+            AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false, false, 3));
+            if (ba.has_sc) {
+                const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
+                AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false, false, 3));
+                if (need_dx) {
+                    AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                    AMP_ALLOC(tmp_in, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                    AMP_TRY(dgrad_s(cs, dcur, B, ba.oh, ba.ow, 0, nullptr, nullptr, tmp_sc));
+                    AMP_TRY(dgrad_s(c1, d_t1, B, ba.oh, ba.ow, 0, tmp_sc, nullptr, tmp_in));
+                    float* dprev = d_res[ba.stage - 1];             // fp32: already holds the FPN lateral's share
+                    if (ba.stride == 2) AMP_TRY(amp_subsample2_bwd_split(ctx, tmp_in, dprev, B, ba.in_h, ba.in_w, ba.cin, 16));
+                    else { amp::set_error("backward: stride-1 projection block is not expected here"); return AMP_ERR_STATE; }
+                }
+            } else {
+                AMP_ALLOC(d_in, float, out_elems);
+                const bool fuse = bi > 0 && m->blocks[bi - 1].out == ba.x_in;
+                AMP_TRY(dgrad_s(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in));
+                dcur = d_in;
+                dcur_masked = fuse;
+            }
+        } else {
+        // d(pre-activation) = d(out) * (out > 0); inside a stage the previous iteration's input-gradient conv has applied it already
+        if (!dcur_masked) AMP_TRY(AS ? amp_relu_mask_split(ctx, dcur, ba.out, out_elems, ba.cout) : amp_relu_mask(ctx, dcur, ba.out, out_elems));
+        dcur_masked = false;
         AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false, false, AS));
         AMP_TRY(dgrad(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2, AS));
         AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false, false, AS));
         AMP_TRY(dgrad(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1, AS));
         AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false, false, AS));
-        const bool need_dx = !(ba.stage == 1 && ba.has_sc);   // the input of res3.0 is the frozen res2 output
         if (ba.has_sc) {
             const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
             AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false, false, AS));
@@ -1137,6 +1187,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in, AS));
             dcur = d_in;
             dcur_masked = fuse;
+        }
         }
         if (bi == 0 || m->blocks[bi - 1].stage != ba.stage) AMP_TRY(issue_bucket(m, 7 - ba.stage));   // res5 -> 4, res4 -> 5, res3 -> 6
     }

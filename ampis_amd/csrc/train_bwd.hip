@@ -343,6 +343,57 @@ __global__ void relu_mask_split_kernel(float* __restrict__ g, const float* __res
     }
 }
 
+// Scaled split gradients (the backbone's backward pass on the ring kernel, model.hip): a gradient tensor d is kept as the split rows of
+// d * scale (scale = 2^16: loss gradients of 1e-9..1e-4 would sit in the f16 subnormals), so that data-gradient convolutions stage it by
+// LDS-DMA like an activation and the weight-gradient kernel passes its halves through.
+// out = split(scale * (act > 0 ? g : 0)): the entry of a stage's chain (g fp32 from the FPN lateral, act = the stage output, split rows)
+__global__ void relu_mask_to_split_kernel(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out, size_t n4, int C4, float scale) {
+    const f32x4* gg = reinterpret_cast<const f32x4*>(g);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const size_t off = (size_t)(c >> 5) * 128 + (size_t)(c & 31) * 2;
+        const char* mb = reinterpret_cast<const char*>(act + row * (size_t)C4 * 4) + off;
+        const rm_f16x4 mh = *reinterpret_cast<const rm_f16x4*>(mb);
+        const rm_f16x4 ml = *reinterpret_cast<const rm_f16x4*>(mb + 64);
+        const f32x4 v = gg[i];
+        rm_f16x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x = ((float)mh[q] + (float)ml[q] * (1.0f / 2048.0f)) > 0.f ? v[q] * scale : 0.f;
+            const _Float16 h = (_Float16)x;
+            hi[q] = h;
+            lo[q] = (_Float16)((x - (float)h) * 2048.0f);
+        }
+        char* ob = reinterpret_cast<char*>(out + row * (size_t)C4 * 4) + off;
+        *reinterpret_cast<rm_f16x4*>(ob) = hi;
+        *reinterpret_cast<rm_f16x4*>(ob + 64) = lo;
+    }
+}
+
+// d_x[b,2y,2x,:] += unscale(d_y[b,y,x,:]) with d_y in scaled split rows (the exit of a stage's chain: stride-2 first block)
+__global__ void subsample2_bwd_split_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C4, int Ho, int Wo, float inv_scale) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    f32x4* o = reinterpret_cast<f32x4*>(dx);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t t = i / C4;
+        const size_t row = t;
+        const int x = (int)(t % Wo); t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int c = c4 * 4;
+        const char* sb = reinterpret_cast<const char*>(dy + row * (size_t)C4 * 4) + (size_t)(c >> 5) * 128 + (size_t)(c & 31) * 2;
+        const rm_f16x4 sh = *reinterpret_cast<const rm_f16x4*>(sb);
+        const rm_f16x4 sl = *reinterpret_cast<const rm_f16x4*>(sb + 64);
+        const size_t d = ((size_t)(b * H + 2 * y) * W + 2 * x) * C4 + c4;
+        f32x4 v = o[d];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __fadd_rn(v[q], ((float)sh[q] + (float)sl[q] * (1.0f / 2048.0f)) * inv_scale);
+        o[d] = v;
+    }
+}
+
 // dx[p][c] = (sum_k dl[p][k] * w[k][c]) * (act[p][c] > 0)     (mask predictor 1x1 conv, K <= 8 classes padded to ld)
 __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K, const float* __restrict__ w, int C,
                                      const float* __restrict__ act, float* __restrict__ dx, size_t npix) {
@@ -483,6 +534,22 @@ int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n) {
 int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n, int C) {
     AMP_REQUIRE(ctx && g && act_split && C > 0 && C % 32 == 0 && n % (size_t)C == 0, "amp_relu_mask_split: bad argument (C %% 32 != 0?)");
     hipLaunchKernelGGL(relu_mask_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ctx->stream, g, act_split, n / 4, C / 4);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_relu_mask_to_split(amp_ctx* ctx, const float* g, const float* act_split, float* out_split, size_t n, int C, int shift) {
+    AMP_REQUIRE(ctx && g && act_split && out_split && C > 0 && C % 32 == 0 && n % (size_t)C == 0 && shift >= 0 && shift <= 24, "amp_relu_mask_to_split: bad argument");
+    hipLaunchKernelGGL(relu_mask_to_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, ctx->stream, g, act_split, out_split, n / 4, C / 4, ldexpf(1.0f, shift));
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int B, int H, int W, int C, int shift) {
+    AMP_REQUIRE(ctx && dy_split && dx && C % 32 == 0 && shift >= 0 && shift <= 24, "amp_subsample2_bwd_split: bad argument");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(subsample2_bwd_split_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, ctx->stream, dy_split, dx, B, H, W, C / 4, Ho, Wo,
+                       ldexpf(1.0f, -shift));
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -198,7 +198,9 @@ constexpr int WOP = 2 * wreg(128);          // bytes of a 128-column operand til
 // XS = true: X is stored in the split hi|lo' row format (the trunk's native activation format; same row offsets as fp32): a lane
 // fetches the 4 B of hi halves and the 4 B of lo' halves of its channel pair and hands them to the tile as they are -- no split
 // arithmetic for that operand (the halves are what the in-kernel split of the fp32 value would produce: same MFMA inputs, same sums).
-template <int SC, bool XS = false, bool BIAS = false>   // SC 0: no operand scaling, 1: dY * scale, 2: X * scale; BIAS: column sums of dY on the side
+// PS = true: dY is stored in the split row format too, ALREADY multiplied by `scale` (the scaled loss gradients a data-gradient convolution
+// on the ring kernel writes): passed through like XS; the sums still get out_scale.
+template <int SC, bool XS = false, bool BIAS = false, bool PS = false>   // SC 0: no operand scaling, 1: dY * scale, 2: X * scale; BIAS: column sums of dY on the side
 __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, const float scale, const float out_scale, int* range_flag) {
     constexpr int REG = wreg(128);
     constexpr int STAGE = 2 * WOP;
@@ -226,7 +228,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
 
     const int pcol = 2 * lane;                     // tile column pair of this lane
-    const unsigned int p_voff = (n0 + pcol < a.N) ? (unsigned int)((n0 + pcol) * 4) : OOB;   // N even: a pair is all-in or all-out
+    const int pc = n0 + pcol;
+    const unsigned int p_voff = (pc < a.N) ? (PS ? (unsigned int)((pc >> 5) * 128 + (pc & 31) * 2) : (unsigned int)(pc * 4)) : OOB;   // N even: a pair is all-in or all-out
     const int qc = c0 + 2 * lane;                  // this lane's channel pair of X
     const unsigned int q_lane = XS ? (unsigned int)((qc >> 5) * 128 + (qc & 31) * 2) : (unsigned int)(qc * 4);
     const unsigned int* tab = a.rowtab + (size_t)tap * a.Mpad + m_begin + 8 * mg;   // wave-uniform: scalar loads
@@ -240,8 +243,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     auto fetch = [&](int step) {
         const int row0 = m_begin + step * BKW + 8 * mg;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            rp[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);   // past the tensor: zero fill
+        for (int r = 0; r < 8; ++r) {
+            if (PS) {
+                rp[r][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);
+                rp[r][1] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_dy, (int)p_voff + 64, (row0 + r) * a.N * 4, 0);
+            } else {
+                rp[r] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_dy, (int)p_voff, (row0 + r) * a.N * 4, 0);   // past the tensor: zero fill
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (XS) {
@@ -270,12 +279,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
             f16x8 ph, pl;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const unsigned int pu = rp[r][q];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
-                float x = __builtin_bit_cast(float, pu);
-                if (SC == 1) x *= scale;
-                const _Float16 h = (_Float16)x;
-                ph[r] = h;
-                pl[r] = (_Float16)((x - (float)h) * LO_SCALE);
+                if (PS) {
+                    const unsigned int hu = rp[r][0], lu = rp[r][1];
+                    ph[r] = __builtin_bit_cast(_Float16, (unsigned short)(q ? (hu >> 16) : (hu & 0xffffu)));
+                    pl[r] = __builtin_bit_cast(_Float16, (unsigned short)(q ? (lu >> 16) : (lu & 0xffffu)));
+                } else {
+                    const unsigned int pu = rp[r][q];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                    float x = __builtin_bit_cast(float, pu);
+                    if (SC == 1) x *= scale;
+                    const _Float16 h = (_Float16)x;
+                    ph[r] = h;
+                    pl[r] = (_Float16)((x - (float)h) * LO_SCALE);
+                }
             }
             *reinterpret_cast<f16x8*>(P + q * REG) = ph;
             *reinterpret_cast<f16x8*>(P + q * REG + 64) = pl;
@@ -390,11 +405,15 @@ void launch_wgrad_f16x3_v(const WgradArgs& a, int blocks, int dy_shift, int x_sh
     else if (x_shift && !XS) hipLaunchKernelGGL((wgrad_f16x3_kernel<2, false, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
     else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
 }
-void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag, int x_split = 0) {
+// fmt: bit 0 = x in the split row format, bit 1 = dy in the split row format AND already multiplied by 2^dy_shift
+void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag, int fmt = 0) {
     const int sh = dy_shift ? dy_shift : x_shift;
     const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);     // exact powers of two
     const bool bias = a.bias_partial != nullptr;
-    if (x_split) { if (bias) launch_wgrad_f16x3_v<true, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<true, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
+    if (fmt & 2) {          // (no bias sums from a scaled split dy: the FrozenBN convolutions that use it have none)
+        if (fmt & 1) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, true, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+        else hipLaunchKernelGGL((wgrad_f16x3_kernel<1, false, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    } else if (fmt & 1) { if (bias) launch_wgrad_f16x3_v<true, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<true, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
     else { if (bias) launch_wgrad_f16x3_v<false, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<false, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
 }
 
@@ -562,8 +581,11 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
                          float* grad, int accumulate, int dy_shift, int x_shift, int x_split, float* bias_grad, int bias_accumulate) {
     AMP_REQUIRE(ctx && d && x && dy && scratch && grad, "amp_conv2d_wgrad: null argument");
     AMP_REQUIRE(!bias_grad || ctx->conv_mode == AMP_CONV_F16X3, "amp_conv2d_wgrad_fmt: the fused bias gradient needs AMP_CONV_F16X3 (use amp_colsum)");
-    AMP_REQUIRE(!x_split || (ctx->conv_mode == AMP_CONV_F16X3 && x_shift == 0 && d->Cin % 32 == 0),
+    AMP_REQUIRE(x_split >= 0 && x_split < 4, "amp_conv2d_wgrad_fmt: x_split is a set of bits: 1 = x split, 2 = dy split and pre-scaled by 2^dy_shift");
+    AMP_REQUIRE(!(x_split & 1) || (ctx->conv_mode == AMP_CONV_F16X3 && x_shift == 0 && d->Cin % 32 == 0),
                 "amp_conv2d_wgrad_fmt: a split-format x needs AMP_CONV_F16X3, no x shift and Cin %% 32 == 0");
+    AMP_REQUIRE(!(x_split & 2) || (ctx->conv_mode == AMP_CONV_F16X3 && x_shift == 0 && d->Cout % 32 == 0 && !bias_grad),
+                "amp_conv2d_wgrad_fmt: a split-format dy needs AMP_CONV_F16X3, no x shift, Cout %% 32 == 0 and no fused bias gradient");
     AMP_REQUIRE(dy_shift >= 0 && dy_shift <= 24 && x_shift >= 0 && x_shift <= 24 && (dy_shift == 0 || x_shift == 0),
                 "amp_conv2d_wgrad: shifts must be in [0, 24] and at most one of them non-zero");
     AMP_REQUIRE(d->Cin % TC == 0, "amp_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, TC);

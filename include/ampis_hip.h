@@ -144,6 +144,8 @@ int amp_conv2d_wgrad(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const
 int amp_conv2d_wgrad_scaled(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
                             float* grad, int accumulate, int dy_shift, int x_shift);
 /* The same with x in the split hi|lo' row format (AMP_FMT_X_SPLIT; written by amp_conv2d_nhwc_fmt / the native trunk): x_split = 1;
+ * x_split & 2: dy is in that format as well and already multiplied by 2^dy_shift (what a data-gradient convolution with AMP_FMT_Y_SPLIT
+ * on scaled split gradients writes);
  * bias_grad != NULL (AMP_CONV_F16X3 only): bias_grad[n] (= or +=) sum over the pixels of dy[.][n], summed on the side by the MFMA kernel
  * from the dy tiles it stages anyway (replaces a separate amp_colsum pass over dy). */
 int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* dy, const float* scale, float* scratch,
@@ -163,7 +165,11 @@ int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, i
 int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, int W, int C);           /* dx[::2, ::2] += dy */
 int amp_relu_mask(amp_ctx* ctx, float* g, const float* act, size_t n);
 /* The same with the activation in the split hi|lo' row format ([.., C] rows, C % 32 == 0). */
-int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n, int C);                                  /* g *= (act > 0) */
+int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n, int C);
+/* Scaled split gradients (the backbone's backward pass on the ring kernel): out = split(2^shift * (act > 0 ? g : 0)), and the
+ * stride-2 scatter-add back into an fp32 gradient: dx[b,2y,2x,:] += 2^-shift * decode(dy_split[b,y,x,:]). */
+int amp_relu_mask_to_split(amp_ctx* ctx, const float* g, const float* act_split, float* out_split, size_t n, int C, int shift);
+int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int B, int H, int W, int C, int shift);                                  /* g *= (act > 0) */
 int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx, size_t npix);
 int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate);
 /* torch.optim.SGD: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
