@@ -927,6 +927,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
     AMP_ALLOC(wt_scratch, float, WT_SCRATCH);
     AMP_ALLOC(cs_scratch, float, (size_t)4 << 20);   // ceil(M/512) * N floats of the largest bias-gradient reduction
+    const size_t DYS_SCRATCH = (size_t)B * T.fh[0] * T.fw[0] * 256;      // floats: the largest dy converted to a scaled split operand (p2 level)
+    AMP_ALLOC(dys_scratch, float, DYS_SCRATCH);
+    const bool GSW = m->acts_split && getenv("AMP_NO_SPLIT_GRADS") == nullptr && ctx->conv_mode == AMP_CONV_F16X3;
     auto GW = [&](const ConvW& cw) { return m->garena + (cw.w - m->parena); };
     auto GB = [&](const ConvW& cw) { return m->garena + (cw.shift - m->parena); };
     auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
@@ -942,6 +945,15 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
         static const bool no_fused_bias = getenv("AMP_NO_FUSED_BIAS") != nullptr;      // EXPERIMENT switch
         const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias && !(xfmt & 2);
+        // a big biased layer whose activation is already split (FPN output / RPN conv at p2, p3; the mask head): one pass over dy gives the bias
+        // gradient AND dy * 2^16 in the split format, and the weight gradient runs on wgrad_split_kernel (+35-45 % on these shapes)
+        static const bool no_conv = getenv("AMP_NO_DY_CONVERT") != nullptr;      // EXPERIMENT switch
+        const long long Mo = (long long)B_ * ((H_ + 2 * pad - cw.kh) / stride + 1) * ((W_ + 2 * pad - cw.kw) / stride + 1);
+        if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && Mo >= 200000 &&
+            (size_t)Mo * cw.cout <= DYS_SCRATCH) {
+            AMP_TRY(amp_colsum_split(ctx, dy, (int)Mo, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0, dys_scratch, 16));
+            return amp_conv2d_wgrad_fmt(ctx, &d, x, dys_scratch, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, 3, nullptr, 0);
+        }
         // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
         AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, x, dy, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, xfmt, fused ? GB(cw) : nullptr, acc ? 1 : 0));
         if (bias && !fused) {

@@ -399,6 +399,230 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
     if (bad && range_flag) *range_flag = 1;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad_split_kernel: the same GEMM when BOTH operands are stored in the split hi|lo' row format (the backbone of a training step:
+// activations of the native trunk, scaled split gradients).  Nothing is split and nothing is transposed in registers:
+//   * a K-step is 32 pixels; the 32 x 128-channel slab of dY rows (512 B per pixel) and the 32 x 256-channel slab of X rows (1 KiB per
+//     pixel, through the [tap][pixel] offset table) are copied AS THEY ARE into LDS by LDS-DMA (6 requests per wave and step, zero fill
+//     beyond the tensor / outside the image), through a ring of three 48-KiB tiles with counted vmcnt and bare barriers, and the two
+//     halves of the workgroup ping-pong between loading and multiplying -- conv_split_kernel's loop (conv.hip);
+//   * the MFMA wants 8 consecutive PIXELS per lane and channel, the rows hold consecutive CHANNELS per pixel: gfx950's transposing LDS read
+//     does the rest -- ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block of 16-bit elements, so
+//     two of them are the f16x8 operand of v_mfma_f32_16x16x32_f16 (probed on the GPU: tools/_probe/tr_probe.hip);
+//   * 16-B chunk j of row R lives at position j ^ (2 s(R)), s(R) = (R & 3) | ((R >> 3) & 1) << 2 (applied to the DMA's SOURCE chunk):
+//     the 8 row pieces (2 groups x 4 rows x 32 B) a half-wave reads at once then cover the 64 banks exactly once.
+// X is the MFMA's A operand (rows c), dY its B operand (columns n): a lane ends with 4 consecutive (tap, c) of one n -- 16-B stores
+// into the slab [split][n][K'].  128 (n) x 256 (tap, c) tile, 8 waves of 64 x 64; K' tiles of 256 may straddle two taps (Cin = 128).
+constexpr int WS_TN = 128, WS_TC = 256;
+constexpr int WS_P = 32 * 512, WS_Q = 32 * 1024, WS_TILE = WS_P + WS_Q;       // bytes
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16x8 tr_pair(const unsigned char* p) {          // pixels 8 lq .. 8 lq + 7 of this lane's channel
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 1024));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ f16x8 tr_pair_p(const unsigned char* p) {        // the same on the 512-B rows of the dY tile
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 512));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
+__global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, const float out_scale, int* range_flag) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * WS_TILE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;       // wave tile: 64 n (wm) x 64 (tap, c) (wn)
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int bid = amp::xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_c = bid % a.ntc; bid /= a.ntc;
+    const int tile_n = bid % a.ntn; bid /= a.ntn;
+    const int split = bid;
+    const int n0 = tile_n * WS_TN;
+    const int kp0 = tile_c * WS_TC;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const int nsteps = (m_end > m_begin) ? (m_end - m_begin + BKW - 1) / BKW : 0;
+
+    const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    auto swz = [](int R) { return ((R & 3) | (((R >> 3) & 1) << 2)) << 1; };
+
+    // ---- staging: dY, 2 requests per wave and step, each 2 rows x 512 B; lane -> (row, chunk position), source chunk swizzled ----
+    unsigned int p_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int R = 2 * (2 * wave + i) + (lane >> 5);
+        const int src = (lane & 31) ^ swz(R);
+        // the tile's 128 channels are 4 groups of 128 B, contiguous in a split row; the row offset (pixel * N * 4) is added per step
+        p_voff[i] = (n0 < a.N) ? (unsigned int)((size_t)(m_begin + R) * a.N * 4 + (size_t)(n0 >> 5) * 128 + 16 * src) : OOB;
+    }
+    const unsigned int p_step = (unsigned int)(BKW * a.N * 4);
+    // ---- X: 4 requests per wave and step, one row of 1 KiB each; the 256 (tap, c) of the tile are one run of a tap's channels, or (Cin =
+    //      128) two runs of two taps; a lane's half decides which ----
+    const int tap0 = kp0 / a.Cin, c0 = kp0 - tap0 * a.Cin;
+    const bool two = a.Cin < WS_TC;                                 // Cin == 128: positions 0..31 -> tap0, 32..63 -> tap0 + 1
+    const int ntaps = a.KH * a.KW;
+    unsigned int q_lane[4];
+    bool q_second[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int R = 4 * wave + i;
+        const int src = lane ^ swz(R);
+        q_second[i] = two && src >= 32;
+        q_lane[i] = two ? (unsigned int)(16 * (src & 31)) : (unsigned int)(c0 * 4 + 16 * src);
+    }
+    // the row offsets are wave-uniform: read through the scalar unit (constant address space), one K-step ahead of their use
+    typedef const __attribute__((address_space(4))) unsigned int* ctab_t;
+    ctab_t tab0 = (ctab_t)(a.rowtab + (size_t)min(tap0, ntaps - 1) * a.Mpad + m_begin + 4 * wave);
+    ctab_t tab1 = (ctab_t)(a.rowtab + (size_t)min(tap0 + 1, ntaps - 1) * a.Mpad + m_begin + 4 * wave);
+    const bool tap0_ok = kp0 < a.Kp, tap1_ok = two && tap0 + 1 < ntaps;
+    unsigned int qt0[4], qt1[4];
+    auto load_tab = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qt0[i] = tap0_ok ? tab0[st * BKW + i] : OOB;
+            qt1[i] = tap1_ok ? tab1[st * BKW + i] : OOB;
+        }
+    };
+
+    int staged = 0;                                                  // next K-step to stage
+    auto stage = [&](int buf) {
+        unsigned char* P = lds + buf * WS_TILE;
+        unsigned char* Q = P + WS_P;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_dy, (__attribute__((address_space(3))) void*)(P + (2 * wave + i) * 1024), 16,
+                                                     (int)p_voff[i], staged * (int)p_step, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int row = q_second[i] ? qt1[i] : qt0[i];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(Q + (4 * wave + i) * 1024), 16,
+                                                     (int)(row + q_lane[i]), 0, 0, 0);      // 0x80000000 + lane part: zero fill
+        }
+        ++staged;
+        if (staged < nsteps) load_tab(staged);                       // for the next call
+    };
+
+    // ---- fragment addresses: row R = 8 lq + q (+ 4 for the second read); lane 4 q + p supplies row q, 8-B piece p of the block's 32 B ----
+    const int fq = (lane >> 2) & 3, fp = lane & 3;
+    const int fR = 8 * lq + fq;
+    const int fs = swz(fR);                                          // (the same for row fR + 4)
+    int offP[4][2], offQ[4][2];                                     // [block][hi / lo] byte offsets inside a tile
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int chP = 8 * (2 * wm + (b >> 1)) + 2 * (b & 1) + 4 * h;          // chunk of the block's 32 B in a 512-B dY row
+            const int chQ = 8 * (2 * wn + (b >> 1)) + 2 * (b & 1) + 4 * h;          // ... in a 1-KiB X row
+            offP[b][h] = fR * 512 + 16 * ((chP + (fp >> 1)) ^ fs) + 8 * (fp & 1);
+            offQ[b][h] = WS_P + fR * 1024 + 16 * ((chQ + (fp >> 1)) ^ fs) + 8 * (fp & 1);
+        }
+
+    f32x4w acc[4][4], acx[4][4];                                    // [c block][n block]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    f16x8 xh[4], xl[4], yh[4], yl[4];
+
+    auto load = [&](int buf) {
+        const unsigned char* T = lds + buf * WS_TILE;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            xh[b] = tr_pair(T + offQ[b][0]);
+            xl[b] = tr_pair(T + offQ[b][1]);
+            yh[b] = tr_pair_p(T + offP[b][0]);
+            yl[b] = tr_pair_p(T + offP[b][1]);
+        }
+    };
+    auto mfma = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[i], yh[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acx[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[i], yl[j], acx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[i], yh[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nsteps > 0) {
+        load_tab(0);
+        stage(0);
+        if (nsteps > 1) stage(1);
+        int cur = 0, nxt = 2;
+        auto open_step = [&](int step) {
+            if (step + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0070 | 6);     // all but the youngest tile's 6 requests; lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        auto advance = [&]() { cur = (cur == 2) ? 0 : cur + 1; nxt = (nxt == 2) ? 0 : nxt + 1; };
+        if (wave < 4) {
+            for (int step = 0; step < nsteps; ++step) {
+                open_step(step);
+                load(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + 2 < nsteps) stage(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+                mfma();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+            }
+        } else {
+            for (int step = 0; step < nsteps; ++step) {
+                open_step(step);
+                __builtin_amdgcn_s_setprio(1);
+                if (step > 0) mfma();
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                load(cur);
+                __builtin_amdgcn_sched_barrier(0);
+                if (step + 2 < nsteps) stage(nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+            }
+            mfma();
+        }
+    }
+    // ---- slab [split][n][K']: lane = (n = l15 of block j, 4 consecutive (tap, c) = 4 lq .. of block i) ----
+    float* out = a.partial + (size_t)split * a.N * a.Kp;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kp = kp0 + wn * 64 + i * 16 + 4 * lq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wm * 64 + j * 16 + l15;
+            f32x4w v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                bad |= !(fabsf(v[e]) <= 3.0e38f);
+                v[e] *= out_scale;
+            }
+            if (n < a.N && kp < a.Kp) *reinterpret_cast<f32x4w*>(out + (size_t)n * a.Kp + kp) = v;       // K' % 4 == 0
+        }
+    }
+    if (bad && range_flag) *range_flag = 1;
+}
+
 template <bool XS, bool BIAS>
 void launch_wgrad_f16x3_v(const WgradArgs& a, int blocks, int dy_shift, int x_shift, float sc, float osc, hipStream_t st, int* flag) {
     if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
@@ -457,7 +681,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
 // 16-byte column group and every (256 / N4)-th row, so a wave reads whole 1 KiB row segments; row lanes are combined through LDS.
 constexpr int COLSUM_ROWS = 512;
 typedef float cs_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int M, int N4, float* __restrict__ partial) {
+// split_out != nullptr: the pass also leaves dY * scale in the split hi|lo' row format (the scaled split gradient wgrad_split_kernel
+// stages by LDS-DMA): one read of dY serves the bias gradient and the operand conversion.
+typedef _Float16 cs_h4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ dy, int M, int N4, float* __restrict__ partial,
+                                                             float* __restrict__ split_out, float scale) {
     __shared__ cs_f4 red[256];
     const int tid = threadIdx.x;
     const int cols = min(N4, 256);               // column groups handled per sweep
@@ -473,6 +701,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                 const cs_f4 v = src[(size_t)r * N4 + c];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = __fadd_rn(acc[q], v[q]);
+                if (split_out) {
+                    cs_h4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = v[q] * scale;
+                        const _Float16 h = (_Float16)x;
+                        hi[q] = h;
+                        lo[q] = (_Float16)((x - (float)h) * LO_SCALE);
+                    }
+                    const int ch = 4 * c;
+                    char* ob = reinterpret_cast<char*>(split_out + (size_t)r * N4 * 4) + (size_t)(ch >> 5) * 128 + (size_t)(ch & 31) * 2;
+                    *reinterpret_cast<cs_h4*>(ob) = hi;
+                    *reinterpret_cast<cs_h4*>(ob + 64) = lo;
+                }
             }
         __syncthreads();
         red[tid] = acc;
@@ -551,6 +793,19 @@ int pick_nsplit(long long M, int tiles) {
     }
     return best_s;
 }
+// the same for wgrad_split_kernel: 128 x 256 tiles, one 512-thread workgroup per CU (rounds of 256), ~10 steps of prologue / epilogue
+bool ring_shape(int N, int Cin, int Kp) { return N % WS_TN == 0 && Cin % 128 == 0 && Kp >= WS_TC; }
+int pick_nsplit_ring(long long M, int tiles) {
+    const int smax = (int)std::max(1LL, std::min(256LL, M / 256));
+    long long best = -1;
+    int best_s = 1;
+    for (int s = 1; s <= smax; ++s) {
+        const long long steps = amp::cdiv((int)((M + s - 1) / s), BKW);
+        const long long cost = (long long)amp::cdiv(tiles * s, 256) * (steps + 10);
+        if (best < 0 || cost < best) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
 }  // namespace
 
 extern "C" {
@@ -562,7 +817,8 @@ size_t amp_conv_wgrad_scratch_floats(const amp_conv_desc* d) {
     const long long M = (long long)d->B * Ho * Wo;
     const int Kp = d->KH * d->KW * d->Cin;
     const int tiles = amp::cdiv(d->Cout, TN) * amp::cdiv(Kp, TC);
-    const int nsplit = pick_nsplit(M, tiles);
+    int nsplit = pick_nsplit(M, tiles);
+    if (ring_shape(d->Cout, d->Cin, Kp)) nsplit = std::max(nsplit, pick_nsplit_ring(M, (d->Cout / WS_TN) * amp::cdiv(Kp, WS_TC)));
     const long long Mpad = (M + BKW - 1) / BKW * BKW;
     return (size_t)nsplit * d->Cout * Kp + (size_t)d->KH * d->KW * Mpad + (size_t)nsplit * d->Cout;   // partial slabs + the row table (4-byte entries) + bias slices
 }
@@ -611,7 +867,10 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
     set_fastdiv((unsigned int)(a.Ho * a.Wo), &a.div_howo_mul, &a.div_howo_shr);
     set_fastdiv((unsigned int)a.Wo, &a.div_wo_mul, &a.div_wo_shr);
     a.Mpad = amp::cdiv(a.M, BKW) * BKW;
-    unsigned int* rowtab = reinterpret_cast<unsigned int*>(scratch + (size_t)a.nsplit * a.N * a.Kp);
+    // scratch layout (amp_conv_wgrad_scratch_floats): slabs of the larger of the two kernels' slice counts, the row table, the bias slices
+    int nsplit_layout = a.nsplit;
+    if (ring_shape(a.N, a.Cin, a.Kp)) nsplit_layout = std::max(nsplit_layout, pick_nsplit_ring(M, (a.N / WS_TN) * amp::cdiv(a.Kp, WS_TC)));
+    unsigned int* rowtab = reinterpret_cast<unsigned int*>(scratch + (size_t)nsplit_layout * a.N * a.Kp);
     a.rowtab = rowtab;
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     a.bias_partial = bias_grad ? reinterpret_cast<float*>(rowtab + tab_n) : nullptr;
@@ -627,7 +886,19 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
             ctx->prof_truncated = true;
         }
     }
-    if (ctx->conv_mode == AMP_CONV_F16X3) {
+    static const bool ring_on = getenv("AMP_NO_WGRAD_RING") == nullptr;      // EXPERIMENT switch
+    if (ctx->conv_mode == AMP_CONV_F16X3 && ring_on && (x_split & 3) == 3 && ring_shape(a.N, a.Cin, a.Kp)) {
+        // both operands in the split row format: LDS-DMA ring + transposing reads (wgrad_split_kernel), 128 x 256 tiles.  The slab count
+        // never exceeds the one the scratch was sized for.
+        WgradArgs r = a;
+        r.ntn = a.N / WS_TN;
+        r.ntc = amp::cdiv(a.Kp, WS_TC);
+        const int rtiles = r.ntn * r.ntc;
+        r.nsplit = pick_nsplit_ring(M, rtiles);      // (amp_conv_wgrad_scratch_floats reserves the larger of the two slab counts)
+        r.rows_per_split = amp::cdiv(amp::cdiv(r.M, r.nsplit), BKW) * BKW;
+        hipLaunchKernelGGL(wgrad_split_kernel, dim3(rtiles * r.nsplit), dim3(512), 0, ctx->stream, r, ldexpf(1.0f, -dy_shift), ctx->d_conv_flag);
+        a.nsplit = r.nsplit;                       // the reduce below adds this many slabs
+    } else if (ctx->conv_mode == AMP_CONV_F16X3) {
         launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag, x_split);   // the fp32 kernel needs no shift
     } else {
         hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
@@ -644,7 +915,18 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate) {
     AMP_REQUIRE(ctx && dy && scratch && out && M >= 0 && N > 0 && N % 4 == 0, "amp_colsum: bad argument (N %% 4 != 0?)");
     const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N / 4, scratch);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N / 4, scratch, (float*)nullptr, 1.0f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, scratch, parts, N, out, accumulate);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+/* amp_colsum that also leaves dy * 2^shift in the split row format (N % 32 == 0): one pass over dy for the bias gradient and for the
+ * operand wgrad_split_kernel stages (amp_conv2d_wgrad_fmt x_split & 2). */
+int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate, float* dy_split, int shift) {
+    AMP_REQUIRE(ctx && dy && scratch && out && dy_split && M >= 0 && N > 0 && N % 32 == 0 && shift >= 0 && shift <= 24, "amp_colsum_split: bad argument (N %% 32 != 0?)");
+    const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N / 4, scratch, dy_split, ldexpf(1.0f, shift));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, scratch, parts, N, out, accumulate);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;

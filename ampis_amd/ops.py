@@ -108,7 +108,7 @@ def resize_bilinear_u8(ctx, img, h, w):
 def conv2d_wgrad(ctx, x, dy, w_shape, stride=1, pad=0, scale=None, grad=None, dy_shift=0, x_shift=0, x_split=False, bias_grad=None,
                  bias_accumulate=False):
     """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dW [Cout,KH,KW,Cin] (accumulated into `grad` when given).  x_split: x is in the split
-    hi|lo' row format (split_rows / a conv with FMT_Y_SPLIT).  bias_grad [Cout]: also receives (or accumulates) the column sums of dy."""
+    hi|lo' row format (split_rows / a conv with FMT_Y_SPLIT); x_split = 3: dy as well, ALREADY multiplied by 2**dy_shift.  bias_grad [Cout]: also receives (or accumulates) the column sums of dy."""
     _f32c(x), _f32c(dy)
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w_shape
@@ -119,7 +119,7 @@ def conv2d_wgrad(ctx, x, dy, w_shape, stride=1, pad=0, scale=None, grad=None, dy
     if grad is None:
         grad = torch.empty(w_shape, device=x.device)
     check(lib().amp_conv2d_wgrad_fmt(ctx.handle, C.byref(d), ptr(x), ptr(dy), ptr(scale), ptr(scratch), ptr(grad), int(acc),
-                                     int(dy_shift), int(x_shift), int(bool(x_split)), ptr(bias_grad), int(bool(bias_accumulate))), "amp_conv2d_wgrad")
+                                     int(dy_shift), int(x_shift), int(x_split), ptr(bias_grad), int(bool(bias_accumulate))), "amp_conv2d_wgrad")
     return grad
 
 

@@ -152,6 +152,8 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
                             float* grad, int accumulate, int dy_shift, int x_shift, int x_split, float* bias_grad, int bias_accumulate);
 /* out[n] (= or +=) sum_m dy[m][n]; N % 4 == 0; scratch >= ceil(M/512)*N floats */
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
+/* the same pass also writing dy * 2^shift in the split row format (N % 32 == 0): the dy operand of amp_conv2d_wgrad_fmt(x_split & 2) */
+int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate, float* dy_split, int shift);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
 /* dfeat[level] += RoIAlign-backward(dout [R,P,P,C]).  C == 256: owner-computes, no atomics -- every 4x4 tile of a gradient map is

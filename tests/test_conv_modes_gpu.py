@@ -182,6 +182,44 @@ def test_wgrad_reads_split_activations_bit_identically(gpu_ctx, case):
     assert not gpu_ctx.conv_range_flag()
 
 
+WGRAD_SPLIT_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dy magnitude
+    (2, 20, 24, 256, 128, 3, 1, 1, 1e-5),        # 3x3: nine taps through the offset table, image borders
+    (3, 17, 19, 512, 256, 1, 1, 0, 1e-6),        # ragged pixel count (969 rows), two K' tiles
+    (2, 32, 32, 128, 128, 3, 1, 1, 1e-4),        # Cin = 128: a K' tile straddles two taps, nine taps = 4.5 tiles
+    (2, 32, 32, 256, 512, 1, 2, 0, 1e-5),        # stride 2 (the first conv of a stage)
+    (1, 1, 300, 1024, 128, 1, 1, 0, 1e-3),       # fc-like
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_SPLIT_CASES)
+def test_wgrad_ring_kernel_on_split_operands(gpu_ctx, case):
+    """amp_conv2d_wgrad_fmt(x_split = 3): activations AND scaled loss gradients in the split row format go through wgrad_split_kernel
+    (LDS-DMA ring + transposing LDS reads).  Same operands as the in-kernel split, another summation order: equal to the fp32-storage
+    result within accumulation noise, as accurate against fp64, bitwise reproducible."""
+    from ampis_amd import ops
+    B, H, W, Cin, Cout, k, s, p, mag = case
+    g = torch.Generator().manual_seed(5 * Cin + k + Cout)
+    x = (torch.randn(B, H, W, Cin, generator=g) * 2).clamp_(min=0).cuda()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy = (torch.randn(B, Ho, Wo, Cout, generator=g) * mag).cuda()
+    ref = torch.nn.grad.conv2d_weight(x.cpu().double().permute(0, 3, 1, 2), (Cout, Cin, k, k), dy.cpu().double().permute(0, 3, 1, 2),
+                                      stride=s, padding=p).permute(0, 2, 3, 1)
+    plain = ops.conv2d_wgrad(gpu_ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=16)
+    xs = ops.split_rows(gpu_ctx, x)
+    dys = ops.split_rows(gpu_ctx, dy * 65536.0)
+    got = ops.conv2d_wgrad(gpu_ctx, xs, dys, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=16, x_split=3)
+    again = ops.conv2d_wgrad(gpu_ctx, xs, dys, (Cout, k, k, Cin), stride=s, pad=p, dy_shift=16, x_split=3)
+    torch.cuda.synchronize()
+    assert not gpu_ctx.conv_range_flag()
+    assert torch.equal(got, again)
+    m = ref.abs().max().item()
+    e_plain = (plain.cpu().double() - ref).abs().max().item() / m
+    e_got = (got.cpu().double() - ref).abs().max().item() / m
+    assert e_got <= max(1.5 * e_plain, 3e-7), (e_got, e_plain)
+    assert (got - plain).abs().max().item() / m < 2e-6
+
+
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_wgrad_fused_bias_gradient(gpu_ctx, case):
     """amp_conv2d_wgrad_fmt(bias_grad): the column sums of dy the MFMA kernel adds up on the side equal an fp64 sum to fp32 accuracy,

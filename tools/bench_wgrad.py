@@ -34,10 +34,13 @@ def main():
         Ho = (H + 2 * p - k) // s + 1; Wo = (W + 2 * p - k) // s + 1
         dy = torch.randn(B, Ho, Wo, Cout, device=d)
         flops = 2.0 * B * Ho * Wo * Cout * k * k * Cin
-        xs = bool(os.environ.get("AMP_SPLIT_IN")) and Cin % 32 == 0      # x stored in the split row format (amp_conv2d_wgrad_fmt)
-        if xs:
+        xs = int(os.environ.get("AMP_SPLIT_IN", "0")) if Cin % 32 == 0 and Cout % 32 == 0 else 0   # 1: x split; 3: dy too (scaled by 2^16)
+        if xs & 1:
             x = ops.split_rows(ctx, x)
             name += " [x split]"
+        if xs & 2:
+            dy = ops.split_rows(ctx, dy * 65536.0)
+            name += " [dy split]"
         g = None
         for _ in range(2):
             g = ops.conv2d_wgrad(ctx, x, dy, (Cout, k, k, Cin), stride=s, pad=p, grad=g, dy_shift=16, x_split=xs)
