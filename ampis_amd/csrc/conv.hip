@@ -1298,14 +1298,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
 #ifdef AMP_STAMP
     st_acc[7] = clock64() - st_loop_end;
 #endif
+    const bool scaled_in = a.out_scale != 1.0f;
 
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
                 acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                if (scaled_in) acc[i][j][e] *= a.out_scale;      // x arrived as split rows of x * 2^shift (a scaled loss gradient): exact power of two
+            }
     if constexpr (BM == 128 && BN == 256 && EPI == 2) {
         if (a.out_mode == 3) { conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0); return; }
     }
@@ -1810,7 +1813,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
-    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && in_shift == 0 && glds),
+    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && glds),
                 "conv: a split-format input needs AMP_CONV_F16X3, Cin %% 32 == 0, a dense layer and operands below 2 GiB");
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
     a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
@@ -1834,6 +1837,9 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         const int nblk256 = (a.Cout % 256 == 0) ? ntm * (a.Cout / 256) : 0;
         const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= 64));
         const int ntm256 = amp::cdiv(a.M, 256);
+        // a split input that carries a 2^in_shift (scaled loss gradients): only the ring kernel undoes it (a.out_scale in its fold)
+        AMP_REQUIRE(!(x_is_split && in_shift != 0) || (g_split_ring && epi != 0 && wide256 && a.out_mode != 3),
+                    "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
             launch_split<128, 256>(a, 2, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -930,6 +930,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const size_t DYS_SCRATCH = (size_t)B * T.fh[0] * T.fw[0] * 256;      // floats: the largest dy converted to a scaled split operand (p2 level)
     AMP_ALLOC(dys_scratch, float, DYS_SCRATCH);
     const bool GSW = m->acts_split && getenv("AMP_NO_SPLIT_GRADS") == nullptr && ctx->conv_mode == AMP_CONV_F16X3;
+    const float* dys_of = nullptr;       // the dy tensor whose scaled split copy dys_scratch currently holds
+    long long dys_rows = 0;
     auto GW = [&](const ConvW& cw) { return m->garena + (cw.w - m->parena); };
     auto GB = [&](const ConvW& cw) { return m->garena + (cw.shift - m->parena); };
     auto bgrad = [&](const ConvW& cw, const float* dy, long long M_, bool acc) -> int {
@@ -952,6 +954,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && Mo >= 200000 &&
             (size_t)Mo * cw.cout <= DYS_SCRATCH) {
             AMP_TRY(amp_colsum_split(ctx, dy, (int)Mo, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0, dys_scratch, 16));
+            dys_of = dy; dys_rows = Mo;                 // the data-gradient convolution of the same dy can stage this copy (dgrad below)
             return amp_conv2d_wgrad_fmt(ctx, &d, x, dys_scratch, cw.scale, wg_scratch, GW(cw), acc ? 1 : 0, 16, 0, 3, nullptr, 0);
         }
         // AMP_CONV_F16X3 splits dy * 2^16 like the data gradients below (ignored on the fp32 MFMA)
@@ -970,7 +973,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
         d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
         // data gradient on the context's arithmetic; AMP_CONV_F16X3 splits dy * 2^16 (gradients of 1e-9..1e-4 would sit in the f16
-        // subnormals)
+        // subnormals) -- unless the weight gradient of the same dy has just left that very tensor in dys_scratch: then the ring kernel stages
+        // it as it is and undoes the 2^16 in its fold
+        static const bool no_reuse = getenv("AMP_NO_DY_REUSE") != nullptr;      // EXPERIMENT switch
+        if (dy == dys_of && !no_reuse && dys_rows == (long long)B_ * Hy * Wy && cw.cin % 256 == 0 && ctx->conv_mode == AMP_CONV_F16X3)
+            return amp::conv_run(ctx, &d, 1, dys_scratch, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, 1 | ((mask && mask_split) ? 8 : 0));
         return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
     };
     // The backbone's chain on SCALED SPLIT gradients (GS): a gradient tensor is kept as the split rows of d * 2^16, so its data-gradient
