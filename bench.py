@@ -232,8 +232,8 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
     peak = PEAK_F16X3_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
     wg_ms, wg_fl, wg_n = prof["ms"][2], prof["flops"][2], prof["launches"][2]
     ach = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
-    kname = "wgrad_f16x3_kernel" if f16 else "wgrad_mfma_kernel"
-    traffic, traffic_src, traffic_key = pmc_traffic([kname])
+    kname = "wgrad_split_kernel + wgrad_f16x3_kernel" if f16 else "wgrad_mfma_kernel"
+    traffic, traffic_src, traffic_key = pmc_traffic(["wgrad_split_kernel", "wgrad_f16x3_kernel"] if f16 else [kname])
     conv_ms = prof["ms"][0] + prof["ms"][1]
     out = {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
            "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
@@ -241,7 +241,9 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
            "dtype": "f32 (forward, data-gradient and weight-gradient convs: f16x3 split-operand MFMA, fp32 accumulate)" if f16 else "f32",
            "workload": "BASELINE configs[2] (N=1) / configs[3] (N=8): K=2, ~480 GT instances/image (polygons), 256 anchors + 512 RoIs "
                        "sampled per image, seeded random-init weights, uint8 images resident in HBM, annotations (boxes, classes, polygons) passed from the host each step",
-           "roofline": {"bound": "mfma", "kernel": f"{kname} (dW = dY^T X, 128x128 tiles, split-K slabs reduced in fixed order)",
+           "roofline": {"bound": "mfma", "kernel": (f"{kname} (dW = dY^T X; both operands in the split row format: 128x256 tiles, LDS-DMA ring + transposing LDS reads; fp32 dY: "
+                                   "128x128 tiles split in registers; split-K slabs reduced in fixed order)" if f16 else
+                                   f"{kname} (dW = dY^T X, 128x128 tiles, split-K slabs reduced in fixed order)"),
                         "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                         **({"frac_of_sustained": round(ach / (SUSTAINED_F16_MFMA_RANDOM_TFLOPS / 3.0), 4)} if f16 else {}),
                         "traffic": traffic, "traffic_from": (f"{traffic_src}: {traffic_key}" if traffic_src else None),
