@@ -59,6 +59,22 @@ def main():
                     mism += 1
             print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
             bad += mism
+        # the weight-gradient ring kernel (wgrad_split_kernel: LDS-DMA of both operands + transposing LDS reads), same rule
+        for name, B, H, W, Cin, Cout, k, p in (("wgrad 3x3 256->256 @64", 8, 64, 64, 256, 256, 3, 1), ("wgrad 3x3 128->128 @48 (two taps per tile)", 4, 48, 49, 128, 128, 3, 1),
+                                               ("wgrad 1x1 1024->256 @32", 8, 32, 32, 1024, 256, 1, 0)):
+            g = torch.Generator().manual_seed(Cin + Cout + k + 1)
+            xs = ops.split_rows(ctx, torch.randn(B, H, W, Cin, generator=g).clamp_(min=0).cuda())
+            dys = ops.split_rows(ctx, (torch.randn(B, H, W, Cout, generator=g) * 1e-4 * 65536.0).cuda())
+            first = ops.conv2d_wgrad(ctx, xs, dys, (Cout, k, k, Cin), stride=1, pad=p, dy_shift=16, x_split=3).clone()
+            torch.cuda.synchronize()
+            mism = 0
+            for _ in range(reps):
+                y = ops.conv2d_wgrad(ctx, xs, dys, (Cout, k, k, Cin), stride=1, pad=p, dy_shift=16, x_split=3)
+                torch.cuda.synchronize()
+                if not torch.equal(y.view(torch.int32), first.view(torch.int32)):
+                    mism += 1
+            print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
+            bad += mism
     finally:
         stop.set()
         th.join()
