@@ -946,6 +946,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         d.relu = 0; d.res_mode = 0; d.out_mode = 0;
         AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
         static const bool no_fused_bias = getenv("AMP_NO_FUSED_BIAS") != nullptr;      // EXPERIMENT switch
+        dys_of = nullptr;                          // a scaled split copy is only trusted right after the weight gradient that made it
         const bool fused = bias && ctx->conv_mode == AMP_CONV_F16X3 && !no_fused_bias && !(xfmt & 2);
         // a big biased layer whose activation is already split (FPN output / RPN conv at p2, p3; the mask head): one pass over dy gives the bias
         // gradient AND dy * 2^16 in the split format, and the weight gradient runs on wgrad_split_kernel (+35-45 % on these shapes)
