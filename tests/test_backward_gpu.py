@@ -174,3 +174,44 @@ def test_training_step_is_bitwise_reproducible(gpu_ctx):
         assert L == grads[0][0]
         assert np.array_equal(a, grads[0][1]), f"{int((a != grads[0][1]).sum())} of {a.size} gradient values differ between runs"
     assert np.abs(grads[0][1]).max() > 0 and len(names) > 50
+
+
+def test_fullsize_step_f16x3_storage_paths_agree_with_fp32_mode():
+    """A training step at a size where every split-storage path is live (B = 4 at 1024^2: p2 has 262 144 rows -- the bias-sum pass converts dY,
+    FPN / RPN / mask-head weight gradients run on wgrad_split_kernel, their data gradients stage the same copy, the backbone chain runs on
+    scaled split gradients) against the same step with every convolution on the fp32 MFMA and fp32 storage throughout: same losses, same
+    gradients within the tolerance the small-size test holds against autograd."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    K, B, S = 2, 4, 1024
+    imgs, gts = synth.batch(B, S, S, first_index=300)
+    gts = [dict(boxes=g["boxes"][:150], classes=g["classes"][:150], polygons=g["polygons"][:150]) for g in gts]
+    npp = P.init_params(K, seed=0, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 200, max_poly_doubles=B * 200 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    out = {}
+    for mode in ("f32", "f16x3"):
+        ctx.conv_mode = mode
+        try:
+            losses = m.forward_losses(imgs, gts, seed=11, backward=True)
+            out[mode] = (losses, {k: m.get_tensor(k, grad=True) for k in names})
+        finally:
+            ctx.conv_mode = "f16x3"
+    assert not ctx.conv_range_flag()
+    for k, v in out["f32"][0].items():
+        assert out["f16x3"][0][k] == pytest.approx(v, rel=2e-4, abs=1e-6), k
+    bad = []
+    for k in names:
+        r, g = out["f32"][1][k], out["f16x3"][1][k]
+        err = float(np.abs(g - r).max()) / max(float(np.abs(r).max()), 1e-8)
+        if err > 2e-3:
+            bad.append((err, k))
+    assert not bad, sorted(bad, reverse=True)[:8]
+    again = m.forward_losses(imgs, gts, seed=11, backward=True)          # and the step repeats bit for bit with all of them live
+    assert again == out["f16x3"][0]
+    for k in names:
+        assert np.array_equal(m.get_tensor(k, grad=True), out["f16x3"][1][k]), k
+    m.close()
+    ctx.close()
