@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16x3_kernel(const WgradArgs a, 
 //     halves of the workgroup ping-pong between loading and multiplying -- conv_split_kernel's loop (conv.hip);
 //   * the MFMA wants 8 consecutive PIXELS per lane and channel, the rows hold consecutive CHANNELS per pixel: gfx950's transposing LDS read
 //     does the rest -- ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block of 16-bit elements, so
-//     two of them are the f16x8 operand of v_mfma_f32_16x16x32_f16 (probed on the GPU: tools/_probe/tr_probe.hip);
+//     two of them are the f16x8 operand of v_mfma_f32_16x16x32_f16 (probed on the GPU: tools/tr_probe.hip);
 //   * 16-B chunk j of row R lives at position j ^ (2 s(R)), s(R) = (R & 3) | ((R >> 3) & 1) << 2 (applied to the DMA's SOURCE chunk):
 //     the 8 row pieces (2 groups x 4 rows x 32 B) a half-wave reads at once then cover the 64 banks exactly once.
 // X is the MFMA's A operand (rows c), dY its B operand (columns n): a lane ends with 4 consecutive (tap, c) of one n -- 16-B stores
