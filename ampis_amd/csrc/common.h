@@ -104,9 +104,14 @@ struct PredictFuse {              // the mask head's tail fused into the deconv'
     int K;
     float* prob;                  // [N][28][28]
 };
+struct RpnFuse {                  // the RPN head's 1x1 predictors fused into the 3x3 conv's epilogue (conv.hip conv_epilogue_rpn)
+    const float* w_split;         // [16][256] objectness + anchor-delta rows (+ a zero row) in the split row format
+    const float* bias;            // [16]
+    float* pred;                  // [M][16]
+};
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
              const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0,
-             const PredictFuse* fuse = nullptr);
+             const PredictFuse* fuse = nullptr, const RpnFuse* rpn = nullptr);
 // comm.hip (all no-ops / errors are explicit when the context has no communicator)
 int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr);   // grouped in-place SUM, after the compute stream's work so far
 int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete on the compute stream (exposed-time reference)

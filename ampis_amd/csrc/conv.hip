@@ -52,6 +52,11 @@ struct ConvArgs {
     const float* pred_b;    // [K]
     const int* pred_cls;    // [B] class of each RoI (row b of the input)
     int pred_K;
+    // out_mode 4 (conv_split_kernel<128,256> only): the RPN head's tail -- ReLU, then the 16 predictor rows (3 objectness + 12 deltas + pad) as a
+    // second f16x3 product in the epilogue (conv_epilogue_rpn); the 256-channel hidden tensor is never written
+    const float* rpn_w;     // [16][Cout] split rows
+    const float* rpn_b;     // [16]
+    float* rpn_pred;        // [M][16]
     float* prob;            // [B][2Ho][2Wo] mask probabilities
     int res_split;          // 1: res is in that format too (decoded in the epilogue: hi + lo' * 2^-11, exact in fp32)
     int mask_split;         // 1: the ReLU mask tensor (training: the forward activation) is in that format (AMP_FMT_MASK_SPLIT)
@@ -1083,6 +1088,82 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
     }
 }
 
+// Epilogue of the fused RPN tail (out_mode 4, 128 x 256 tile = 128 pixels x all 256 hidden channels).  With the role-swapped MFMA a lane
+// holds, per tile row, channels [8 lq, 8 lq + 8) of each 32-channel group of its wave's 64 -- after affine, ReLU and the split, exactly the
+// A fragment (row = pixel l15, k group lq) of a v_mfma_f32_16x16x32_f16 over that group.  So the 1x1 predictors are a second f16x3
+// product right here: B = the predictor rows (16 outputs x 32 channels, split rows, straight from memory), 2 groups per wave, the four
+// N-waves' partial sums added through LDS in wave order, + bias -> pred [M][16].  Same operands as the separate 1x1 launch read from the
+// stored hidden tensor (the halves are identical), another summation order.  Replaces a 537 MB write + read at p2 and a launch per level.
+__device__ __forceinline__ void conv_epilogue_rpn(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nw0 = n0 + wn * 64;
+    f32x2 sc[2][4], sh[2][4];
+    f16x8 wh[2], wl[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int n = nw0 + 32 * g + 8 * lq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            sc[g][p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
+            sh[g][p] = a.shift ? f32x2{a.shift[n + 2 * p], a.shift[n + 2 * p + 1]} : f32x2{0.f, 0.f};
+        }
+        const char* wb = reinterpret_cast<const char*>(a.rpn_w + (size_t)l15 * a.Cout) + (size_t)(n >> 5) * 128 + (size_t)(n & 31) * 2;
+        wh[g] = *reinterpret_cast<const f16x8*>(wb);
+        wl[g] = *reinterpret_cast<const f16x8*>(wb + 64);
+    }
+    f32x4* red = reinterpret_cast<f32x4*>(lds);                     // [wm][wn][i][lane]
+    f32x2 chk = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x4& blk = acc[i][2 * g + (p >> 1)];
+                const f32x2 v = {blk[2 * (p & 1)], blk[2 * (p & 1) + 1]};
+                chk = __builtin_elementwise_fma(v, f32x2{0.f, 0.f}, chk);
+                f32x2 o = v * sc[g][p] + sh[g][p];
+                o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f);
+                const f16x2 h = __builtin_convertvector(o, f16x2);
+                const f32x2 hf = {(float)h[0], (float)h[1]};
+                const f32x2 l = __builtin_elementwise_fma(hf, f32x2{-LO_SCALE, -LO_SCALE}, o * LO_SCALE);
+                const f16x2 lh = __builtin_convertvector(l, f16x2);
+                hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+                lo[2 * p] = lh[0]; lo[2 * p + 1] = lh[1];
+            }
+            dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, wh[g], dx, 0, 0, 0);
+            dx = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wl[g], dx, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, wh[g], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = __fadd_rn(d[e], __fmul_rn(dx[e], 1.0f / LO_SCALE));
+        red[((wm * 4 + wn) * 4 + i) * 64 + lane] = d;
+    }
+    if (!(chk[0] == 0.f) || !(chk[1] == 0.f)) atomicOr(a.range_flag, 1);
+    __syncthreads();
+    if (wn == 0) {                                                  // lane = (output l15, pixels 4 lq .. 4 lq + 3 of block i)
+        const float bias = a.rpn_b[l15];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 s = red[((wm * 4 + 0) * 4 + i) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4 t = red[((wm * 4 + w) * 4 + i) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], t[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm * 64 + i * 16 + 4 * lq + e;
+                if (m < a.M) a.rpn_pred[(size_t)m * 16 + l15] = __fadd_rn(s[e], bias);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // conv_split_kernel: AMP_CONV_F16X3 with BOTH operands already in the split hi|lo' row format (the trunk's native activation
 // format in inference, and the pre-split weights), 8 waves on a 128x256 or 256x128 tile, one workgroup per CU.
@@ -1309,8 +1390,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kern
                 acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
                 if (scaled_in) acc[i][j][e] *= a.out_scale;      // x arrived as split rows of x * 2^shift (a scaled loss gradient): exact power of two
             }
-    if constexpr (BM == 128 && BN == 256 && EPI == 2) {
-        if (a.out_mode == 3) { conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0); return; }
+    if constexpr (BM == 128 && BN == 256 && EPI == 3) {          // the fused tails have an instantiation of their own: no row epilogue, no spills
+        if (a.out_mode == 3) conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0);
+        else conv_epilogue_rpn(a, acc, lds, wave, lane, m0, n0);
+        return;
     }
     if (a.y_split && (!a.mask || a.mask_split) && a.out_mode == 0 && (a.res_mode == 0 || a.res_split) && a.direct_epi)
         conv_epilogue_direct<EPI == 2, true>(a, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
@@ -1570,6 +1653,9 @@ void launch_f16x3s(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, 
 template <int BM, int BN>
 void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BM / 64) * (BN / 64) * 64;
+    if constexpr (BM == 128 && BN == 256) {
+        if (epi == 3) { hipLaunchKernelGGL((conv_split_kernel<128, 256, 3>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); return; }
+    }
     if (epi == 2) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
 }
@@ -1675,6 +1761,26 @@ extern "C" int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const f
     return amp::conv_run(ctx, d, 1, x, w, nullptr, 0, scale, shift, res, nullptr, y, 0, fmt);
 }
 
+// Stage a11, fused: x [B,H,W,256] (a pyramid level, split rows) -> 3x3 conv 256 -> 256 + bias + ReLU -> the 16 predictor rows (3 objectness
+// logits, 12 anchor deltas, one zero row; w_pred [16][256], b_pred [16]) -> pred [B*H*W][16]; the hidden tensor is never written.
+// The predictor rows are split here per call (the model keeps its own split copy); B*H*W >= 24576 so that the 128 x 256 tiles fill the chip.
+extern "C" int amp_rpn_head_fused(amp_ctx* ctx, const float* x_split, int B, int H, int W, const float* w_conv, const float* b_conv, const float* w_pred,
+                                  const float* b_pred, float* pred) {
+    AMP_REQUIRE(ctx && x_split && w_conv && b_conv && w_pred && b_pred && pred && B > 0 && H > 0 && W > 0, "amp_rpn_head_fused: bad argument");
+    AMP_REQUIRE(ctx->conv_mode == AMP_CONV_F16X3, "amp_rpn_head_fused: AMP_CONV_F16X3 only (the fp32 path runs the two convolutions)");
+    AMP_REQUIRE((long long)B * H * W >= 24576, "amp_rpn_head_fused: fewer than 24576 pixels: run the two convolutions (amp_conv2d_nhwc_fmt)");
+    float* wps = nullptr;
+    AMP_HIP_CHECK(hipMalloc(&wps, 16 * 256 * sizeof(float)));
+    hipLaunchKernelGGL(split_weights_kernel, dim3(8), dim3(256), 0, ctx->stream, w_pred, (size_t)16, 256, reinterpret_cast<unsigned int*>(wps));
+    amp_conv_desc d;
+    d.B = B; d.H = H; d.W = W; d.Cin = 256; d.Cout = 256; d.KH = 3; d.KW = 3; d.stride = 1; d.pad = 1; d.relu = 1; d.res_mode = 0; d.out_mode = 0;
+    amp::RpnFuse rf{wps, b_pred, pred};
+    const int st = amp::conv_run(ctx, &d, 1, x_split, w_conv, nullptr, 0, nullptr, b_conv, nullptr, nullptr, pred, 0, 1, nullptr, &rf);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(wps);
+    return st;
+}
+
 // Stage a16 tail, fused: x [N,14,14,256] in the split row format -> ConvTranspose2d 2x2 s2 (w_deconv [(ky,kx,co)][256], bias [1024]: the
 // bias of co repeated per tap) -> ReLU -> 1x1 predictor row of classes[n] (pred_w [K][256], pred_b [K]) -> sigmoid -> prob [N,28,28]
 extern "C" int amp_mask_deconv_predict(amp_ctx* ctx, const float* x_split, int N, const float* w_deconv, const float* bias, const float* pred_w,
@@ -1735,7 +1841,7 @@ extern "C" int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float
 
 int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
                   const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift, int fmt,
-                  const amp::PredictFuse* fuse) {
+                  const amp::PredictFuse* fuse, const amp::RpnFuse* rpn) {
     AMP_REQUIRE(ctx && d && x && w && y, "amp_conv2d_nhwc: null argument");
     AMP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "amp_conv2d_nhwc: bad shape");
     AMP_REQUIRE(d->Cin % 4 == 0, "amp_conv2d_nhwc: Cin=%d must be a multiple of 4 (pad the input)", d->Cin);
@@ -1810,6 +1916,15 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         a.out_mode = 3;
         a.pred_w = fuse->pred_w; a.pred_b = fuse->pred_b; a.pred_cls = fuse->cls; a.pred_K = fuse->K; a.prob = fuse->prob;
     }
+    a.rpn_w = a.rpn_b = nullptr; a.rpn_pred = nullptr;
+    if (rpn) {      // the RPN head's predictors in the 3x3 conv's epilogue (conv_epilogue_rpn): one 128 x 256 tile = all hidden channels of 128 pixels
+        AMP_REQUIRE(!fuse && x_is_split && d->out_mode == 0 && a.Cout == 256 && a.relu && !res && !mask && g_split_ring && in_shift == 0,
+                    "conv: the fused RPN epilogue needs a split input, Cout = 256, ReLU and the ring kernel");
+        AMP_REQUIRE(rpn->w_split && rpn->bias && rpn->pred, "conv: incomplete RpnFuse");
+        a.out_mode = 4;
+        a.y_split = 0;
+        a.rpn_w = rpn->w_split; a.rpn_b = rpn->bias; a.rpn_pred = rpn->pred;
+    }
     AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
@@ -1842,7 +1957,10 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
                     "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
-            launch_split<128, 256>(a, 2, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+            launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (a.out_mode == 4) {                                        // fused RPN tail: one N tile
+            a.ntn = 1; a.nblk = ntm;
+            launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -391,8 +391,20 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         const size_t keep = ws.off;
         AMP_ALLOC(t, float, (size_t)B * fh[l] * fw[l] * 256);
         if (!dry) {
-            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.conv"), feat[l], B, fh[l], fw[l], 1, 1, true, 0, nullptr, 0, t, FMT(native_all, native_all, false)));
-            AMP_TRY(launch_conv(m, CONV("proposal_generator.rpn_head.pred"), t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred, FMT(native_all, false, false)));
+            const ConvW& rc = CONV("proposal_generator.rpn_head.conv");
+            const ConvW& rp = CONV("proposal_generator.rpn_head.pred");
+            static const bool no_rpn_fuse = getenv("AMP_NO_RPN_FUSE") != nullptr;      // EXPERIMENT switch
+            const long long Ml = (long long)B * fh[l] * fw[l];
+            if (native_all && !m->saving && !no_rpn_fuse && rc.cout == 256 && rc.w_split && rp.w_split && rp.cout == 16 && rp.cin == 256 && Ml >= 24576) {
+                // inference on the native trunk: the predictors run in the 3x3 conv's epilogue, the hidden tensor is never written
+                amp_conv_desc d;
+                d.B = B; d.H = fh[l]; d.W = fw[l]; d.Cin = rc.cin; d.Cout = rc.cout; d.KH = rc.kh; d.KW = rc.kw; d.stride = 1; d.pad = 1; d.relu = 1; d.res_mode = 0; d.out_mode = 0;
+                amp::RpnFuse rf{rp.w_split, rp.shift, pred};
+                AMP_TRY(amp::conv_run(ctx, &d, 1, feat[l], rc.w, rc.w_split, 0, rc.scale, rc.shift, nullptr, nullptr, t, 0, 1, nullptr, &rf));
+            } else {
+                AMP_TRY(launch_conv(m, rc, feat[l], B, fh[l], fw[l], 1, 1, true, 0, nullptr, 0, t, FMT(native_all, native_all, false)));
+                AMP_TRY(launch_conv(m, rp, t, B, fh[l], fw[l], 1, 0, false, 0, nullptr, 0, pred, FMT(native_all, false, false)));
+            }
         }
         (void)mark;
         if (m->saving) m->rpn_t[l] = t; else ws.off = keep;

@@ -248,6 +248,11 @@ int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const flo
 
 /* Stages a16 / a17 / a3: mask probability, paste + threshold + RLE counts ----------------------- */
 int amp_mask_prob(amp_ctx* ctx, const float* logits, const int* classes, int N, int K, float* prob);
+/* the RPN head of one pyramid level in one kernel (AMP_CONV_F16X3; stage a11): x_split [B,H,W,256] (split rows) -> 3x3 conv + bias + ReLU ->
+ * the 16 predictor rows (3 objectness logits, 12 anchor deltas, 1 zero row: w_pred [16][256], b_pred [16]) as a second product in the
+ * epilogue -> pred [B*H*W][16]; the 256-channel hidden tensor is never written. B*H*W >= 24576. */
+int amp_rpn_head_fused(amp_ctx* ctx, const float* x_split, int B, int H, int W, const float* w_conv, const float* b_conv, const float* w_pred,
+                       const float* b_pred, float* pred);
 /* the tail of the mask head in one kernel (AMP_CONV_F16X3): x_split [N,14,14,256] (split rows) -> ConvTranspose2d 2x2 s2 (w_deconv
  * [(ky,kx,co)][256], bias [1024] = the 256 biases once per tap) -> ReLU -> predictor row of classes[n] (pred_w [K][256], pred_b [K]) ->
  * sigmoid -> prob [N,28,28]; the [N,28,28,256] activation is never written */

@@ -298,3 +298,32 @@ def test_fused_mask_tail_matches_the_three_stage_chain(gpu_ctx):
     print("max |prob - fp64|: three-stage chain", e_chain, "fused", e_fused)
     assert e_chain < 2e-6 and e_fused < 2e-6
     assert not gpu_ctx.conv_range_flag()
+
+
+def test_fused_rpn_head_matches_the_two_convolutions(gpu_ctx):
+    """amp_rpn_head_fused (3x3 conv + ReLU, then the objectness / anchor-delta rows as a second f16x3 product in the conv's epilogue)
+    against (a) the two convolutions it replaces and (b) torch in fp64."""
+    from ampis_amd import ops, _lib
+    g = torch.Generator().manual_seed(21)
+    B, H, W = 2, 112, 120                                        # 26 880 pixels, ragged against the 128-row tiles
+    x = (torch.randn(B, H, W, 256, generator=g).clamp_(min=0)).to(DEV)
+    wc = (torch.randn(256, 3, 3, 256, generator=g) * 0.02).to(DEV)
+    bc = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    wp = torch.zeros(16, 1, 1, 256); wp[:15] = torch.randn(15, 1, 1, 256, generator=g) * 0.05
+    bp = torch.zeros(16); bp[:15] = torch.randn(15, generator=g) * 0.1
+    wp_d, bp_d = wp.to(DEV), bp.to(DEV)
+    xs = ops.split_rows(gpu_ctx, x)
+    pred = torch.empty(B * H * W, 16, device=DEV)
+    _lib.check(_lib.lib().amp_rpn_head_fused(gpu_ctx.handle, _lib.ptr(xs), B, H, W, _lib.ptr(wc), _lib.ptr(bc), _lib.ptr(wp_d), _lib.ptr(bp_d),
+                                             _lib.ptr(pred)), "amp_rpn_head_fused")
+    t = ops.conv2d_nhwc(gpu_ctx, x, wc, None, bc, pad=1, relu=True)
+    chain = ops.conv2d_nhwc(gpu_ctx, t, wp_d, None, bp_d).reshape(-1, 16)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), wc.cpu().double().permute(0, 3, 1, 2), bc.cpu().double(), padding=1).relu()
+    ref = torch.nn.functional.conv2d(ref, wp.double().permute(0, 3, 1, 2), bp.double()).permute(0, 2, 3, 1).reshape(-1, 16)
+    m = ref.abs().max().item()
+    e_chain, e_fused = (chain.cpu().double() - ref).abs().max().item() / m, (pred.cpu().double() - ref).abs().max().item() / m
+    print("max |pred - fp64| / max: two convolutions", e_chain, "fused", e_fused)
+    assert e_fused <= max(1.5 * e_chain, 5e-7), (e_fused, e_chain)
+    assert float(pred[:, 15].abs().max()) == 0.0                 # the pad row stays a pad row
+    assert not gpu_ctx.conv_range_flag()
