@@ -116,10 +116,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         // OR the kept rows into the removed words of later chunks (lane owns words lane, lane + 64)
         unsigned long long kk = keep;
         const int nw = (Wn + 63) >> 6;   // 64-word groups in use (wave-uniform)
-        while (kk != 0ull) {   // 4 independent row loads in flight per trip (the ORs are associative)
-            int bits[4];
+        while (kk != 0ull) {   // NU independent row loads in flight per trip (the ORs are associative): the scan is a chain of L2 round trips
+            constexpr int NU = 16;
+            int bits[NU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 bits[u] = kk ? __builtin_ctzll(kk) : -1;
                 if (kk) kk &= kk - 1ull;
             }
@@ -127,11 +128,13 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
             for (int wgrp = 0; wgrp < 4; ++wgrp) {
                 if (wgrp >= nw) break;
                 const int word = lane + 64 * wgrp;
-                unsigned long long v[4] = {0ull, 0ull, 0ull, 0ull};
+                unsigned long long v[NU];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (bits[u] >= 0 && word < Wn) v[u] = M[(size_t)(c * 64 + bits[u]) * a.W + word];
-                rem[wgrp] |= (v[0] | v[1]) | (v[2] | v[3]);
+                for (int u = 0; u < NU; ++u) v[u] = (bits[u] >= 0 && word < Wn) ? M[(size_t)(c * 64 + bits[u]) * a.W + word] : 0ull;
+                unsigned long long o = 0ull;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) o |= v[u];
+                rem[wgrp] |= o;
             }
         }
     }
