@@ -964,7 +964,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         // gradient AND dy * 2^16 in the split format, and the weight gradient runs on wgrad_split_kernel (+35-45 % on these shapes)
         static const bool no_conv = getenv("AMP_NO_DY_CONVERT") != nullptr;      // EXPERIMENT switch
         const long long Mo = (long long)B_ * ((H_ + 2 * pad - cw.kh) / stride + 1) * ((W_ + 2 * pad - cw.kw) / stride + 1);
-        if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && Mo >= 200000 &&
+        if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && (Mo >= 200000 || (cw.kh * cw.kw * cw.cin >= 4096 && Mo >= 4096)) &&
             (size_t)Mo * cw.cout <= DYS_SCRATCH) {
             AMP_TRY(amp_colsum_split(ctx, dy, (int)Mo, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0, dys_scratch, 16));
             dys_of = dy; dys_rows = Mo;                 // the data-gradient convolution of the same dy can stage this copy (dgrad below)
@@ -989,7 +989,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         // subnormals) -- unless the weight gradient of the same dy has just left that very tensor in dys_scratch: then the ring kernel stages
         // it as it is and undoes the 2^16 in its fold
         static const bool no_reuse = getenv("AMP_NO_DY_REUSE") != nullptr;      // EXPERIMENT switch
-        if (dy == dys_of && !no_reuse && dys_rows == (long long)B_ * Hy * Wy && cw.cin % 256 == 0 && ctx->conv_mode == AMP_CONV_F16X3)
+        const long long nblk256 = (((long long)B_ * Hy * Wy + 127) / 128) * (cw.cin / 256);      // conv_run takes the 128 x 256 ring kernel for this
+        const bool ring_fits = cw.cin % 256 == 0 && (nblk256 >= 512 || (nblk256 >= 192 && cw.kh * cw.kw * cw.cout / 32 >= 64));
+        if (dy == dys_of && !no_reuse && dys_rows == (long long)B_ * Hy * Wy && ring_fits && ctx->conv_mode == AMP_CONV_F16X3)
             return amp::conv_run(ctx, &d, 1, dys_scratch, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, 1 | ((mask && mask_split) ? 8 : 0));
         return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
     };
