@@ -1088,8 +1088,22 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
         const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
         AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0, true, AS));
-        AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t, AS));
-        AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0, true, AS));
+        const long long Ml = (long long)B * T.fh[l] * T.fw[l];
+        static const bool no_rpn_split = getenv("AMP_NO_RPN_SPLIT") != nullptr;      // EXPERIMENT switch
+        if (GSW && !no_rpn_split && Ml >= 200000 && (size_t)Ml * 256 <= DYS_SCRATCH && cpred.scale == nullptr && T.lv.ld == 16 && cpred.cout <= 16 && cconv.cout == 256) {
+            // big levels on the native trunk: the predictor's data gradient (K = 15) is one bandwidth-bound pass that writes d_t * 2^16 as split
+            // rows and sums the conv's bias gradient on the side; both gradients of the conv then stage that copy on the ring kernels
+            AMP_TRY(amp_small_k_dgrad_split(ctx, d_rpn_pred[l], cpred.cout, cpred.w, 256, m->rpn_t[l], dys_scratch, (int)Ml, 16, cs_scratch, GB(cconv), l > 0 ? 1 : 0));
+            amp_conv_desc dd;
+            dd.B = B; dd.H = T.fh[l]; dd.W = T.fw[l]; dd.Cin = cconv.cin; dd.Cout = cconv.cout; dd.KH = cconv.kh; dd.KW = cconv.kw; dd.stride = 1; dd.pad = 1;
+            dd.relu = 0; dd.res_mode = 0; dd.out_mode = 0;
+            AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&dd) <= WG_SCRATCH, "backward: wgrad scratch too small");
+            AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &dd, T.feat[l], dys_scratch, cconv.scale, wg_scratch, GW(cconv), l > 0 ? 1 : 0, 16, 0, 3, nullptr, 0));
+            dys_of = d_t; dys_rows = Ml;             // (d_t itself stays unwritten: its only reader below takes the split copy)
+        } else {
+            AMP_TRY(dgrad(cpred, d_rpn_pred[l], B, T.fh[l], T.fw[l], 0, nullptr, m->rpn_t[l], d_t, AS));
+            AMP_TRY(wgrad(cconv, T.feat[l], B, T.fh[l], T.fw[l], 1, 1, d_t, l > 0, true, AS));
+        }
         AMP_TRY(dgrad(cconv, d_t, B, T.fh[l], T.fw[l], 1, d_feat[l], nullptr, d_feat[l]));   // accumulate in place
     }
     AMP_TRY(issue_bucket(m, 2));

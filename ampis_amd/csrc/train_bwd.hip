@@ -418,6 +418,73 @@ __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K
     }
 }
 
+// The same product for the RPN predictor on the native trunk (K <= 16, C = 256, act in the split row format), writing what its consumers
+// stage: dx * scale as split rows (the dy operand of the RPN conv's weight- and data-gradient on the ring kernels) and, on the side, the
+// column sums of dx (that conv's bias gradient) per 512-row slice -- one bandwidth-bound pass instead of an fp32 MFMA launch (0.87 ms at
+// p2), a mask pass and a conversion.  A thread owns 8 channels for all its rows: its 16 x 8 weights stay in registers, a row costs four
+// 16-B loads of dl (the same address for the 32 threads of the row), the mask halves, 120 FMAs and two 16-B stores.
+// 32 column groups x 8 row lanes per workgroup; partial [gridDim.x][C] for colsum_final.
+typedef _Float16 sk_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void small_k_dgrad_split_kernel(const float* __restrict__ dl, int K, const float* __restrict__ w, int C,
+                                                                   const float* __restrict__ act_split, float* __restrict__ dx_split, int npix,
+                                                                   float* __restrict__ partial, float scale) {
+    __shared__ float red[8][32][8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 512, r1 = min(npix, r0 + 512);
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int ch = cbase + 8 * cg;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ch < C) {
+            f32x4 wr[16][2];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                wr[k][0] = (k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+                wr[k][1] = (k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + ch + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const size_t col_b = (size_t)(ch >> 5) * 128 + (size_t)(ch & 31) * 2;
+            for (int r = r0 + rl; r < r1; r += 8) {
+                f32x4 d4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) d4[q] = *reinterpret_cast<const f32x4*>(dl + (size_t)r * 16 + 4 * q);
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float d = d4[k >> 2][k & 3];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = __fadd_rn(v[q], __fmul_rn(d, q < 4 ? wr[k][0][q] : wr[k][1][q - 4]));
+                }
+                const char* mb = reinterpret_cast<const char*>(act_split + (size_t)r * C) + col_b;
+                const sk_h8 mh = *reinterpret_cast<const sk_h8*>(mb), ml = *reinterpret_cast<const sk_h8*>(mb + 64);
+                sk_h8 hi, lo;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float g = ((float)mh[q] + (float)ml[q] * (1.0f / 2048.0f)) > 0.f ? v[q] : 0.f;
+                    acc[q] = __fadd_rn(acc[q], g);
+                    const float x = g * scale;
+                    const _Float16 h = (_Float16)x;
+                    hi[q] = h;
+                    lo[q] = (_Float16)((x - (float)h) * 2048.0f);
+                }
+                char* ob = reinterpret_cast<char*>(dx_split + (size_t)r * C) + col_b;
+                *reinterpret_cast<sk_h8*>(ob) = hi;
+                *reinterpret_cast<sk_h8*>(ob + 64) = lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[rl][cg][q] = acc[q];
+        __syncthreads();
+        if (rl == 0 && ch < C) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float t = red[0][cg][q];
+                for (int k = 1; k < 8; ++k) t = __fadd_rn(t, red[k][cg][q]);
+                partial[(size_t)blockIdx.x * C + ch + q] = t;
+            }
+        }
+    }
+}
+
 // out[(t*C2 + co)*Cin + ci] (+)= in[(ci*T + t)*C2 + co]: gradient of the ConvTranspose weight from its [ci][tap][co] wgrad form
 __global__ void deconv_grad_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int Cin, int T, int C2, int accumulate) {
     const size_t total = (size_t)Cin * T * C2;
@@ -559,6 +626,18 @@ int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float*
     hipLaunchKernelGGL(small_k_dgrad_kernel, dim3(grid_for(npix * (C / 4))), dim3(256), 0, ctx->stream, dl, ld, K, w, C, act, dx, npix);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
+}
+
+int amp_colsum_finish(amp_ctx* ctx, const float* partial, int parts, int N, float* out, int accumulate);      // wgrad.hip
+
+int amp_small_k_dgrad_split(amp_ctx* ctx, const float* dl, int K, const float* w, int C, const float* act_split, float* dx_split, int npix,
+                            int shift, float* scratch, float* colsum_out, int accumulate) {
+    AMP_REQUIRE(ctx && dl && w && act_split && dx_split && scratch && colsum_out && C % 32 == 0 && K >= 1 && K <= 16 && npix > 0 && shift >= 0 && shift <= 24,
+                "amp_small_k_dgrad_split: bad argument (dl rows are 16 floats, K <= 16)");
+    const int parts = (npix + 511) / 512;
+    hipLaunchKernelGGL(small_k_dgrad_split_kernel, dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, ldexpf(1.0f, shift));
+    AMP_HIP_CHECK(hipGetLastError());
+    return amp_colsum_finish(ctx, scratch, parts, C, colsum_out, accumulate);
 }
 
 int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate) {

@@ -968,6 +968,14 @@ int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, floa
     return AMP_OK;
 }
 
+/* second pass of the column sums alone (partial [parts][N] from a kernel that summed its slices itself: amp_small_k_dgrad_split) */
+int amp_colsum_finish(amp_ctx* ctx, const float* partial, int parts, int N, float* out, int accumulate) {
+    AMP_REQUIRE(ctx && partial && out && parts >= 1 && N > 0, "amp_colsum_finish: bad argument");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, partial, parts, N, out, accumulate);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
 /* amp_colsum that also leaves dy * 2^shift in the split row format (N % 32 == 0): one pass over dy for the bias gradient and for the
  * operand wgrad_split_kernel stages (amp_conv2d_wgrad_fmt x_split & 2). */
 int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate, float* dy_split, int shift) {

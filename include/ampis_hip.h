@@ -173,6 +173,12 @@ int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n
 int amp_relu_mask_to_split(amp_ctx* ctx, const float* g, const float* act_split, float* out_split, size_t n, int C, int shift);
 int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int B, int H, int W, int C, int shift);                                  /* g *= (act > 0) */
 int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx, size_t npix);
+/* The same product for dl rows of 16 floats (K <= 16), C % 32 == 0 and act in the split row format, leaving dx * 2^shift as split rows (the
+ * dy operand of the ring kernels) and colsum_out[c] (= or +=) the sum over the pixels of dx[.][c] (the bias gradient of the layer that
+ * produced act); scratch: ceil(npix / 512) * C floats. */
+int amp_small_k_dgrad_split(amp_ctx* ctx, const float* dl, int K, const float* w, int C, const float* act_split, float* dx_split, int npix,
+                            int shift, float* scratch, float* colsum_out, int accumulate);
+int amp_colsum_finish(amp_ctx* ctx, const float* partial, int parts, int N, float* out, int accumulate);
 int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate);
 /* torch.optim.SGD: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
 int amp_sgd_update(amp_ctx* ctx, float* p, const float* g, float* v, size_t n, float lr, float momentum, float weight_decay, float grad_scale);
