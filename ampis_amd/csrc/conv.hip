@@ -1447,7 +1447,6 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = (BN == 64) ? 32 : 64;
     constexpr int NWN = BN / WTN, NW = 2 * NWN;   // waves across N, waves per workgroup
-    constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int RPT = 512 / (64 * NW);  // activation rows per lane (128 rows x 4 lanes per row over the workgroup)
     constexpr int GB = BN / NW / 8;       // DMA instructions per wave per step for B: BN/NW rows per wave, 8 rows each
     constexpr int TILE_FLOATS = (BM + BN) * BK;   // a row = 32 k = 64 B hi halves + 64 B lo halves = 32 dwords, as in the fp32 kernel
@@ -1460,7 +1459,6 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
-    const int l31 = lane & 31, lh = lane >> 5;
 
     const int tile = amp::xcd_remap(blockIdx.x, a.nblk);
     const int tile_n = tile % a.ntn;
