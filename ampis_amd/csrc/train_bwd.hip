@@ -232,21 +232,33 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTil
             // bins whose taps can reach the tile (conservative by one bin on each side; a bin that does not gets zero weights)
             const int ph_lo = max(0, (int)floorf(__fdiv_rn((float)(ty0 - 1) - sh, bh)) - 1), ph_hi = min(a.P - 1, (int)floorf(__fdiv_rn((float)(ty0 + 4) - sh, bh)) + 1);
             const int pw_lo = max(0, (int)floorf(__fdiv_rn((float)(tx0 - 1) - sw, bw)) - 1), pw_hi = min(a.P - 1, (int)floorf(__fdiv_rn((float)(tx0 + 4) - sw, bw)) + 1);
+            // the separable weights of every (bin, tile row) and (bin, tile column) pair at once: lane 4 q + k holds bin lo + q against
+            // row / column k (P <= 16 bins per axis), instead of one loop over the samples per bin pair
+            const int q = lane >> 2;
+            const float wy_all = (ph_lo + q <= ph_hi) ? roi_axis_weight(gh, sh, bh, ph_lo + q, H, ty0 + l3) : 0.f;
+            const float wx_all = (pw_lo + q <= pw_hi) ? roi_axis_weight(gw, sw, bw, pw_lo + q, W, tx0 + l3) : 0.f;
+            const unsigned long long nzy = __ballot(wy_all != 0.f), nzx = __ballot(wx_all != 0.f);
+            if (nzy == 0ull || nzx == 0ull) continue;
             for (int ph = ph_lo; ph <= ph_hi; ++ph) {
-                const float wy = roi_axis_weight(gh, sh, bh, ph, H, ty0 + l3);         // lane k & 3 = row ty0 + k
-                if (__ballot(wy != 0.f) == 0ull) continue;
+                const int qy = 4 * (ph - ph_lo);
+                if (((nzy >> qy) & 0xfull) == 0ull) continue;
+                float wyr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wyr[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wy_all), qy + r));
                 for (int pw = pw_lo; pw <= pw_hi; ++pw) {
-                    const float wx = roi_axis_weight(gw, sw, bw, pw, W, tx0 + l3);
-                    if (__ballot(wx != 0.f) == 0ull) continue;
+                    const int qx = 4 * (pw - pw_lo);
+                    if (((nzx >> qx) & 0xfull) == 0ull) continue;
                     f32x4 gv = *reinterpret_cast<const f32x4*>(a.dout + ((size_t)(rr * a.P + ph) * a.P + pw) * 256 + 4 * lane);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) gv[e] = __fmul_rn(gv[e], inv);
+                    float wxc[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wxc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx_all), qx + c));
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float wyr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wy), r));
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            const float w = __fmul_rn(wyr, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx), c)));
+                            const float w = __fmul_rn(wyr[r], wxc[c]);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[r][c][e] = __fadd_rn(acc[r][c][e], __fmul_rn(w, gv[e]));
                         }
@@ -528,7 +540,8 @@ int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[
     AMP_REQUIRE(ctx && dfeat && fh && fw && stride && rois && dout, "amp_roi_align_bwd_batched: null argument");
     if (R == 0) return AMP_OK;
     static const bool env_atomics = getenv("AMP_ROI_BWD_ATOMICS") != nullptr;
-    if (C != 256 || env_atomics || g_roi_bwd_atomics) {     // other widths, or the round-1 kernel for comparison: float atomics
+    if (C != 256 || P > 16 || env_atomics || g_roi_bwd_atomics) {     // other widths / more than 16 bins per axis (the tile kernel's lane
+        // layout), or the round-1 kernel for comparison: float atomics
         RoiBwdArgs a;
         for (int l = 0; l < 4; ++l) { a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l]; }
         a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.C = C;

@@ -51,20 +51,49 @@ __device__ __forceinline__ float iou_gt_box(float gx1, float gy1, float gx2, flo
     return inter > 0.f ? __fdiv_rn(inter, __fsub_rn(__fadd_rn(garea, area), inter)) : 0.f;
 }
 
+// The same value for the anchor sweeps, where a wave is 64 neighbouring anchors and a GT box meets few of them: the division (most of
+// the arithmetic) sits behind a wave-uniform test, so a wave pays it only for the GT boxes that touch one of its anchors.
+// `any` = some lane of the wave has a non-empty intersection.
+__device__ __forceinline__ float iou_gt_box_sweep(float gx1, float gy1, float gx2, float gy2, float garea, float x1, float y1, float x2,
+                                                  float y2, float area, bool& any) {
+    const float w = fmaxf(__fsub_rn(fminf(gx2, x2), fmaxf(gx1, x1)), 0.f);
+    const float h = fmaxf(__fsub_rn(fminf(gy2, y2), fmaxf(gy1, y1)), 0.f);
+    const float inter = __fmul_rn(w, h);
+    float v = 0.f;
+    any = __builtin_amdgcn_ballot_w64(inter > 0.f) != 0ull;
+    if (any) v = inter > 0.f ? __fdiv_rn(inter, __fsub_rn(__fadd_rn(garea, area), inter)) : 0.f;
+    return v;
+}
+
 // ---- anchors <-> GT: best GT per anchor and best IoU per GT (Matcher inputs) -------------------------------------------------
+// Both sweeps walk the GT boxes of an image per wave of 64 neighbouring anchors.  A wave first takes the bounding box of its anchors;
+// of every 64 GT boxes (one per lane) only those that overlap it are evaluated -- a GT box outside the bounding box has IoU 0 with
+// each of the wave's anchors, which changes neither a maximum that starts at 0 nor an equality test against a positive best IoU.
+struct WaveBox { float x1, y1, x2, y2; };
+__device__ __forceinline__ WaveBox wave_bounds(float x1, float y1, float x2, float y2) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        x1 = fminf(x1, __shfl_xor(x1, o)); y1 = fminf(y1, __shfl_xor(y1, o));
+        x2 = fmaxf(x2, __shfl_xor(x2, o)); y2 = fmaxf(y2, __shfl_xor(y2, o));
+    }
+    return WaveBox{x1, y1, x2, y2};
+}
+
 __global__ __launch_bounds__(256) void anchor_match_kernel(const AnchorGeom g, const float* __restrict__ gt_boxes,
                                                            const int* __restrict__ gt_off, float* match_val, int* match_idx,
                                                            unsigned int* gt_best /* [sum G] float bits, zeroed */) {
     __shared__ float sg[MAXG_TILE][5];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
     float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     int lvl, local;
     const bool av = a < g.total;
-    if (av) anchor_box(g, a, x1, y1, x2, y2, lvl, local);
+    if (av) anchor_box(g, a, x1, y1, x2, y2, lvl, local);      // lanes beyond the last anchor hold an empty box at the origin: IoU 0
     const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
-    float best = -1.f;
+    const WaveBox wb = wave_bounds(x1, y1, x2, y2);
+    float best = 0.f;     // torch.max(dim=0) over IoUs >= 0: the first GT unless a later one is strictly larger
     int besti = 0;
     for (int t0 = 0; t0 < G; t0 += MAXG_TILE) {
         const int tn = min(MAXG_TILE, G - t0);
@@ -75,22 +104,30 @@ __global__ __launch_bounds__(256) void anchor_match_kernel(const AnchorGeom g, c
             sg[threadIdx.x][4] = __fmul_rn(__fsub_rn(p[2], p[0]), __fsub_rn(p[3], p[1]));
         }
         __syncthreads();
-        for (int j = 0; j < tn; ++j) {
-            const float v = av ? iou_gt_box(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area) : 0.f;
-            if (v > best) { best = v; besti = t0 + j; }        // first maximum, like torch.max(dim=0)
-            // this GT's best IoU over all anchors: wave maximum -> one atomicMax per (wave, GT), and only for the few GTs the wave's
-            // 64 neighbouring anchors touch at all (a max is order-independent: deterministic).  A workgroup-level reduction here
-            // cost two barriers per GT and 2/3 of the kernel.
-            if (__builtin_amdgcn_ballot_w64(v > 0.f)) {
-                float m = v;
+        for (int c0 = 0; c0 < tn; c0 += 64) {
+            const int jl = c0 + lane;
+            const bool hit = jl < tn && sg[jl][0] < wb.x2 && sg[jl][2] > wb.x1 && sg[jl][1] < wb.y2 && sg[jl][3] > wb.y1;
+            unsigned long long pend = __builtin_amdgcn_ballot_w64(hit);
+            while (pend) {                                     // ascending GT index: the first maximum wins
+                const int j = c0 + __builtin_ctzll(pend);
+                pend &= pend - 1;
+                bool any;
+                const float v = iou_gt_box_sweep(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area, any);
+                if (v > best) { best = v; besti = t0 + j; }
+                // this GT's best IoU over all anchors: wave maximum -> one atomicMax per (wave, GT), and only for the few GTs the wave's
+                // 64 neighbouring anchors touch at all (a max is order-independent: deterministic).  A workgroup-level reduction here
+                // cost two barriers per GT and 2/3 of the kernel.
+                if (any) {
+                    float m = v;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                if ((threadIdx.x & 63) == 0) atomicMax(&gt_best[g0 + t0 + j], __float_as_uint(m));   // IoU >= 0: uint order == float order
+                    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                    if (lane == 0) atomicMax(&gt_best[g0 + t0 + j], __float_as_uint(m));   // IoU >= 0: uint order == float order
+                }
             }
         }
     }
     if (av) {
-        match_val[(size_t)b * g.total + a] = (G > 0) ? best : 0.f;
+        match_val[(size_t)b * g.total + a] = best;
         match_idx[(size_t)b * g.total + a] = besti;
     }
 }
@@ -102,28 +139,40 @@ __global__ __launch_bounds__(256) void anchor_label_kernel(const AnchorGeom g, c
     __shared__ float sg[MAXG_TILE][6];
     const int b = blockIdx.y;
     const int a = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
     float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     int lvl, local;
     const bool av = a < g.total;
     if (av) anchor_box(g, a, x1, y1, x2, y2, lvl, local);
     const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+    const WaveBox wb = wave_bounds(x1, y1, x2, y2);
     bool lowq = false;
     for (int t0 = 0; t0 < G; t0 += MAXG_TILE) {
         const int tn = min(MAXG_TILE, G - t0);
         __syncthreads();
+        bool zero_best = false;
         if ((int)threadIdx.x < tn) {
             const float* p = gt_boxes + (size_t)(g0 + t0 + threadIdx.x) * 4;
             sg[threadIdx.x][0] = p[0]; sg[threadIdx.x][1] = p[1]; sg[threadIdx.x][2] = p[2]; sg[threadIdx.x][3] = p[3];
             sg[threadIdx.x][4] = __fmul_rn(__fsub_rn(p[2], p[0]), __fsub_rn(p[3], p[1]));
             sg[threadIdx.x][5] = __uint_as_float(gt_best[g0 + t0 + threadIdx.x]);
+            zero_best = sg[threadIdx.x][5] == 0.f;
         }
-        __syncthreads();
-        if (av)
-            for (int j = 0; j < tn; ++j) {
-                const float v = iou_gt_box(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area);
+        // a GT box that no anchor touches has best IoU 0 and "equals" the IoU 0 of every anchor (the reference marks them all)
+        if (__syncthreads_or(zero_best ? 1 : 0)) lowq = true;
+        for (int c0 = 0; c0 < tn; c0 += 64) {
+            const int jl = c0 + lane;
+            const bool hit = jl < tn && sg[jl][0] < wb.x2 && sg[jl][2] > wb.x1 && sg[jl][1] < wb.y2 && sg[jl][3] > wb.y1;
+            unsigned long long pend = __builtin_amdgcn_ballot_w64(hit);
+            while (pend) {
+                const int j = c0 + __builtin_ctzll(pend);
+                pend &= pend - 1;
+                bool any;
+                const float v = iou_gt_box_sweep(sg[j][0], sg[j][1], sg[j][2], sg[j][3], sg[j][4], x1, y1, x2, y2, area, any);
                 lowq = lowq || (v == sg[j][5]);
             }
+        }
     }
     if (av) {
         signed char l = 0;
