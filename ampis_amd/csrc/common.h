@@ -124,6 +124,19 @@ int roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, const
 int box_candidates_run(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B, int Rcap, int K,
                        const float reg_weights[4], float score_thresh, int img_h, int img_w, const int* img_hw, const float* thresh_img,
                        float* dense_boxes, unsigned long long* keys, int ccap, int* cand_count, int* overflow);
+// conv.hip: the f16x3 split copies of many weight tensors in one launch (weight_jobs_kernel).  chunks_dev: uint2 {job, first pair}, 8192 pairs each
+struct WeightJob {
+    const float* w;               // [N][KH][KW][C] fp32
+    const float* scale;           // transpose = 1: per-n factor (folded FrozenBN) or null
+    unsigned int* out;            // split rows
+    int N, KH, KW, C;
+    int transpose;                // 1: the data-gradient form [C][KH flipped][KW flipped][N], N % 32 == 0; 0: rows of w, (KH*KW*C) % 32 == 0;
+                                  // 2: as 1 through 64 x 64 LDS tiles (N % 64 == 0, C % 64 == 0; chunk = {job, tile})
+};
+int weight_jobs_run(amp_ctx* ctx, const WeightJob* jobs_dev, const void* chunks_dev, int nchunks);
+// train_bwd.hip: amp_sgd_update over a device table of chunks (low 32 bits: offset in floats, a multiple of 4; high 32: length) of the arenas p / g / v
+int sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchunks, float* p, const float* g, float* v, float lr,
+                   float momentum, float weight_decay, float grad_scale);
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
 // only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)

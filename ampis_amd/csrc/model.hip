@@ -23,6 +23,7 @@ struct ConvW {
     float* shift = nullptr;  // device [Cout] or null
     int cout = 0, cin = 0, kh = 0, kw = 0;
     float* w_split = nullptr; // AMP_CONV_F16X3 operand copy of w (amp_split_weights), made at finalize; null: not eligible / out of range
+    float* wt_split = nullptr; // training: split data-gradient form of w (refresh_dgrad_weights, once per step); null: not made
     float w_absmax = 0.f;    // max |w| seen at load (range check of the split copy)
     int groups = 1;          // > 1: w is the window layout [Cout][KH][KW][64] of amp_group_expand_weights (ResNeXt conv2)
 };
@@ -106,6 +107,13 @@ struct amp_model {
     float* rpn_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     struct Trainable { float* p; size_t n; };
     std::vector<Trainable> trainable;
+    unsigned long long* sgd_chunks = nullptr;   // device table for amp::sgd_chunks_run, built at the first amp_model_sgd_step
+    int sgd_nchunks = 0;
+    struct JobTable { amp::WeightJob* jobs = nullptr; void* chunks = nullptr; int nchunks = 0; };
+    JobTable fwd_jobs, dgrad_jobs;              // refresh_split_weights / refresh_dgrad_weights: every layer's split copy in one launch
+    bool fwd_jobs_dirty = true, dgrad_jobs_dirty = true;
+    float* dgrad_arena = nullptr;               // split data-gradient weights (ConvW::wt_split), AMP_CONV_F16X3 training
+    size_t dgrad_floats = 0;
     bool grads_valid = false;
     float* split_arena = nullptr;       // f16x3 operand copies of the weights (inference)
     size_t split_floats = 0;
@@ -741,6 +749,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
 }
 
 int refresh_split_weights(amp_model* m);
+int refresh_dgrad_weights(amp_model* m);
 
 // Training-mode forward + losses. With ws.dry nothing is launched (workspace sizing only).
 int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const amp_gt* gt, unsigned int seed, float losses[5], bool backward) {
@@ -756,6 +765,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // the forward trunk of a training step runs on pre-split operands like inference: refresh the weights' split copies (stale since the
     // last SGD step) once here instead of splitting every layer's weights inside its own launch
     if (!dry && backward && m->split_stale && m->ctx->conv_mode == AMP_CONV_F16X3 && getenv("AMP_NO_TRAIN_NATIVE") == nullptr) AMP_TRY(refresh_split_weights(m));
+    static const bool no_dgrad_batch = getenv("AMP_NO_DGRAD_BATCH") != nullptr;      // EXPERIMENT switch: transpose + split in front of every data-gradient conv
+    const bool dgrad_batch = !dry && backward && !no_dgrad_batch && m->ctx->conv_mode == AMP_CONV_F16X3;
+    if (dgrad_batch) AMP_TRY(refresh_dgrad_weights(m));
     const int trunk_status = run_trunk(m, imgs_d, B, H, W, T);
     m->saving = false;
     AMP_TRY(trunk_status);
@@ -978,10 +990,19 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         return AMP_OK;
     };
+    // the split data-gradient weights of this step (refresh_dgrad_weights) where conv_run would take a split copy: its LDS-DMA kernels,
+    // i.e. operands below 2 GiB (cout % 32 == 0 by construction); null: transpose and split in front of the launch as before
+    auto dgrad_wsplit = [&](const ConvW& cw, int B_, int Hy, int Wy) -> const float* {
+        if (!dgrad_batch || !cw.wt_split) return nullptr;
+        const size_t xb = (size_t)B_ * Hy * Wy * cw.cout * 4, wb = (size_t)cw.cout * cw.kh * cw.kw * cw.cin * 4;
+        return (xb < 0x80000000ull && wb < 0x80000000ull) ? cw.wt_split : nullptr;
+    };
     // dx = conv(dy, flipped/transposed/scaled w) (+ res) (* mask>0); dy is [B_,Hy,Wy,cw.cout]
     auto dgrad = [&](const ConvW& cw, const float* dy, int B_, int Hy, int Wy, int fwd_pad, const float* res, const float* mask, float* dx, bool mask_split = false) -> int {
         AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
-        AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
+        const float* wsp = dgrad_wsplit(cw, B_, Hy, Wy);
+        const float* wt = wsp ? cw.w : wt_scratch;        // with a split copy the fp32 pointer is not read
+        if (!wsp) AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
         amp_conv_desc d;
         d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
         d.relu = 0; d.res_mode = res ? 1 : 0; d.out_mode = 0;
@@ -992,8 +1013,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const long long nblk256 = (((long long)B_ * Hy * Wy + 127) / 128) * (cw.cin / 256);      // conv_run takes the 128 x 256 ring kernel for this
         const bool ring_fits = cw.cin % 256 == 0 && (nblk256 >= 512 || (nblk256 >= 192 && cw.kh * cw.kw * cw.cout / 32 >= 64));
         if (dy == dys_of && !no_reuse && dys_rows == (long long)B_ * Hy * Wy && ring_fits && ctx->conv_mode == AMP_CONV_F16X3)
-            return amp::conv_run(ctx, &d, 1, dys_scratch, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, 1 | ((mask && mask_split) ? 8 : 0));
-        return amp::conv_run(ctx, &d, 1, dy, wt_scratch, nullptr, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
+            return amp::conv_run(ctx, &d, 1, dys_scratch, wt, wsp, 0, nullptr, nullptr, res, mask, dx, 16, 1 | ((mask && mask_split) ? 8 : 0));
+        return amp::conv_run(ctx, &d, 1, dy, wt, wsp, 0, nullptr, nullptr, res, mask, dx, 16, (mask && mask_split) ? 8 : 0);
     };
     // The backbone's chain on SCALED SPLIT gradients (GS): a gradient tensor is kept as the split rows of d * 2^16, so its data-gradient
     // convolution stages both operands by LDS-DMA on the ring kernel (no split, no scaling: the scale rides through the linear chain),
@@ -1002,11 +1023,12 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const bool GS = AS && !no_gs && ctx->conv_mode == AMP_CONV_F16X3;
     auto dgrad_s = [&](const ConvW& cw, const float* dy_s, int B_, int Hy, int Wy, int fwd_pad, const float* res_s, const float* mask_s, float* dx_s) -> int {
         AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
-        AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
+        const float* wsp = dgrad_wsplit(cw, B_, Hy, Wy);
+        if (!wsp) AMP_TRY(amp_dgrad_weights(ctx, cw.w, cw.scale, cw.cout, cw.kh, cw.kw, cw.cin, wt_scratch));
         amp_conv_desc d;
         d.B = B_; d.H = Hy; d.W = Wy; d.Cin = cw.cout; d.Cout = cw.cin; d.KH = cw.kh; d.KW = cw.kw; d.stride = 1; d.pad = cw.kh - 1 - fwd_pad;
         d.relu = 0; d.res_mode = res_s ? 1 : 0; d.out_mode = 0;
-        return amp::conv_run(ctx, &d, 1, dy_s, wt_scratch, nullptr, 0, nullptr, nullptr, res_s, mask_s, dx_s, 0, 1 | 2 | (res_s ? 4 : 0) | (mask_s ? 8 : 0));
+        return amp::conv_run(ctx, &d, 1, dy_s, wsp ? cw.w : wt_scratch, wsp, 0, nullptr, nullptr, res_s, mask_s, dx_s, 0, 1 | 2 | (res_s ? 4 : 0) | (mask_s ? 8 : 0));
     };
 
     // ---- gradient buffers of the FPN outputs p2..p6 ----
@@ -1038,10 +1060,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
             for (int q = 0; q < 4; ++q) AMP_HIP_CHECK(hipMemcpyAsync(GB(cd) + q * 256, dbd_t, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
             // data gradient: a 2x2 stride-2 convolution of d_mtb with w[ci][ky][kx][co], masked by fcn4's ReLU
-            AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
+            const float* wsp = (cd.scale == nullptr && cd.cout == 1024 && cd.cin == 256) ? dgrad_wsplit(cd, N, 28, 28) : nullptr;   // [ci][(tap, co)] = the 2x2 window rows
+            if (!wsp) AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
             amp_conv_desc g;
             g.B = N; g.H = 28; g.W = 28; g.Cin = 256; g.Cout = 256; g.KH = 2; g.KW = 2; g.stride = 2; g.pad = 0; g.relu = 0; g.res_mode = 0; g.out_mode = 0;
-            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16));
+            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16));
         }
         float* dcur = d_ma;
         float* dnext = d_mb;
@@ -1375,6 +1398,9 @@ void amp_model_destroy(amp_model* m) {
     (void)hipFree(m->parena);
     (void)hipFree(m->garena);
     (void)hipFree(m->varena);
+    (void)hipFree(m->sgd_chunks);
+    (void)hipFree(m->fwd_jobs.jobs); (void)hipFree(m->fwd_jobs.chunks); (void)hipFree(m->dgrad_jobs.jobs); (void)hipFree(m->dgrad_jobs.chunks);
+    (void)hipFree(m->dgrad_arena);
     (void)hipFree(m->split_arena);
     (void)hipFree(m->img_stage);
     (void)hipFree(m->ws.base);
@@ -1536,18 +1562,46 @@ int amp_model_load_tensor(amp_model* m, const char* name_c, const float* data, c
 namespace {
 // AMP_CONV_F16X3 operand copies (hi|lo f16 halves, x 2^8): every dense layer with Cin % 32 == 0 whose weights fit the fp16 range.
 // Re-made after the weights change (amp_model_sgd_step marks them stale).
+// device tables of a weight_jobs_kernel launch (common.h WeightJob): built once per set of pointers, one launch per refresh
+int upload_weight_jobs(amp_model::JobTable& t, const std::vector<amp::WeightJob>& jobs) {
+    std::vector<unsigned int> ch;      // uint2 {job, first pair}
+    for (size_t j = 0; j < jobs.size(); ++j) {
+        if (jobs[j].transpose == 2) {     // one chunk per 64 x 64 tile of a tap
+            const size_t ntiles = (size_t)jobs[j].KH * jobs[j].KW * (jobs[j].N / 64) * (jobs[j].C / 64);
+            for (size_t t = 0; t < ntiles; ++t) { ch.push_back((unsigned int)j); ch.push_back((unsigned int)t); }
+            continue;
+        }
+        const size_t npairs = (size_t)jobs[j].N * jobs[j].KH * jobs[j].KW * jobs[j].C / 2;
+        for (size_t p0 = 0; p0 < npairs; p0 += 8192) { ch.push_back((unsigned int)j); ch.push_back((unsigned int)p0); }
+    }
+    if (t.jobs) (void)hipFree(t.jobs);
+    if (t.chunks) (void)hipFree(t.chunks);
+    t.jobs = nullptr; t.chunks = nullptr; t.nchunks = 0;
+    if (jobs.empty()) return AMP_OK;
+    AMP_HIP_CHECK(hipMalloc(&t.jobs, jobs.size() * sizeof(amp::WeightJob)));
+    AMP_HIP_CHECK(hipMalloc(&t.chunks, ch.size() * sizeof(unsigned int)));
+    AMP_HIP_CHECK(hipMemcpy(t.jobs, jobs.data(), jobs.size() * sizeof(amp::WeightJob), hipMemcpyHostToDevice));
+    AMP_HIP_CHECK(hipMemcpy(t.chunks, ch.data(), ch.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
+    t.nchunks = (int)(ch.size() / 2);
+    return AMP_OK;
+}
+
 int refresh_split_weights(amp_model* m) {
-        size_t need = 0;
-        for (auto& kv : m->conv) {
-            const ConvW& cw = kv.second;
-            if ((cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f) need += ((size_t)cw.cout * cw.kh * cw.kw * (cw.groups > 1 ? 64 : cw.cin) + 63) & ~(size_t)63;
-        }
-        if (m->split_floats < need) {
-            if (m->split_arena) AMP_HIP_CHECK(hipFree(m->split_arena));
-            m->split_arena = nullptr; m->split_floats = 0;
-            AMP_HIP_CHECK(hipMalloc(&m->split_arena, need * sizeof(float)));
-            m->split_floats = need;
-        }
+    size_t need = 0;
+    for (auto& kv : m->conv) {
+        const ConvW& cw = kv.second;
+        if ((cw.cin % 32 == 0 || (cw.cin == 4 && cw.kw == 8)) && cw.w_absmax < 60000.f) need += ((size_t)cw.cout * cw.kh * cw.kw * (cw.groups > 1 ? 64 : cw.cin) + 63) & ~(size_t)63;
+    }
+    if (m->split_floats < need) {
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        if (m->split_arena) AMP_HIP_CHECK(hipFree(m->split_arena));
+        m->split_arena = nullptr; m->split_floats = 0;
+        AMP_HIP_CHECK(hipMalloc(&m->split_arena, need * sizeof(float)));
+        m->split_floats = need;
+        m->fwd_jobs_dirty = true;
+    }
+    if (m->fwd_jobs_dirty) {
+        std::vector<amp::WeightJob> jobs;
         size_t off = 0;
         for (auto& kv : m->conv) {
             ConvW& cw = kv.second;
@@ -1557,11 +1611,54 @@ int refresh_split_weights(amp_model* m) {
             const size_t n = (size_t)cw.cout * cw.kh * cw.kw * kin;
             cw.w_split = m->split_arena + off;
             off += (n + 63) & ~(size_t)63;
-            AMP_TRY(amp_split_weights(m->ctx, cw.w, cw.cout, cw.kh * cw.kw * kin, cw.w_split));
+            jobs.push_back(amp::WeightJob{cw.w, nullptr, reinterpret_cast<unsigned int*>(cw.w_split), cw.cout, cw.kh, cw.kw, kin, 0});
         }
-        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));     // the old tables may still be read by a launch in flight
+        AMP_TRY(upload_weight_jobs(m->fwd_jobs, jobs));
+        m->fwd_jobs_dirty = false;
+    }
+    AMP_TRY(amp::weight_jobs_run(m->ctx, m->fwd_jobs.jobs, m->fwd_jobs.chunks, m->fwd_jobs.nchunks));
     m->split_stale = false;
     return AMP_OK;
+}
+
+// AMP_CONV_F16X3 training: the data-gradient form of every weight the backward pass convolves with (flipped, transposed, FrozenBN scale
+// folded in, split) -- once per step in one launch instead of a transpose and a split in front of each of its 63 data-gradient convs.
+int refresh_dgrad_weights(amp_model* m) {
+    auto takes = [](const std::string& key, const ConvW& cw) {
+        if (key.rfind("backbone.bottom_up.stem", 0) == 0 || key.rfind("backbone.bottom_up.res2", 0) == 0) return false;
+        return cw.groups == 1 && cw.cout % 32 == 0 && cw.cin % 4 == 0;
+    };
+    size_t need = 0;
+    for (auto& kv : m->conv)
+        if (takes(kv.first, kv.second)) need += ((size_t)kv.second.cout * kv.second.kh * kv.second.kw * kv.second.cin + 63) & ~(size_t)63;
+    if (m->dgrad_floats < need) {
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        if (m->dgrad_arena) AMP_HIP_CHECK(hipFree(m->dgrad_arena));
+        m->dgrad_arena = nullptr; m->dgrad_floats = 0;
+        AMP_HIP_CHECK(hipMalloc(&m->dgrad_arena, need * sizeof(float)));
+        m->dgrad_floats = need;
+        m->dgrad_jobs_dirty = true;
+    }
+    if (m->dgrad_jobs_dirty) {
+        std::vector<amp::WeightJob> jobs;
+        size_t off = 0;
+        for (auto& kv : m->conv) {
+            ConvW& cw = kv.second;
+            cw.wt_split = nullptr;
+            if (!takes(kv.first, cw)) continue;
+            const size_t n = (size_t)cw.cout * cw.kh * cw.kw * cw.cin;
+            cw.wt_split = m->dgrad_arena + off;
+            off += (n + 63) & ~(size_t)63;
+            // the mask head's deconv is stored as a 1x1 layer with 4 x 256 outputs: same transform
+            jobs.push_back(amp::WeightJob{cw.w, cw.scale, reinterpret_cast<unsigned int*>(cw.wt_split), cw.cout, cw.kh, cw.kw, cw.cin,
+                                          (cw.cout % 64 == 0 && cw.cin % 64 == 0) ? 2 : 1});
+        }
+        AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        AMP_TRY(upload_weight_jobs(m->dgrad_jobs, jobs));
+        m->dgrad_jobs_dirty = false;
+    }
+    return amp::weight_jobs_run(m->ctx, m->dgrad_jobs.jobs, m->dgrad_jobs.chunks, m->dgrad_jobs.nchunks);
 }
 
 }  // namespace
@@ -1616,9 +1713,11 @@ int amp_model_finalize(amp_model* m) {
     AMP_TRY(fuse("proposal_generator.rpn_head.pred", "proposal_generator.rpn_head.objectness_logits",
                  "proposal_generator.rpn_head.anchor_deltas", 3, 12, 256));
     AMP_TRY(fuse("roi_heads.box_predictor", "roi_heads.box_predictor.cls_score", "roi_heads.box_predictor.bbox_pred", K + 1, 4 * K, 1024));
+    m->fwd_jobs_dirty = m->dgrad_jobs_dirty = true;      // eligibility (w_absmax) and the FrozenBN scale pointers are settled here
     AMP_TRY(refresh_split_weights(m));
     // trainable tensors: every conv / fc weight and true bias outside the frozen stem + res2 (FREEZE_AT = 2); FrozenBN has none
     m->trainable.clear();
+    if (m->sgd_chunks) { (void)hipFree(m->sgd_chunks); m->sgd_chunks = nullptr; m->sgd_nchunks = 0; }   // rebuilt by the next amp_model_sgd_step
     for (auto& kv : m->conv) {
         const std::string& key = kv.first;
         if (key.rfind("backbone.bottom_up.stem", 0) == 0 || key.rfind("backbone.bottom_up.res2", 0) == 0) continue;
@@ -1755,8 +1854,21 @@ int amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_deca
     AMP_REQUIRE(m && m->garena && m->varena, "amp_model_sgd_step: the model was created without cfg.train_enable");
     AMP_REQUIRE(m->grads_valid, "amp_model_sgd_step: no gradients (call amp_model_forward_backward first)");
     AMP_TRY(amp::comm_wait_done(m->ctx));    // the gradient exchange (if any) completes before the first update kernel, on the device
-    for (auto& t : m->trainable)
-        AMP_TRY(amp_sgd_update(m->ctx, t.p, m->garena + (t.p - m->parena), m->varena + (t.p - m->parena), t.n, lr, momentum, weight_decay, grad_scale));
+    if (!m->sgd_chunks) {     // one launch for every trainable tensor: chunks of <= 16384 floats of the arena (tensors start 64-float aligned)
+        std::vector<unsigned long long> ch;
+        for (auto& t : m->trainable)
+            for (size_t o = 0; o < t.n; o += 16384) {
+                const size_t off = (size_t)(t.p - m->parena) + o, n = std::min<size_t>(16384, t.n - o);
+                AMP_REQUIRE(off % 4 == 0 && off < (1ull << 32), "amp_model_sgd_step: arena offset out of range");
+                ch.push_back((unsigned long long)off | ((unsigned long long)n << 32));
+            }
+        m->sgd_nchunks = (int)ch.size();
+        if (!ch.empty()) {
+            AMP_HIP_CHECK(hipMalloc(&m->sgd_chunks, ch.size() * sizeof(unsigned long long)));
+            AMP_HIP_CHECK(hipMemcpy(m->sgd_chunks, ch.data(), ch.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
+    }
+    AMP_TRY(amp::sgd_chunks_run(m->ctx, m->sgd_chunks, m->sgd_nchunks, m->parena, m->garena, m->varena, lr, momentum, weight_decay, grad_scale));
     m->grads_valid = false;
     m->split_stale = true;               // the f16x3 operand copies no longer match the weights
     return AMP_OK;

@@ -519,9 +519,47 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
 }
 
+// The same update over a table of chunks of one parameter arena (offset and length in floats, offset % 4 == 0): every trainable tensor
+// of a model in ONE launch instead of one launch per tensor (80 launches whose host-side issue left the GPU idle at the end of a step).
+__global__ __launch_bounds__(256) void sgd_chunks_kernel(const unsigned long long* __restrict__ chunks, float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ v, float lr, float mu, float wd, float gscale) {
+    const unsigned long long ch = chunks[blockIdx.x];
+    const size_t off = (size_t)(ch & 0xffffffffull);
+    const int n = (int)(ch >> 32), n4 = n >> 2;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p + off);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + off);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v + off);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        f32x4 pi = p4[i], vi = v4[i];
+        const f32x4 gi = g4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = __fadd_rn(__fmul_rn(gi[e], gscale), __fmul_rn(wd, pi[e]));
+            vi[e] = __fadd_rn(__fmul_rn(mu, vi[e]), ge);
+            pi[e] = __fsub_rn(pi[e], __fmul_rn(lr, vi[e]));
+        }
+        v4[i] = vi; p4[i] = pi;
+    }
+    const int i = 4 * n4 + (int)threadIdx.x;
+    if (i < n) {
+        const float ge = __fadd_rn(__fmul_rn(g[off + i], gscale), __fmul_rn(wd, p[off + i]));
+        const float ve = __fadd_rn(__fmul_rn(mu, v[off + i]), ge);
+        v[off + i] = ve;
+        p[off + i] = __fsub_rn(p[off + i], __fmul_rn(lr, ve));
+    }
+}
+
 inline unsigned grid_for(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 4096); }
 
 }  // namespace
+
+int amp::sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchunks, float* p, const float* g, float* v, float lr,
+                        float momentum, float weight_decay, float grad_scale) {
+    if (nchunks <= 0) return AMP_OK;
+    hipLaunchKernelGGL(sgd_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, chunks_dev, p, g, v, lr, momentum, weight_decay, grad_scale);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
 
 static int g_roi_bwd_atomics = 0;     // tests: 1 = the float-atomic kernel
 extern "C" void amp_debug_set_roi_bwd_atomics(int v) { g_roi_bwd_atomics = v; }
