@@ -126,11 +126,19 @@ TRAIN_BATCH = 16
 PROFILE_DIRS = ("r02", "r01")      # committed rocprofv3 --pmc summaries (tools/profile_round.sh): newest first
 
 
-def pmc_traffic(kernel_keys):
-    """HBM bytes per launch of the first of `kernel_keys` found in the committed PMC summaries (profiles/rNN/pmc_summary*.json)."""
+def pmc_traffic(kernel_keys, leg="infer"):
+    """HBM bytes per launch of the first of `kernel_keys` found in the committed PMC summaries of this leg's own command
+    (profiles/rNN/pmc_summary_vK.json: the inference bench; pmc_summary_train_vK.json: the training leg), newest version first."""
     import glob
+    import re
+
+    def version(f):
+        m = re.search(r"_v(\d+)\.json$", f)
+        return int(m.group(1)) if m else -1
+
     for d in PROFILE_DIRS:
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")), key=os.path.getmtime, reverse=True):
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")) if ("_train_" in os.path.basename(f)) == (leg == "train")]
+        for f in sorted(files, key=version, reverse=True):
             try:
                 k = json.load(open(f))["kernels"]
             except Exception:
@@ -233,7 +241,7 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
     wg_ms, wg_fl, wg_n = prof["ms"][2], prof["flops"][2], prof["launches"][2]
     ach = wg_fl / (wg_ms * 1e-3) / 1e12 if wg_ms > 0 else 0.0
     kname = "wgrad_split_kernel + wgrad_f16x3_kernel" if f16 else "wgrad_mfma_kernel"
-    traffic, traffic_src, traffic_key = pmc_traffic(["wgrad_split_kernel", "wgrad_f16x3_kernel"] if f16 else [kname])
+    traffic, traffic_src, traffic_key = pmc_traffic(["wgrad_split_kernel", "wgrad_f16x3_kernel"] if f16 else [kname], leg="train")
     conv_ms = prof["ms"][0] + prof["ms"][1]
     out = {"metric": "images/sec Mask R-CNN R50-FPN @1024x1024 training (fwd + losses + bwd + all-reduce + SGD)",
            "value": round(world * TRAIN_BATCH * steps / el, 3), "unit": "images/s", "ms_per_step": round(el / steps * 1e3, 2),
