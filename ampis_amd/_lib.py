@@ -114,6 +114,7 @@ def _declare(L):
         "amp_conv2d_wgrad_scaled": ([vp, C.POINTER(ConvDesc), vp, vp, vp, vp, vp, i, i, i], i),
         "amp_colsum": ([vp, vp, i, i, vp, vp, i], i),
         "amp_dgrad_weights": ([vp, vp, vp, i, i, i, i, vp], i),
+        "amp_dgrad_weights_split": ([vp, vp, vp, i, i, i, i, vp], i),
         "amp_preprocess": ([vp, vp, i, i, i, i, i, C.POINTER(f), C.POINTER(f), vp, vp], i),
         "amp_model_set_image_sizes": ([vp, vp, i], i),
         "amp_maxpool3x3s2": ([vp, vp, i, i, i, i, vp], i),

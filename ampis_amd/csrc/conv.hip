@@ -1813,6 +1813,35 @@ int amp::weight_jobs_run(amp_ctx* ctx, const amp::WeightJob* jobs_dev, const voi
     return AMP_OK;
 }
 
+/* The split data-gradient form of one weight tensor: wt_split = split rows (amp_split_weights) of Wt[c][KH-1-ky][KW-1-kx][n] =
+ * w[n][ky][kx][c] * scale[n] (amp_dgrad_weights), bit for bit, in one pass.  Cout % 32 == 0.  A training step of the model makes these
+ * for all its layers in one launch (weight_jobs_kernel); this entry runs the same kernel on one tensor (it allocates its two small
+ * tables per call: for tests and bindings, not for a hot loop). */
+extern "C" int amp_dgrad_weights_split(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt_split) {
+    AMP_REQUIRE(ctx && w && wt_split && Cout > 0 && KH > 0 && KW > 0 && Cin > 0 && Cout % 32 == 0, "amp_dgrad_weights_split: bad argument (Cout %% 32 != 0?)");
+    amp::WeightJob job{w, scale, reinterpret_cast<unsigned int*>(wt_split), Cout, KH, KW, Cin, (Cout % 64 == 0 && Cin % 64 == 0) ? 2 : 1};
+    std::vector<unsigned int> ch;
+    if (job.transpose == 2) {
+        const size_t ntiles = (size_t)KH * KW * (Cout / 64) * (Cin / 64);
+        for (size_t t = 0; t < ntiles; ++t) { ch.push_back(0u); ch.push_back((unsigned int)t); }
+    } else {
+        const size_t npairs = (size_t)Cout * KH * KW * Cin / 2;
+        for (size_t p0 = 0; p0 < npairs; p0 += 8192) { ch.push_back(0u); ch.push_back((unsigned int)p0); }
+    }
+    amp::WeightJob* d_job = nullptr;
+    unsigned int* d_ch = nullptr;
+    AMP_HIP_CHECK(hipMalloc(&d_job, sizeof(job)));
+    if (hipMalloc(&d_ch, ch.size() * sizeof(unsigned int)) != hipSuccess) { (void)hipFree(d_job); AMP_REQUIRE(false, "amp_dgrad_weights_split: out of device memory"); }
+    int st = AMP_OK;
+    if (hipMemcpy(d_job, &job, sizeof(job), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ch, ch.data(), ch.size() * sizeof(unsigned int), hipMemcpyHostToDevice) != hipSuccess) st = AMP_ERR_HIP;
+    if (st == AMP_OK) st = amp::weight_jobs_run(ctx, d_job, d_ch, (int)(ch.size() / 2));
+    if (st == AMP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = AMP_ERR_HIP;     // the tables are freed below
+    (void)hipFree(d_job);
+    (void)hipFree(d_ch);
+    return st;
+}
+
 extern "C" int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, int K, float* w_split) {
     AMP_REQUIRE(ctx && w && w_split && rows > 0 && K > 0 && K % 32 == 0, "amp_split_weights: bad argument (K %% 32 != 0?)");
     hipLaunchKernelGGL(split_weights_kernel, dim3(2048), dim3(256), 0, ctx->stream, w, (size_t)rows, K, reinterpret_cast<unsigned int*>(w_split));

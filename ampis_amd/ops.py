@@ -130,6 +130,14 @@ def dgrad_weights(ctx, w, scale=None):
     return wt
 
 
+def dgrad_weights_split(ctx, w, scale=None):
+    """the data-gradient form of w in the split row format, in one pass (= split_rows(dgrad_weights(w, scale)) bit for bit)."""
+    Cout, KH, KW, Cin = w.shape
+    wt = torch.empty((Cin, KH, KW, Cout), device=w.device)
+    check(lib().amp_dgrad_weights_split(ctx.handle, ptr(_f32c(w)), ptr(scale), Cout, KH, KW, Cin, ptr(wt)), "amp_dgrad_weights_split")
+    return wt
+
+
 def colsum(ctx, dy):
     M, N = dy.shape
     scratch = torch.empty(((M + 511) // 512 + 1) * N, device=dy.device)

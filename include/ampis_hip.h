@@ -156,6 +156,9 @@ int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, floa
 int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate, float* dy_split, int shift);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
+/* the same tensor already in the AMP_CONV_F16X3 split row format (= amp_split_weights of amp_dgrad_weights' result, bit for bit, in one
+ * pass; Cout % 32 == 0): what a training step of amp_model makes for all its layers in one launch.  Allocates two small tables per call. */
+int amp_dgrad_weights_split(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt_split);
 /* dfeat[level] += RoIAlign-backward(dout [R,P,P,C]).  C == 256: owner-computes, no atomics -- every 4x4 tile of a gradient map is
  * summed by one wave over the RoIs in index order: bitwise reproducible.  Other C: float atomics (reproducible to fp32 rounding).
  * _batched: B = number of images (maps are [B,h,w,C]); amp_roi_align_bwd derives it from batch_idx (one small read-back). */

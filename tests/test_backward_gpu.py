@@ -215,3 +215,17 @@ def test_fullsize_step_f16x3_storage_paths_agree_with_fp32_mode():
         assert np.array_equal(m.get_tensor(k, grad=True), out["f16x3"][1][k]), k
     m.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("shape,scaled", [((256, 3, 3, 128), True), ((1024, 1, 1, 256), False), ((96, 3, 3, 36), True), ((64, 1, 1, 12544), True)])
+def test_dgrad_weights_split_is_transpose_then_split(gpu_ctx, shape, scaled):
+    """One pass (LDS-tiled where both channel counts are multiples of 64, pairwise otherwise) against the two passes it replaces in a
+    training step -- amp_dgrad_weights then amp_split_weights: the same bytes."""
+    from ampis_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    w = (torch.randn(shape, generator=g) * 0.05).cuda()
+    scale = (torch.rand(shape[0], generator=g) + 0.5).cuda() if scaled else None
+    two = ops.split_rows(gpu_ctx, ops.dgrad_weights(gpu_ctx, w, scale))
+    one = ops.dgrad_weights_split(gpu_ctx, w, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32))

@@ -163,3 +163,57 @@ def test_losses_other_class_counts(gpu_ctx, K):
     model.close()
     for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
         assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
+
+
+@pytest.mark.parametrize("case", ["untouched_gt", "two_lds_tiles", "no_gt_image"])
+def test_anchor_labels_edge_cases(gpu_ctx, case):
+    """amp_anchor_labels through the C ABI against the oracle's pairwise_iou + Matcher on the cases the sweep's culling must not change
+    (the kernel evaluates only GT boxes that overlap a wave's bounding box): a GT box no anchor touches and a zero-area one -- their best
+    IoU is 0, which "equals" the IoU 0 of EVERY anchor, so set_low_quality_matches_ marks them all (detectron2 matcher.py semantics) --,
+    more than 256 GT boxes (two LDS tiles), and an image without GT between two that have some."""
+    import ctypes as C
+    from ampis_amd import _lib, ops
+    from oracle import maskrcnn as M, train as T
+    rng = np.random.default_rng(3)
+    shapes = [(64, 80), (32, 40), (16, 20), (8, 10), (4, 5)]
+    H, W = 256, 320
+
+    def boxes(n):
+        c = rng.uniform([0, 0], [W, H], size=(n, 2)); s = rng.uniform(6, 120, size=(n, 2))
+        return np.concatenate([np.clip(c - s / 2, 0, None), np.minimum(c + s / 2, [W, H])], axis=1).astype(np.float32)
+
+    if case == "untouched_gt":
+        per_image = [np.concatenate([boxes(20), np.array([[5000, 5000, 5100, 5100], [40, 40, 40, 90]], np.float32)]), boxes(7)]
+    elif case == "two_lds_tiles":
+        per_image = [boxes(300), boxes(257)]
+    else:
+        per_image = [boxes(12), np.zeros((0, 4), np.float32), boxes(5)]
+    B = len(per_image)
+    anchors = torch.cat([M.grid_anchors(h, w, M.STRIDES[l], M.ANCHOR_SIZES[l]) for l, (h, w) in enumerate(shapes)])
+    A = anchors.shape[0]
+    gt_all = np.concatenate(per_image).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in per_image])]).astype(np.int32)
+    dev = "cuda:0"
+    d_gt = torch.from_numpy(gt_all if len(gt_all) else np.zeros((1, 4), np.float32)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    dummy = [torch.zeros((B, h * w, 16), device=dev) for h, w in shapes]
+    lv = ops.make_rpn_levels(dummy, shapes)
+    mv = torch.empty((B, A), device=dev); mi = torch.empty((B, A), dtype=torch.int32, device=dev)
+    best = torch.zeros((max(len(gt_all), 1),), dtype=torch.int32, device=dev)
+    lab = torch.empty((B, A), dtype=torch.int8, device=dev)
+    ops.check(_lib.lib().amp_anchor_labels(gpu_ctx.handle, C.byref(lv), B, ops.ptr(d_gt), ops.ptr(d_off), int(len(gt_all)), 0.3, 0.7,
+                                           ops.ptr(mv), ops.ptr(mi), ops.ptr(best), ops.ptr(lab)), "amp_anchor_labels")
+    torch.cuda.synchronize()
+    for b in range(B):
+        gtb = torch.from_numpy(per_image[b])
+        if len(gtb) == 0:
+            assert int(lab[b].abs().sum()) == 0 and float(mv[b].abs().sum()) == 0.0
+            continue
+        mq = T.pairwise_iou(gtb, anchors)
+        matches, ml = T.matcher(mq, (0.3, 0.7), (0, -1, 1), True)
+        assert np.array_equal(lab[b].cpu().numpy(), ml.numpy()), case
+        assert np.array_equal(mv[b].cpu().numpy(), mq.max(dim=0)[0].numpy())
+        assert np.array_equal(mi[b].cpu().numpy(), matches.numpy().astype(np.int32))
+        assert np.array_equal(best[off[b]:off[b + 1]].cpu().numpy().view(np.float32), mq.max(dim=1)[0].numpy())
+    if case == "untouched_gt":
+        assert int((lab[0] == 1).sum()) == A and int((lab[1] == 1).sum()) < A
