@@ -1929,6 +1929,14 @@ extern "C" int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int
     return conv_impl(ctx, d, groups, x, w_win, scale, shift, res, nullptr, y);
 }
 
+// the same with split-format tensors (AMP_CONV_F16X3; fmt as in amp_conv2d_nhwc_fmt: bit 0 x, bit 1 y, bit 2 res)
+extern "C" int amp_conv2d_grouped_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
+                                           const float* scale, const float* shift, const float* res, float* y, int fmt) {
+    AMP_REQUIRE(d && groups >= 1 && fmt >= 0 && fmt < 8, "amp_conv2d_grouped_nhwc_fmt: bad argument");
+    AMP_REQUIRE(fmt == 0 || (ctx && ctx->conv_mode == AMP_CONV_F16X3), "amp_conv2d_grouped_nhwc_fmt: split formats exist in AMP_CONV_F16X3 only");
+    return amp::conv_run(ctx, d, groups, x, w_win, nullptr, 0, scale, shift, res, nullptr, y, 0, fmt);
+}
+
 namespace {
 __global__ void group_expand_kernel(const float* __restrict__ w, int Cout, int taps, int cpg, float* __restrict__ out) {
     const size_t total = (size_t)Cout * taps * 64;
@@ -2049,8 +2057,8 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
-    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && !a.grouped && glds),
-                "conv: a split-format input needs AMP_CONV_F16X3, Cin %% 32 == 0, a dense layer and operands below 2 GiB");
+    AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && glds),
+                "conv: a split-format input needs AMP_CONV_F16X3, Cin %% 32 == 0 and operands below 2 GiB");
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
     a.out_scale = (in_shift != 0) ? ldexpf(1.0f, -in_shift) : 1.0f;
     if (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && g_conv_ablate == 0 && (glds || stem)) {
@@ -2085,17 +2093,17 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-        } else if (x_is_split && g_split_ring && epi != 0 && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {
+        } else if (x_is_split && g_split_ring && epi != 0 && !a.grouped && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {
             a.ntn = a.Cout / 128; a.nblk = ntm256 * a.ntn;                  // Cout = 128 (or 384, ...): 256 x 128 tiles
             launch_split<256, 128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split) {      // both operands by LDS-DMA
             if (wide256) {
                 a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
                 launch_f16x3s<256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-            } else if (a.Cout > 64 && nblk128 >= 512) {
+            } else if (!a.grouped && a.Cout > 64 && nblk128 >= 512) {
                 a.ntn = amp::cdiv(a.Cout, 128); a.nblk = ntm * a.ntn;
                 launch_f16x3s<128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-            } else {
+            } else {    // (grouped: the window of a 64-wide N tile is the tile's own 64 input channels = 256 B of a split row too)
                 a.ntn = amp::cdiv(a.Cout, 64); a.nblk = ntm * a.ntn;
                 launch_f16x3s<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
             }

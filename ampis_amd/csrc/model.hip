@@ -277,8 +277,8 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     }
     // AMP_CONV_F16X3 inference: from the max-pool on, every activation of the trunk lives in the split hi|lo' row format (same bytes,
     // same row offsets as fp32): each conv epilogue writes it, the next conv stages it by LDS-DMA without splitting anything, and
-    // residual / FPN top-down adds and RoIAlign decode it exactly (hi + lo' * 2^-11).  A conv that cannot read the format (grouped
-    // 3x3 of ResNeXt, weights beyond the fp16 range) gets an fp32 input from its producer.  Training keeps fp32 activations: the
+    // residual / FPN top-down adds and RoIAlign decode it exactly (hi + lo' * 2^-11).  A conv that cannot read the format (weights
+    // beyond the fp16 range) gets an fp32 input from its producer.  Training keeps fp32 activations: the
     // backward kernels read them.
     // Training (m->saving): the saved activations stay in the format too when EVERY trunk conv reads it (R50 / R101) -- the backward
     // kernels take them as they are (wgrad x_split, AMP_FMT_MASK_SPLIT, amp_relu_mask_split) -- otherwise the trunk keeps fp32.
@@ -287,7 +287,8 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     auto reads_split = [&](const std::string& key) {
         if (!native) return false;
         auto it = m->conv.find(key);
-        return it != m->conv.end() && it->second.w_split != nullptr && it->second.groups == 1 && it->second.cin % 32 == 0;
+        static const bool no_grouped_split = getenv("AMP_NO_GROUPED_SPLIT") != nullptr;      // EXPERIMENT switch: ResNeXt conv2 takes fp32 input
+        return it != m->conv.end() && it->second.w_split != nullptr && (it->second.groups == 1 || (!m->saving && !no_grouped_split)) && it->second.cin % 32 == 0;
     };
     bool native_all = native;          // every dense conv of backbone / FPN / RPN can read the format
     if (native)

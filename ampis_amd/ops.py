@@ -74,8 +74,9 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
     return y
 
 
-def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, stride=1, pad=0, relu=False):
-    """Grouped conv (ResNeXt conv2): x [B,H,W,C], w [C,KH,KW,C/groups] (grouped OHWI) -> y [B,Ho,Wo,C]."""
+def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, fmt=0):
+    """Grouped conv (ResNeXt conv2): x [B,H,W,C], w [C,KH,KW,C/groups] (grouped OHWI) -> y [B,Ho,Wo,C].
+    fmt: FMT_* bits (split-format x / y / res, AMP_CONV_F16X3 only)."""
     _f32c(x), _f32c(w), _f32c(scale), _f32c(shift), _f32c(res)
     B, H, W, Cin = x.shape
     Cout, KH, KW, cpg = w.shape
@@ -86,6 +87,10 @@ def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, str
     Wo = (W + 2 * pad - KW) // stride + 1
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), 0 if res is None else 1, 0)
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    if fmt:
+        check(lib().amp_conv2d_grouped_nhwc_fmt(ctx.handle, C.byref(d), int(groups), ptr(x), ptr(w_win), ptr(scale), ptr(shift), ptr(res), ptr(y), int(fmt)),
+              "amp_conv2d_grouped_nhwc_fmt")
+        return y
     check(lib().amp_conv2d_grouped_nhwc(ctx.handle, C.byref(d), int(groups), ptr(x), ptr(w_win), ptr(scale), ptr(shift), ptr(res), ptr(y)),
           "amp_conv2d_grouped_nhwc")
     return y

@@ -118,6 +118,10 @@ int amp_conv2d_nhwc(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const 
 int amp_group_expand_weights(amp_ctx* ctx, const float* w, int Cout, int KH, int KW, int cpg, float* w_win);
 int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
                             const float* scale, const float* shift, const float* res, float* y);
+/* the same on split-format tensors (AMP_CONV_F16X3; fmt: AMP_FMT_* bits as in amp_conv2d_nhwc_fmt): the 64-channel window of an N tile
+ * is 256 B of a split row as it is of an fp32 row, so a ResNeXt trunk stays in the format through its grouped layers */
+int amp_conv2d_grouped_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
+                                const float* scale, const float* shift, const float* res, float* y, int fmt);
 /* same, with an optional mask tensor indexed like y: y = mask > 0 ? y : 0 (applied last; the ReLU backward of a data gradient) */
 int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                        const float* res, const float* mask, float* y);

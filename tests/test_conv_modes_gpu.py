@@ -460,6 +460,29 @@ def _lib_set_ring(v):
     _lib.lib().amp_debug_set_split_ring(int(v))
 
 
+@pytest.mark.parametrize("case", [(2, 20, 24, 256, 32, 1), (1, 17, 19, 512, 32, 2), (1, 12, 12, 1024, 32, 2), (2, 9, 9, 128, 2, 1)])
+def test_grouped_conv_reads_and_writes_the_split_format(gpu_ctx, case):
+    """ResNeXt conv2 on a split-format input (amp_conv2d_grouped_nhwc_fmt): the 64-channel window of an N tile is the same 256 B of a
+    split row; the result equals the grouped convolution that splits the fp32 tensor in the kernel, bit for bit, as fp32 and as split output."""
+    from ampis_amd import ops
+    B, H, W, Cw, groups, stride = case
+    g = torch.Generator().manual_seed(7 * Cw + stride)
+    cpg = Cw // groups
+    d = "cuda:0"
+    x = (torch.randn(B, H, W, Cw, generator=g) * 2).to(d)
+    w = (torch.randn(Cw, 3, 3, cpg, generator=g) * (2.0 / (9 * cpg)) ** 0.5).to(d)
+    sc, sh = (torch.rand(Cw, generator=g) + 0.5).to(d), torch.randn(Cw, generator=g).to(d)
+    xs = ops.split_rows(gpu_ctx, x)                     # what the producer (conv1's epilogue) writes for the fp32 value x
+    legacy = ops.conv2d_grouped_nhwc(gpu_ctx, x, w, groups, sc, sh, stride=stride, pad=1, relu=True)      # splits x in the kernel: the same (hi, lo')
+    y_plain = ops.conv2d_grouped_nhwc(gpu_ctx, xs, w, groups, sc, sh, stride=stride, pad=1, relu=True, fmt=ops.FMT_X_SPLIT)
+    y_split = ops.conv2d_grouped_nhwc(gpu_ctx, xs, w, groups, sc, sh, stride=stride, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+    torch.cuda.synchronize()
+    assert legacy.abs().max() > 0
+    assert torch.equal(y_plain, legacy)
+    assert torch.equal(y_split, ops.split_rows(gpu_ctx, legacy))
+    assert not gpu_ctx.conv_range_flag()
+
+
 @pytest.mark.parametrize("C,P", [(256, 7), (256, 14), (64, 7)])
 def test_roi_align_reads_and_writes_the_split_format(gpu_ctx, C, P):
     """RoIAlign on split-row feature maps (the trunk's native format) == RoIAlign on the decoded fp32 maps, bit for bit, with fp32 and
