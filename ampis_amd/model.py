@@ -26,12 +26,18 @@ class PackedGt:
         total = int(off[B])
         boxes = np.ascontiguousarray(np.concatenate([np.asarray(g["boxes"], np.float32).reshape(-1, 4) for g in gt]) if total else np.zeros((0, 4), np.float32))
         classes = np.ascontiguousarray(np.concatenate([np.asarray(g["classes"], np.int32).reshape(-1) for g in gt]) if total else np.zeros(0, np.int32), dtype=np.int32)
-        polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
-        assert len(polys) == total, "one polygon per instance"
         poff = np.zeros(total + 1, dtype=np.int32)
-        if total:
-            poff[1:] = np.cumsum([len(p) for p in polys])
-        pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
+        if total and all("poly_flat" in g and len(g["poly_len"]) == len(g["boxes"]) for g in gt):
+            # the mapper's transform left every image's polygons as one flat array already (data.transform_parsed)
+            poff[1:] = np.cumsum(np.concatenate([np.asarray(g["poly_len"], np.int64) for g in gt]))
+            pxy = np.ascontiguousarray(np.concatenate([np.asarray(g["poly_flat"], np.float64).reshape(-1) for g in gt]))
+            assert int(poff[-1]) == len(pxy), "poly_len does not add up to poly_flat"
+        else:
+            polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
+            assert len(polys) == total, "one polygon per instance"
+            if total:
+                poff[1:] = np.cumsum([len(p) for p in polys])
+            pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
         self.B, self.total = B, total
         self._keep = (off, boxes, classes, poff, pxy)
         self.struct = Gt(B, off.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(C.POINTER(C.c_float)),

@@ -51,6 +51,39 @@ def _register(n=7):
     DatasetCatalog.register("cpu_Train", lambda: dd)
 
 
+def test_vectorised_annotation_transform_equals_the_per_instance_form():
+    """transform_annotations handles all instances of an image in a few array operations (and the mapper parses a dataset dict once);
+    values must equal the per-instance statement of detectron2's transform bit for bit: XYWH boxes, crowd instances, boxes that
+    collapse after clipping, flips, anisotropic scales -- and PackedGt must flatten both forms to the same amp_gt arrays."""
+    from ampis_amd import data, synth
+    from ampis_amd.model import PackedGt
+    _, gt = synth.micrograph(3, 512, 512)
+    annos = [{"bbox": [float(v) for v in b], "bbox_mode": 0, "segmentation": [[float(v) for v in p]], "category_id": i % 3}
+             for i, (b, p) in enumerate(zip(gt["boxes"], gt["polygons"]))]
+    assert len(annos) > 50
+    annos[5]["bbox_mode"] = 1
+    annos[5]["bbox"][2] -= annos[5]["bbox"][0]; annos[5]["bbox"][3] -= annos[5]["bbox"][1]
+    annos[7]["iscrowd"] = 1
+    annos[9]["bbox"] = [10.0, 10.0, 10.0, 50.0]            # empty: dropped with its polygon
+    annos[11]["bbox"] = [600.0, 20.0, 700.0, 90.0]         # outside the frame after clipping
+    parsed = data.parse_annotations(annos)
+    for flip in (False, True):
+        for sx, sy, W, H in ((1.0, 1.0, 512, 512), (0.78125, 0.78125, 400, 400), (1.3, 0.7, 666, 358)):
+            ref = data._transform_annotations_loop(annos, sx, sy, flip, W, H)
+            for got in (data.transform_annotations(annos, sx, sy, flip, W, H), data.transform_parsed(parsed, sx, sy, flip, W, H)):
+                assert got["boxes"].dtype == np.float32 and got["classes"].dtype == np.int64
+                assert np.array_equal(got["boxes"], ref["boxes"]) and np.array_equal(got["classes"], ref["classes"])
+                assert len(got["polygons"]) == len(ref["polygons"]) == len(ref["boxes"]) < len(annos) - 1
+                assert all(np.array_equal(a, b) for a, b in zip(got["polygons"], ref["polygons"]))
+                a, b = PackedGt([got, got]), PackedGt([ref, ref])
+                assert all(np.array_equal(x, y) for x, y in zip(a._keep, b._keep))
+    odd = [dict(annos[0], segmentation=[[1.0, 2.0, 3.0]])]  # a dangling coordinate: the per-instance form decides
+    assert data.parse_annotations(odd) is None
+    got, ref = data.transform_annotations(odd, 0.5, 0.5, False, 512, 512), data._transform_annotations_loop(odd, 0.5, 0.5, False, 512, 512)
+    assert len(got["polygons"]) == len(ref["polygons"]) == 1 and np.array_equal(got["polygons"][0], ref["polygons"][0]) and np.array_equal(got["boxes"], ref["boxes"])
+    assert data.transform_annotations([], 1.0, 1.0, False, 8, 8)["boxes"].shape == (0, 4)
+
+
 def test_train_loader_shards_the_same_stream():
     from ampis_amd.config import get_cfg
     from ampis_amd.data import DatasetCatalog, build_detection_train_loader
