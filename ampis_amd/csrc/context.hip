@@ -171,6 +171,7 @@ int amp_free(amp_ctx* ctx, void* p) {
 
 int amp_memcpy_h2d(amp_ctx* ctx, void* dst, const void* src_h, size_t bytes) {
     AMP_REQUIRE(ctx && dst && src_h, "amp_memcpy_h2d: null argument");
+    AMP_HIP_CHECK(hipSetDevice(ctx->device));      // callable from any host thread (the train loader uploads from its collating thread)
     AMP_HIP_CHECK(hipMemcpyAsync(dst, src_h, bytes, hipMemcpyHostToDevice, ctx->stream));
     AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return AMP_OK;
@@ -178,6 +179,7 @@ int amp_memcpy_h2d(amp_ctx* ctx, void* dst, const void* src_h, size_t bytes) {
 
 int amp_memcpy_d2h(amp_ctx* ctx, void* dst_h, const void* src, size_t bytes) {
     AMP_REQUIRE(ctx && dst_h && src, "amp_memcpy_d2h: null argument");
+    AMP_HIP_CHECK(hipSetDevice(ctx->device));
     AMP_HIP_CHECK(hipMemcpyAsync(dst_h, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return AMP_OK;

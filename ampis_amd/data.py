@@ -221,11 +221,13 @@ def build_detection_test_loader(cfg, dataset_name, mapper=None):
     return _Loader()
 
 
-def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0):
+def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0, upload=None):
     """Infinite iterator of per-rank batches (lists of mapped dicts). TrainingSampler semantics: an infinite stream of seeded
     shuffles of the dataset indices, rank r takes elements r, r+world, ...; IMS_PER_BATCH is the GLOBAL batch.  MIN_SIZE_TRAIN is
     drawn per image, as detectron2's ResizeShortestEdge does; a batch of differently sized images is stacked top-left into a common
-    frame with its per-image sizes (TrainModel.stack, amp_model_set_image_sizes)."""
+    frame with its per-image sizes (TrainModel.stack, amp_model_set_image_sizes).
+    upload (optional, used with NUM_WORKERS > 0): callable(stacked uint8 frame) -> (device pointer, (B, H, W)); the collating thread
+    calls it, so a batch reaches the training thread already in HBM (`CollatedBatch.device`)."""
     names = cfg.DATASETS.TRAIN
     dicts = [d for n in names for d in DatasetCatalog.get(n)]
     dicts = [d for d in dicts if len(d.get("annotations", [])) > 0]       # FILTER_EMPTY_ANNOTATIONS
@@ -255,24 +257,30 @@ def build_detection_train_loader(cfg, mapper=None, rank=0, world_size=1, seed=0)
     workers = int(cfg.DATALOADER.get("NUM_WORKERS", 0)) if "DATALOADER" in cfg else 0
     if workers <= 0 or not hasattr(mapper, "apply"):
         return ([mapper.apply(*t) if hasattr(mapper, "apply") else mapper(t[0]) for t in plan] for plan in plans())
-    return _prefetched(plans(), mapper, workers)
+    return _prefetched(plans(), mapper, workers, upload=upload)
 
 
 class CollatedBatch(list):
     """A batch (list of mapped dicts, what `model(batch)` takes) that also carries its stacked frame, per-image sizes and flattened
     annotations, prepared off the training thread."""
     collated = None
+    device = None      # (device pointer, (B, H, W)) of the stacked frame when the loader was given an `upload` callable
 
 
-def _collate(futures):
+def _collate(futures, upload=None):
     batch = CollatedBatch(f.result() for f in futures)
     if all("gt" in d for d in batch):
         from .engine.defaults import TrainModel
         batch.collated = TrainModel.collate(batch)
+        if upload is not None:
+            batch.device = upload(batch.collated[0])
     return batch
 
 
-def _prefetched(plans, mapper, workers, depth=3):
+PREFETCH_DEPTH = 3
+
+
+def _prefetched(plans, mapper, workers, depth=PREFETCH_DEPTH, upload=None):
     """DATALOADER.NUM_WORKERS threads decode / resize / transform the images of the next `depth` batches while the GPU trains on the
     current one (detectron2 uses worker processes; PIL and numpy release the GIL for the heavy parts).  Order and content are exactly
     those of the sequential loader: every random choice was drawn by the producer before the work was handed out."""
@@ -287,7 +295,7 @@ def _prefetched(plans, mapper, workers, depth=3):
     def produce():
         try:
             for plan in plans:
-                futs = collator.submit(_collate, [pool.submit(mapper.apply, *t) for t in plan])
+                futs = collator.submit(_collate, [pool.submit(mapper.apply, *t) for t in plan], upload)
                 while not stop.is_set():
                     try:
                         q.put(futs, timeout=0.2)

@@ -186,7 +186,41 @@ class TrainModel:
         if seed is None:
             self._seed += 1
             seed = 0x5EED0000 + self._seed
+        dev = getattr(batch, "device", None)          # the loader's collating thread has put the frame into HBM already (_Uploader)
+        if dev is not None:
+            return self.net.forward_losses(None, gt, seed=seed, backward=backward, device_ptr=dev[0], shape=dev[1])
         return self.net.forward_losses(imgs, gt, seed=seed, backward=backward)
+
+
+class _Uploader:
+    """H2D of the next batches off the training thread: a context of its own (its own HIP stream, non-blocking) and a ring of device
+    buffers; the train loader's collating thread calls it, the training thread passes the pointer to amp_model_forward_backward.
+    The copy is complete (stream-synchronised) when __call__ returns, so the compute stream needs no event.  A buffer is re-used after
+    `nbuf` batches: the loader holds at most PREFETCH_DEPTH finished batches plus the one being collated, the trainer one."""
+
+    def __init__(self, device, nbuf):
+        self.ctx = _lib.Context(device)
+        self.bufs = [(0, 0)] * nbuf       # (pointer, bytes)
+        self.k = 0
+
+    def __call__(self, imgs):
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        ptr, cap = self.bufs[self.k]
+        if cap < imgs.nbytes:
+            if ptr:
+                self.ctx.free(ptr)
+            ptr, cap = self.ctx.malloc(imgs.nbytes), imgs.nbytes
+            self.bufs[self.k] = (ptr, cap)
+        self.ctx.h2d(ptr, imgs)           # returns when the bytes are in HBM
+        self.k = (self.k + 1) % len(self.bufs)
+        return ptr, tuple(int(v) for v in imgs.shape[:3])
+
+    def close(self):
+        for ptr, _ in self.bufs:
+            if ptr:
+                self.ctx.free(ptr)
+        self.bufs = []
+        self.ctx.close()
 
 
 class DefaultTrainer:
@@ -217,8 +251,11 @@ class DefaultTrainer:
         self.model = TrainModel(None, self.ctx, ensure=self._ensure_net)
         self._cap = self._capacity_from_cfg()              # one allocation for everything the loaders can produce
         self._per_rank = int(cfg.SOLVER.IMS_PER_BATCH) // self.world_size
+        from ..data import PREFETCH_DEPTH
+        workers = int(cfg.DATALOADER.get("NUM_WORKERS", 0)) if "DATALOADER" in cfg else 0
+        self._uploader = _Uploader(dev, PREFETCH_DEPTH + 3) if workers > 0 else None      # batches arrive in HBM (48 MB / step otherwise copied by the training thread)
         self.data_loader = build_detection_train_loader(cfg, rank=comm.get_rank(), world_size=self.world_size,
-                                                        seed=max(int(cfg.get("SEED", -1)), 0))
+                                                        seed=max(int(cfg.get("SEED", -1)), 0), upload=self._uploader)
         self._hooks = []
         self.register_hooks(self.build_hooks())
 
@@ -360,6 +397,12 @@ class DefaultTrainer:
         self.iter = self.start_iter
         for h in self._hooks:
             h.before_train()
+        # The loader threads run Python between their numpy / PIL calls; a training thread that comes back from the library waits for the
+        # interpreter lock for up to one switch interval (5 ms by default) per call -- several calls per step.  0.2 ms while training.
+        import sys
+        switch = sys.getswitchinterval()
+        if self._uploader is not None:
+            sys.setswitchinterval(min(switch, 2e-4))
         try:
             for self.iter in range(self.start_iter, self.max_iter):
                 for h in self._hooks:
@@ -369,6 +412,7 @@ class DefaultTrainer:
                     h.after_step()
                 self.storage.step()
         finally:
+            sys.setswitchinterval(switch)
             for h in self._hooks:
                 h.after_train()
         self._sync_params()
