@@ -149,6 +149,30 @@ def pmc_traffic(kernel_keys, leg="infer"):
     return None, None, None
 
 
+def rocprof_reported(leg="infer"):
+    """north_star's "rocprof-reported HBM GB/s and MFMA utilisation for the backbone conv stack and RoIAlign": the committed PMC
+    summary of this leg's own command (tools/profile_round.sh + tools/summarize_profiles.py), quoted -- not measured in this run."""
+    import glob
+    import re
+    for d in PROFILE_DIRS:
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", d, "pmc_summary*.json")) if ("_train_" in os.path.basename(f)) == (leg == "train")]
+        files.sort(key=lambda f: int((re.search(r"_v(\d+)\.json$", f) or [0, -1])[1]), reverse=True)
+        for f in files:
+            try:
+                k = json.load(open(f))["kernels"]
+            except Exception:
+                continue
+            pick = {}
+            for name, v in k.items():
+                if name.startswith(("conv_split_kernel", "conv_glds_kernel", "conv_f16x3_kernel", "roi_align", "wgrad_split_kernel", "wgrad_f16x3_kernel")):
+                    pick[name] = {"avg_us": v.get("avg_duration_us"), "launches": v.get("launches_in_stats_run"), "hbm_GBps": v.get("hbm_GBps"),
+                                  "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"), "mfma_util": v.get("mfma_util")}
+            if pick:
+                return {"source": os.path.relpath(f, ROOT), "what": "rocprofv3 --kernel-trace --stats + separate --pmc passes (FETCH_SIZE, WRITE_SIZE, "
+                        "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE) of this command on one MI355X; hbm = L2 <-> fabric bytes", "kernels": pick}
+    return None
+
+
 class Ranks:
     """Barrier and max-over-ranks for the timed regions.  N > 1: the device collectives are the library's own RCCL calls
     (amp_barrier / amp_allreduce on the context's communicator); torch.distributed (gloo) only carried the RCCL id.
@@ -504,6 +528,9 @@ def main(args):
                          "events_on": f"every {PROF_EVERY}th timed step ({prof['steps']} of {args.steps} steps, {prof['launches'][0]} launches of the dominant kernel)",
                          "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
         }
+        rp = rocprof_reported("infer") if mode == "f16x3" else None
+        if rp:
+            out["rocprof_reported"] = rp
 
     emitted = threading.Lock()
 
