@@ -849,16 +849,22 @@ constexpr unsigned int OOB_VOFF = 0x80000000u;   // >= num_records of every buff
 // F16 = true: AMP_CONV_F16X3 with BOTH operands already in the split hi|lo' row format -- the input tensor was written that way by
 // its producer (conv epilogue / RoIAlign with split output; byte offsets equal the fp32 tensor's) -- so activations and weights
 // are staged by LDS-DMA with no per-step VALU, and the compute loop is conv_f16x3_kernel's.  BN = 256 runs 8 waves (2 x 4).
-template <int BN, bool STEM = false, int EPI = 0, bool F16 = false>
+// G32 = true (grouped conv with <= 32 channels per group, BN = 64, F16): a tap is ONE K-step.  The 64-channel window of the N tile is
+// staged as two planes of 32 channels; wave column wn multiplies plane wn only -- in the block-diagonal window layout the weights of
+// outputs [32 wn, 32 wn + 32) are zero outside that plane, so the two-steps-per-tap form spends half its MFMAs on zeros.  The weight
+// rows are read from the same split copy (group (n >> 5) & 1 of each tap's 64 channels).  Same sums in the same order, bit for bit.
+template <int BN, bool STEM = false, int EPI = 0, bool F16 = false, bool G32 = false>
 __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv_glds_kernel(const ConvArgs a, const unsigned int x_bytes,
                                                                                                const unsigned int w_bytes) {
+    static_assert(!G32 || (BN == 64 && F16 && !STEM), "G32 is the grouped form of the 64-wide f16x3 tile");
     constexpr int BM = 128;
     constexpr int WTM = BM / 2, WTN = (BN == 64) ? 32 : 64;
     constexpr int NWN = BN / WTN, NW = 2 * NWN;   // waves across N, waves per workgroup
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    constexpr int GA = BM / NW / 8;       // DMA instructions per wave per step for A: BM/NW rows per wave, 8 rows each
+    constexpr int NPL = G32 ? 2 : 1;      // A planes per tile
+    constexpr int GA = BM / NW / 8;       // DMA instructions per wave, step and plane for A: BM/NW rows per wave, 8 rows each
     constexpr int GB = BN / NW / 8;       // ... for B: BN/NW rows per wave
-    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int TILE_FLOATS = (NPL * BM + BN) * BK;
     constexpr int SLD = WTN + 4;
     constexpr int STAGE_FLOATS = NW * WTM * SLD;
     constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
@@ -907,11 +913,12 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     for (int g = 0; g < GB; ++g) {
         const int r = wave * (BN / NW) + 8 * g + srow;
         const int n = n0 + r;
-        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + (G32 ? 32 * ((n >> 5) & 1) : 0) + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
     unsigned int a_voff[GA];              // byte offset of the input pixel of the current tap (+ swizzled chunk), or OOB
 
-    const int csteps = STEM ? 1 : a.cin_win / BK;   // K-steps per tap
+    const int csteps = (STEM || G32) ? 1 : a.cin_win / BK;   // K-steps per tap
+    const int nsteps = G32 ? a.nsteps / 2 : a.nsteps;        // (G32: both 32-channel halves of a tap's window in one step)
     const int a_win = a.grouped ? n0 * 4 : 0;   // bytes: first input channel of this N-tile's window (grouped conv)
     const int kw_taps = STEM ? 1 : a.KW;        // STEM: the 8 taps of a row travel inside one K-step
     int ky = 0, kx = 0, cs = 0;           // block-uniform tap state of the tile being STAGED
@@ -929,13 +936,15 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
             }
         }
         float* As = lds + buf * TILE_FLOATS;
-        float* Bs = As + BM * BK;
+        float* Bs = As + NPL * BM * BK;
         const int a_soff = cs * (BK * 4) + a_win;   // bytes, block-uniform
-        const int b_soff = kstep * (BK * 4);
+        const int b_soff = kstep * (NPL * BK * 4);  // (G32: a tap's weights are two groups of 32 channels, this row's one picked in b_voff)
 #pragma unroll
-        for (int g = 0; g < GA; ++g)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK),
-                                                     16, (int)a_voff[g], a_soff, 0, 0);
+        for (int h = 0; h < NPL; ++h)       // (G32: plane h = channels [32 h, 32 h + 32) of the window: the same rows, 128 B further)
+#pragma unroll
+            for (int g = 0; g < GA; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + h * BM * BK + (wave * (BM / NW) + 8 * g) * BK),
+                                                         16, (int)a_voff[g], a_soff + h * (BK * 4), 0, 0);
 #pragma unroll
         for (int g = 0; g < GB; ++g)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK),
@@ -975,15 +984,15 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the LDS-DMA has landed (explicit: do not rely on the fence lowering)
     __syncthreads();
 
-    for (int step = 0; step < a.nsteps; ++step) {
+    for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < a.nsteps) stage(cur ^ 1);
+        if (step + 1 < nsteps) stage(cur ^ 1);
 
         const float* As = lds + cur * TILE_FLOATS + (wm * WTM + l31) * BK;
-        const float* Bs = lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l31) * BK;
+        const float* Bs = lds + cur * TILE_FLOATS + NPL * BM * BK + (wn * WTN + l31) * BK;
         if (F16) {
-            f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
-                                 fo16_hi, fo16_lo, acc16, acx16);
+            f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (G32 ? wn * BM * BK : 0) + (wm * WTM + l15) * BK,
+                                 lds + cur * TILE_FLOATS + NPL * BM * BK + (wn * WTN + l15) * BK, fo16_hi, fo16_lo, acc16, acx16);
         } else {
 #pragma unroll
             for (int q = 0; q < BK / 8; ++q) {
@@ -1735,6 +1744,14 @@ void launch_f16x3s(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, 
     }
 }
 
+void launch_f16x3s_g32(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {     // grouped, <= 32 channels per group: one K-step per tap
+    switch (epi) {
+        case 1: hipLaunchKernelGGL((conv_glds_kernel<64, false, 1, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        case 2: hipLaunchKernelGGL((conv_glds_kernel<64, false, 2, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        default: hipLaunchKernelGGL((conv_glds_kernel<64, false, 0, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    }
+}
+
 template <int BM, int BN>
 void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BM / 64) * (BN / 64) * 64;
@@ -2105,7 +2122,9 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
                 launch_f16x3s<128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
             } else {    // (grouped: the window of a 64-wide N tile is the tile's own 64 input channels = 256 B of a split row too)
                 a.ntn = amp::cdiv(a.Cout, 64); a.nblk = ntm * a.ntn;
-                launch_f16x3s<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+                static const bool no_g32 = getenv("AMP_NO_G32") != nullptr;      // EXPERIMENT switch: two K-steps per tap for every grouped layer
+                if (a.grouped && cpg <= 32 && !no_g32) launch_f16x3s_g32(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+                else launch_f16x3s<64>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
             }
         } else if (stem) {
             a.ntn = 1;
