@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         unsigned long long kk = keep;
         const int nw = (Wn + 63) >> 6;   // 64-word groups in use (wave-uniform)
         while (kk != 0ull) {   // NU independent row loads in flight per trip (the ORs are associative): the scan is a chain of L2 round trips
-            constexpr int NU = 16;
+            constexpr int NU = 64;      // (16: four dependent round trips per chunk; 64: one -- the wave owns 512 registers)
             int bits[NU];
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
