@@ -165,3 +165,21 @@ def test_c_abi_exports_every_declared_symbol():
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
     assert len(names) >= 40
+
+
+def test_bench_reads_the_pmc_summary_of_its_own_leg():
+    """bench.py quotes HBM bytes / MFMA utilisation from the committed rocprofv3 --pmc summaries: the inference line from
+    pmc_summary_vN.json, the training object from pmc_summary_train_vN.json, newest N by name (file times are equal after a checkout)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    t, src, key = b.pmc_traffic(["conv_split_kernel<128x256>"])
+    assert t and "_train_" not in src and key == "conv_split_kernel<128x256>"
+    t2, src2, _ = b.pmc_traffic(["wgrad_split_kernel"], leg="train")
+    assert t2 and "_train_" in src2
+    rp = b.rocprof_reported("infer")
+    assert rp and rp["source"] == src and any(k.startswith("roi_align") for k in rp["kernels"])
+    assert all(v["hbm_GBps"] is not None for v in rp["kernels"].values())
