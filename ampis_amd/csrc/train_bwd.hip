@@ -193,6 +193,8 @@ __device__ __forceinline__ float roi_axis_weight(int n_samp, float start, float 
     return wsum;
 }
 
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTileArgs a) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -254,13 +256,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTil
                     float wxc[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) wxc[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx_all), qx + c));
+                    // packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two values per instruction, each product and sum rounded on its own as before)
+                    const f32x2p g01 = {gv[0], gv[1]}, g23 = {gv[2], gv[3]};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float w = __fmul_rn(wyr[r], wxc[c]);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[r][c][e] = __fadd_rn(acc[r][c][e], __fmul_rn(w, gv[e]));
+                            const f32x2p w2 = {w, w};
+                            const f32x2p a01 = f32x2p{acc[r][c][0], acc[r][c][1]} + w2 * g01;
+                            const f32x2p a23 = f32x2p{acc[r][c][2], acc[r][c][3]} + w2 * g23;
+                            acc[r][c] = f32x4{a01[0], a01[1], a23[0], a23[1]};
                         }
                     }
                     any = true;
