@@ -425,13 +425,21 @@ __global__ __launch_bounds__(512, 2) void roi_align_rows_kernel(const RoiArgs a)
 // 50 % longer).  Bins 2w and 2w+1 mostly belong to one RoI (same sampling grid); where they do not, the two halves of the wave run
 // loops of different length under the exec mask.  Arithmetic and its order per output value are exactly those of roi_align_kernel.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void load_tap8(const float* row, int c8, float (&v)[8]) {
+typedef _Float16 f16x2r __attribute__((ext_vector_type(2)));
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+// (packed fp32: v_pk_mul_f32 / v_pk_add_f32 work on two values per instruction, each rounded on its own -- the same value per element as
+//  the scalar form; the kernel's interpolation arithmetic is half its instruction stream)
+__device__ __forceinline__ void load_tap8(const float* row, int c8, f32x2r (&v)[4]) {
     const int ch = 8 * c8;
     const char* base = reinterpret_cast<const char*>(row) + (ch >> 5) * 128 + (ch & 31) * 2;
     const f16x8 h = *reinterpret_cast<const f16x8*>(base);
     const f16x8 l = *reinterpret_cast<const f16x8*>(base + 64);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = __fadd_rn((float)h[e], __fmul_rn((float)l[e], 1.0f / 2048.0f));
+    for (int p = 0; p < 4; ++p) {
+        const f32x2r hf = __builtin_convertvector(f16x2r{h[2 * p], h[2 * p + 1]}, f32x2r);
+        const f32x2r lf = __builtin_convertvector(f16x2r{l[2 * p], l[2 * p + 1]}, f32x2r);
+        v[p] = hf + lf * (1.0f / 2048.0f);
+    }
 }
 
 __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
@@ -463,9 +471,9 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
         const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
         const float count = (float)max(gh * gw, 1);
         const float* fb = a.feat[lv] + (size_t)b * H * W * a.C;
-        float acc[8];
+        f32x2r acc[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int p = 0; p < 4; ++p) acc[p] = f32x2r{0.f, 0.f};
         for (int iy = 0; iy < gh; ++iy) {
             float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
             const bool ybad = (y < -1.0f) || (y > (float)H);
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
             // the next one: the four taps stay in registers and only the columns that changed are fetched (the kernel is bound by the
             // 64 B/clk of the CU's vector L1, not by HBM or arithmetic: tools/bench_roi.py).  Same values, same operations, same order.
             int cxlo = -2, cxhi = -2;
-            float v1[8], v2[8], v3[8], v4[8];
+            f32x2r v1[4], v2[4], v3[4], v4[4];
             for (int ix = 0; ix < gw; ++ix) {
                 float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
                 const bool bad = ybad || (x < -1.0f) || (x > (float)W);
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
                 const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
                 if (g_share && xlo == cxhi && xlo != cxlo) {               // advanced by one cell: the right column becomes the left one
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { v1[e] = v2[e]; v3[e] = v4[e]; }
+                    for (int p = 0; p < 4; ++p) { v1[p] = v2[p]; v3[p] = v4[p]; }
                     cxlo = xlo;
                 }
                 if (!g_share || xlo != cxlo) {
@@ -503,30 +511,31 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
                     cxhi = xhi;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float s = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, v1[e]), __fmul_rn(w2, v2[e])), __fmul_rn(w3, v3[e])), __fmul_rn(w4, v4[e]));
-                    acc[e] = __fadd_rn(acc[e], s);
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2r s2 = ((v1[p] * w1 + v2[p] * w2) + v3[p] * w3) + v4[p] * w4;     // (-ffp-contract=off: products and sums stay separate)
+                    acc[p] = acc[p] + s2;
                 }
             }
         }
+        float accs[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = __fdiv_rn(acc[e], count);
+        for (int e = 0; e < 8; ++e) accs[e] = __fdiv_rn(acc[e >> 1][e & 1], count);
         float* orow = a.out + (size_t)bin * a.C;
         if (a.out_split) {
             f16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const _Float16 h = (_Float16)acc[e];
+                const _Float16 h = (_Float16)accs[e];
                 hi[e] = h;
-                lo[e] = (_Float16)((acc[e] - (float)h) * 2048.0f);
+                lo[e] = (_Float16)((accs[e] - (float)h) * 2048.0f);
             }
             const int ch = 8 * c8;
             char* base = reinterpret_cast<char*>(orow) + (ch >> 5) * 128 + (ch & 31) * 2;
             *reinterpret_cast<f16x8*>(base) = hi;
             *reinterpret_cast<f16x8*>(base + 64) = lo;
         } else {
-            reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{accs[0], accs[1], accs[2], accs[3]};
+            reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{accs[4], accs[5], accs[6], accs[7]};
         }
     }
 }
