@@ -11,6 +11,7 @@ namespace amp {
 
 constexpr int SELECT_THREADS = 1024;
 constexpr int SELECT_MAX_K = 2048;
+constexpr int SELECT_UNROLL = 8;      // elements in flight per thread in the passes of the memory version
 
 struct SelectSmem {
     unsigned int hist[256];
@@ -44,11 +45,22 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
     if (tid < 256) sm.hist[tid] = 0;
     if (tid == 0) sm.ncand = 0;
     __syncthreads();
+    // (SELECT_UNROLL independent elements per trip in every pass over the keys: the passes are chains of L2 round trips -- 256 per thread at
+    //  n = 262 144 -- and their latency, not the arithmetic, is the kernel)
     unsigned int mine = 0;
-    for (int i = tid; i < n; i += SELECT_THREADS) {
-        const uint32_t key = key_fn(i);
-        keys[i] = key;
-        if (key) { atomicAdd(&sm.hist[key >> 24], 1u); ++mine; }
+    for (int i0 = tid; i0 < n; i0 += SELECT_UNROLL * SELECT_THREADS) {
+        uint32_t key[SELECT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {
+            const int i = i0 + u * SELECT_THREADS;
+            key[u] = (i < n) ? key_fn(i) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {
+            const int i = i0 + u * SELECT_THREADS;
+            if (i < n) keys[i] = key[u];
+            if (key[u]) { atomicAdd(&sm.hist[key[u] >> 24], 1u); ++mine; }
+        }
     }
     if (mine) atomicAdd(&sm.ncand, mine);
     __syncthreads();
@@ -63,9 +75,16 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
             __syncthreads();
             const uint32_t prefix = sm.prefix;
             const uint32_t himask = 0xffffffffu << (shift + 8);
-            for (int i = tid; i < n; i += SELECT_THREADS) {
-                const uint32_t key = keys[i];
-                if (key && (key & himask) == prefix) atomicAdd(&sm.hist[(key >> shift) & 0xff], 1u);
+            for (int i0 = tid; i0 < n; i0 += SELECT_UNROLL * SELECT_THREADS) {
+                uint32_t key[SELECT_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SELECT_UNROLL; ++u) {
+                    const int i = i0 + u * SELECT_THREADS;
+                    key[u] = (i < n) ? keys[i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < SELECT_UNROLL; ++u)
+                    if (key[u] && (key[u] & himask) == prefix) atomicAdd(&sm.hist[(key[u] >> shift) & 0xff], 1u);
             }
             __syncthreads();
         }
@@ -88,11 +107,18 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
     const int chunk = ((n + 16 * 64 - 1) / (16 * 64)) * 64;
     const int beg = wave * chunk, end = min(n, beg + chunk);
     unsigned int cgt = 0, ceq = 0;
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t key = (i < end) ? keys[i] : 0u;
-        cgt += __popcll(__ballot(key > T));
-        ceq += __popcll(__ballot(key == T));
+    for (int i0 = beg; i0 < end; i0 += SELECT_UNROLL * 64) {
+        uint32_t key[SELECT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {
+            const int i = i0 + u * 64 + lane;
+            key[u] = (i < end) ? keys[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {
+            cgt += __popcll(__ballot(key[u] > T));
+            ceq += __popcll(__ballot(key[u] == T));
+        }
     }
     if (lane == 0) { sm.wave_gt[wave] = cgt; sm.wave_eq[wave] = ceq; }
     for (int i = tid; i < SELECT_MAX_K; i += SELECT_THREADS) sm.sorted[i] = 0ull;
@@ -102,20 +128,29 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
         if (w < wave) { rgt += sm.wave_gt[w]; req += sm.wave_eq[w]; }
         gt_total += sm.wave_gt[w];
     }
-    for (int i0 = beg; i0 < end; i0 += 64) {
-        const int i = i0 + lane;
-        const uint32_t key = (i < end) ? keys[i] : 0u;
-        const bool gt = key > T, eq = key == T;
-        const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
-        if (gt) sm.sorted[rgt + __popcll(mgt & below)] = word;
-        if (eq) {
-            const unsigned int r = req + __popcll(meq & below);
-            if (r < need_eq) sm.sorted[gt_total + r] = word;
+    for (int j0 = beg; j0 < end; j0 += SELECT_UNROLL * 64) {
+        uint32_t key4[SELECT_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {
+            const int i = j0 + u * 64 + lane;
+            key4[u] = (i < end) ? keys[i] : 0u;
         }
-        rgt += __popcll(mgt);
-        req += __popcll(meq);
+#pragma unroll
+        for (int u = 0; u < SELECT_UNROLL; ++u) {          // in index order, as before
+            const int i = j0 + u * 64 + lane;
+            const uint32_t key = key4[u];
+            const bool gt = key > T, eq = key == T;
+            const unsigned long long mgt = __ballot(gt), meq = __ballot(eq);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const unsigned long long word = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+            if (gt) sm.sorted[rgt + __popcll(mgt & below)] = word;
+            if (eq) {
+                const unsigned int r = req + __popcll(meq & below);
+                if (r < need_eq) sm.sorted[gt_total + r] = word;
+            }
+            rgt += __popcll(mgt);
+            req += __popcll(meq);
+        }
     }
     __syncthreads();
     int N = 64;
