@@ -47,7 +47,13 @@ __global__ __launch_bounds__(256) void rle_str_len_kernel(const unsigned int* __
     const int m = len[i];
     const unsigned int* cnt = pool + off[i];
     int total = 0;
-    for (int r = lane; r < m; r += 64) total += rle_nchar(rle_delta(cnt, r));
+    for (int r0 = lane; r0 < m; r0 += 4 * 64) {          // four runs per lane in flight: the loop is a chain of L2 round trips otherwise
+        long long x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = (r0 + 64 * u < m) ? rle_delta(cnt, r0 + 64 * u) : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) total += (r0 + 64 * u < m) ? rle_nchar(x[u]) : 0;
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
     if (lane == 0) str_len[i] = total;
@@ -92,9 +98,11 @@ __global__ __launch_bounds__(256) void rle_str_write_kernel(const unsigned int* 
     const int m = len[i];
     const unsigned int* cnt = pool + off[i];
     unsigned long long base = str_off[i];
+    long long x_next = (lane < m) ? rle_delta(cnt, lane) : 0;          // the next chunk's values are fetched while this one is written
     for (int r0 = 0; r0 < m; r0 += 64) {
         const int r = r0 + lane;
-        long long x = (r < m) ? rle_delta(cnt, r) : 0;
+        long long x = x_next;
+        x_next = (r + 64 < m) ? rle_delta(cnt, r + 64) : 0;
         const int nc = (r < m) ? rle_nchar(x) : 0;
         const int incl = wave_incl_scan(nc, lane);
         unsigned long long p = base + (unsigned long long)(incl - nc);
