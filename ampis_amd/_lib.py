@@ -164,6 +164,7 @@ def _declare(L):
         "amp_model_momentum_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
         "amp_model_sgd_step": ([vp, f, f, f, f], i),
         "amp_model_get_tensor": ([vp, C.c_char_p, i, vp, C.c_size_t], i),
+        "amp_model_set_momentum_tensor": ([vp, C.c_char_p, vp, C.c_size_t], i),
         "amp_roi_align_bwd": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp], i),
         "amp_roi_align_bwd_batched": ([vp, vp, vp, vp, vp, i, vp, vp, i, i, vp, i], i),
         "amp_upsample2_bwd": ([vp, vp, vp, i, i, i, i], i),
@@ -179,11 +180,15 @@ def _declare(L):
         "amp_barrier": ([vp], i),
         "amp_allreduce": ([vp, vp, C.c_size_t, i, i], i),
         "amp_comm_stats": ([vp, C.POINTER(f), C.POINTER(f)], i),
+        "amp_comm_bucket_stats": ([vp, C.POINTER(f)], i),
+        "amp_comm_broadcast": ([vp, vp, C.c_size_t, i], i),
         "amp_grad_bucket_of": ([C.c_char_p], i),
         "amp_plan_grad_buckets": ([i, vp, vp, vp, C.c_size_t, i, vp, vp, vp, C.POINTER(i)], i),
         "amp_model_grad_buckets": ([vp, i, vp, vp, vp, C.POINTER(i)], i),
         "amp_model_set_grad_overlap": ([vp, i], i),
         "amp_model_allreduce_grads": ([vp], i),
+        "amp_model_grads_exchanged": ([vp, C.POINTER(i)], i),
+        "amp_model_broadcast_params": ([vp, i], i),
         "amp_model_get_tap": ([vp, C.c_char_p, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_longlong)], i),
     }
     for name, (args, res) in sig.items():
@@ -284,6 +289,15 @@ class Context:
         e, s = C.c_float(), C.c_float()
         check(lib().amp_comm_stats(self._h, C.byref(e), C.byref(s)), "amp_comm_stats")
         return {"exposed_ms": e.value, "span_ms": s.value}
+
+    def comm_bucket_stats(self):
+        """Microseconds of each of the 7 gradient buckets of the last exchange on the communication stream (-1: not exchanged)."""
+        us = (C.c_float * 7)()
+        check(lib().amp_comm_bucket_stats(self._h, us), "amp_comm_bucket_stats")
+        return [round(float(x), 1) for x in us]
+
+    def broadcast(self, dptr, nbytes, root=0):
+        check(lib().amp_comm_broadcast(self._h, C.c_void_p(int(dptr)), int(nbytes), int(root)), "amp_comm_broadcast")
 
     def d2h(self, arr, src):
         check(lib().amp_memcpy_d2h(self._h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(int(src)), arr.nbytes), "amp_memcpy_d2h")

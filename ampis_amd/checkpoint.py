@@ -28,7 +28,7 @@ logger = logging.getLogger("ampis_amd")
 
 
 class LoadReport(dict):
-    """{'missing': [...], 'shape_mismatch': [(name, file shape, model shape)], 'unexpected': [...], 'renamed': n, 'source': 'd2'|'caffe2'}"""
+    """{'missing': [...], 'shape_mismatch': [(name, file shape, model shape)], 'unexpected': [...], 'renamed': n, 'source': 'd2'|'d2-suffix'|'caffe2'}"""
 
 
 def convert_c2_backbone_names(keys):
@@ -61,7 +61,12 @@ def _to_numpy(a):
 
 
 def read_state(path):
-    """File -> (state dict name -> ndarray in detectron2 names, source tag, number of renamed keys)."""
+    """File -> (state dict name -> ndarray in detectron2 names, source tag, number of renamed keys).
+
+    Two independent switches, as in detectron2's DetectionCheckpointer._load_file / _load_model: blob names are converted only when the
+    file says `__author__ == 'Caffe2'` (or is a bare blob dict, which detectron2 tags that way); `matching_heuristics` only turns on
+    matching by name suffix.  source: 'd2' exact names | 'd2-suffix' detectron2 names matched by suffix (e.g. the torchvision-converted
+    ImageNetPretrained R-50.pkl, whose keys are `stem.conv1.norm.running_mean` ...) | 'caffe2' converted names matched by suffix."""
     path = str(path)
     if path.startswith(("http://", "https://", "detectron2://")):
         raise FileNotFoundError(f"{path}: fetching weights needs a network; put the file on disk and set cfg.MODEL.WEIGHTS to its path")
@@ -73,13 +78,14 @@ def read_state(path):
     else:
         data = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(data, dict) and "model" in data and isinstance(data["model"], dict):
-        state, caffe2 = data["model"], data.get("__author__") == "Caffe2" or bool(data.get("matching_heuristics"))
+        state, caffe2 = data["model"], data.get("__author__") == "Caffe2"
+        heuristics = caffe2 or bool(data.get("matching_heuristics"))
     else:                                                          # a bare blob dict: Detectron / MSRA ImageNet files
         state = data["blobs"] if isinstance(data, dict) and "blobs" in data else data
-        caffe2 = True
+        caffe2 = heuristics = True
     state = {k: _to_numpy(v) for k, v in state.items() if not str(k).endswith("_momentum")}
     if not caffe2:
-        return state, "d2", 0
+        return state, ("d2-suffix" if heuristics else "d2"), 0
     ren = convert_c2_backbone_names(state.keys())
     return {ren[k]: v for k, v in state.items()}, "caffe2", sum(1 for k, v in ren.items() if k != v)
 
@@ -102,7 +108,7 @@ def load_checkpoint(path, num_classes, arch="R50", init=None, strict=False, seed
     if init is None:
         init = P.init_params(num_classes, seed=seed, style="d2", arch=arch)
     # caffe2 names carry no module prefix: match by suffix, as detectron2's align_and_update_state_dicts does (longest suffix wins)
-    if source == "caffe2":
+    if source in ("caffe2", "d2-suffix"):
         by_suffix = {}
         for k in state:
             cands = [n for n in want if n == k or n.endswith("." + k)]

@@ -23,6 +23,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -31,10 +32,17 @@ RcclApi g_rccl;
 
 int load_rccl() {
     if (g_rccl.handle) return AMP_OK;
-    // a copy this process already mapped (same soname) first, then the loader's search path, then the ROCm tree
+    // AMP_RCCL_LIB names the library outright (another RCCL build; the tests' shared-memory stand-in that lets two ranks share one
+    // card, tests/fake_rccl).  Otherwise: a copy this process already mapped (same soname) first, then the loader's search path, then
+    // the ROCm tree.
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    const char* forced = getenv("AMP_RCCL_LIB");
+    if (forced && *forced) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (!h) { amp::set_error("amp_comm: AMP_RCCL_LIB=%s could not be opened: %s", forced, dlerror()); return AMP_ERR_STATE; }
+    }
+    if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
     if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) { amp::set_error("amp_comm: librccl.so.1 could not be opened: %s", dlerror()); return AMP_ERR_STATE; }
     RcclApi a;
@@ -47,6 +55,7 @@ int load_rccl() {
     AMP_SYM(CommInitRank, "ncclCommInitRank")
     AMP_SYM(CommDestroy, "ncclCommDestroy")
     AMP_SYM(AllReduce, "ncclAllReduce")
+    AMP_SYM(Broadcast, "ncclBroadcast")
     AMP_SYM(GroupStart, "ncclGroupStart")
     AMP_SYM(GroupEnd, "ncclGroupEnd")
     AMP_SYM(GetErrorString, "ncclGetErrorString")
@@ -75,6 +84,8 @@ struct amp_comm {
     hipEvent_t ev_first = nullptr;       // comm stream: the first collective of the current round may start (its inputs are ready)
     hipEvent_t ev_mark = nullptr;        // compute stream: the producer finished (end of the backward pass)
     hipEvent_t ev_last = nullptr;        // comm stream: the last collective of the round has completed
+    hipEvent_t ev_b0[AMP_GRAD_BUCKETS] = {}, ev_b1[AMP_GRAD_BUCKETS] = {};   // comm stream: around each bucket's grouped all-reduce
+    unsigned bucket_seen = 0;            // buckets whose event pair belongs to the last round
     int* d_token = nullptr;              // barrier payload
     bool round_open = false;             // ev_first recorded for the current round
     bool pending = false;                // collectives issued since the last wait_done
@@ -99,11 +110,15 @@ static int comm_follow_compute(amp_ctx* ctx) {
 
 // In-place SUM all-reduce of `nr` float ranges of `base` as ONE grouped RCCL operation, ordered after the compute stream's work
 // so far, running on the communication stream.  Nothing waits for it until comm_wait_done.
-int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr) {
+int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr, int slot) {
     amp_comm* c = ctx->comm;
     AMP_REQUIRE(c, "amp_comm: no communicator on this context (amp_comm_init)");
     if (nr <= 0) return AMP_OK;
+    const bool first_of_round = !c->round_open;
     AMP_TRY_STATUS(comm_follow_compute(ctx));
+    if (first_of_round) c->bucket_seen = 0;
+    const bool timed = slot >= 0 && slot < AMP_GRAD_BUCKETS && !(c->bucket_seen >> slot & 1);
+    if (timed) AMP_HIP_CHECK(hipEventRecord(c->ev_b0[slot], c->stream));
     AMP_NCCL_CHECK(g_rccl.GroupStart());
     for (int i = 0; i < nr; ++i) {
         ncclResult_t r = g_rccl.AllReduce(base + off[i], base + off[i], n[i], ncclFloat, ncclSum, c->comm, c->stream);
@@ -114,6 +129,7 @@ int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const si
         }
     }
     AMP_NCCL_CHECK(g_rccl.GroupEnd());
+    if (timed) { AMP_HIP_CHECK(hipEventRecord(c->ev_b1[slot], c->stream)); c->bucket_seen |= 1u << slot; }
     c->pending = true;
     return AMP_OK;
 }
@@ -192,6 +208,7 @@ int amp_comm_init(amp_ctx* ctx, int rank, int world, const unsigned char* id_h) 
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev_done) == hipSuccess && hipEventCreate(&c->ev_first) == hipSuccess && hipEventCreate(&c->ev_mark) == hipSuccess && hipEventCreate(&c->ev_last) == hipSuccess;
+    for (int b = 0; b < AMP_GRAD_BUCKETS && ok; ++b) ok = hipEventCreate(&c->ev_b0[b]) == hipSuccess && hipEventCreate(&c->ev_b1[b]) == hipSuccess;
     ok = ok && hipMalloc(&c->d_token, 16) == hipSuccess && hipMemset(c->d_token, 0, 16) == hipSuccess;
     if (!ok) {
         amp::set_error("amp_comm_init: stream / event / token allocation failed");
@@ -210,6 +227,7 @@ int amp_comm_destroy(amp_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream);
     (void)g_rccl.CommDestroy(c->comm);
     (void)hipEventDestroy(c->ev_ready); (void)hipEventDestroy(c->ev_done); (void)hipEventDestroy(c->ev_first); (void)hipEventDestroy(c->ev_mark); (void)hipEventDestroy(c->ev_last);
+    for (int b = 0; b < AMP_GRAD_BUCKETS; ++b) { if (c->ev_b0[b]) (void)hipEventDestroy(c->ev_b0[b]); if (c->ev_b1[b]) (void)hipEventDestroy(c->ev_b1[b]); }
     (void)hipFree(c->d_token);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -262,6 +280,32 @@ int amp_comm_stats(amp_ctx* ctx, float* exposed_ms, float* span_ms) {
     *exposed_ms = tail > 0.f ? tail : 0.f;
     AMP_HIP_CHECK(hipEventElapsedTime(span_ms, c->ev_first, c->ev_last));
     return AMP_OK;
+}
+
+int amp_comm_bucket_stats(amp_ctx* ctx, float us[AMP_GRAD_BUCKETS]) {
+    AMP_REQUIRE(ctx && ctx->comm && us, "amp_comm_bucket_stats: no communicator on this context, or null argument");
+    amp_comm* c = ctx->comm;
+    for (int b = 0; b < AMP_GRAD_BUCKETS; ++b) {
+        us[b] = -1.f;                                   /* not exchanged in the last round */
+        if (!(c->bucket_seen >> b & 1)) continue;
+        AMP_HIP_CHECK(hipEventSynchronize(c->ev_b1[b]));
+        float ms = 0.f;
+        AMP_HIP_CHECK(hipEventElapsedTime(&ms, c->ev_b0[b], c->ev_b1[b]));
+        us[b] = ms * 1000.f;
+    }
+    return AMP_OK;
+}
+
+int amp_comm_broadcast(amp_ctx* ctx, void* buf, size_t bytes, int root) {
+    AMP_REQUIRE(ctx && ctx->comm && buf, "amp_comm_broadcast: no communicator on this context, or null buffer");
+    amp_comm* c = ctx->comm;
+    AMP_REQUIRE(root >= 0 && root < c->world, "amp_comm_broadcast: root %d of %d ranks", root, c->world);
+    if (bytes == 0) return AMP_OK;
+    AMP_HIP_CHECK(hipEventRecord(c->ev_ready, ctx->stream));
+    AMP_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    AMP_NCCL_CHECK(g_rccl.Broadcast(buf, buf, bytes, ncclChar, root, c->comm, c->stream));
+    c->pending = true;
+    return amp::comm_wait_done(ctx);
 }
 
 /* ---- the bucket plan: host-only, no device call (tests drive it without a GPU) ---- */

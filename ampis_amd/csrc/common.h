@@ -113,7 +113,8 @@ int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, c
              const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0,
              const PredictFuse* fuse = nullptr, const RpnFuse* rpn = nullptr);
 // comm.hip (all no-ops / errors are explicit when the context has no communicator)
-int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr);   // grouped in-place SUM, after the compute stream's work so far
+// grouped in-place SUM, after the compute stream's work so far; slot in [0, AMP_GRAD_BUCKETS): timed for amp_comm_bucket_stats
+int comm_allreduce_ranges(amp_ctx* ctx, float* base, const size_t* off, const size_t* n, int nr, int slot = -1);
 int comm_mark_producer_end(amp_ctx* ctx);      // the backward pass is complete on the compute stream (exposed-time reference)
 int comm_wait_done(amp_ctx* ctx);              // compute stream waits (device side) for every collective issued so far
 int comm_agree_flag(amp_ctx* ctx, int* d_flag); // MAX of a device int over the ranks, complete on return

@@ -126,6 +126,7 @@ struct amp_model {
     std::vector<int> gb_bucket;
     std::vector<size_t> gb_off, gb_n;
     int grad_overlap = -1;              // -1: on when the context has a communicator; 0 / 1: amp_model_set_grad_overlap
+    unsigned issued_mask = 0;           // buckets of the current gradients already handed to RCCL (bit b); all set = exchanged
 };
 
 static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
@@ -232,11 +233,17 @@ void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_li
 int issue_bucket(amp_model* m, int b) {
     amp_ctx* ctx = m->ctx;
     if (m->ws.dry || !ctx->comm || m->grad_overlap == 0) return AMP_OK;
+    // every range of the bucket, in groups of at most 64 per grouped RCCL call (a fragmented arena may hold more than 64)
     size_t off[64], n[64];
     int nr = 0;
-    for (size_t i = 0; i < m->gb_bucket.size() && nr < 64; ++i)
-        if (m->gb_bucket[i] == b) { off[nr] = m->gb_off[i]; n[nr] = m->gb_n[i]; ++nr; }
-    return amp::comm_allreduce_ranges(ctx, m->garena, off, n, nr);
+    for (size_t i = 0; i < m->gb_bucket.size(); ++i) {
+        if (m->gb_bucket[i] != b) continue;
+        off[nr] = m->gb_off[i]; n[nr] = m->gb_n[i];
+        if (++nr == 64) { AMP_TRY(amp::comm_allreduce_ranges(ctx, m->garena, off, n, nr, b)); nr = 0; }
+    }
+    AMP_TRY(amp::comm_allreduce_ranges(ctx, m->garena, off, n, nr, b));
+    m->issued_mask |= 1u << b;
+    return AMP_OK;
 }
 
 struct Trunk {
@@ -947,6 +954,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // parameters).  Stem and res2 are frozen (FREEZE_AT = 2), FrozenBN has no parameters; its scale is folded into the weight
     // transforms (data gradients) and the wgrad reduce (weight gradients).
     if (!dry) AMP_TRY(amp::comm_wait_done(ctx));    // a previous exchange of this arena (a step without sgd_step, a re-run) must have finished
+    if (!dry) { m->issued_mask = 0; m->grads_valid = false; }
     const size_t WG_SCRATCH = (size_t)64 << 20;     // floats: split-K slabs of the largest layer
     const size_t WT_SCRATCH = (size_t)13 << 20;     // floats: transformed weights of the largest layer (fc1: 12.85 M)
     AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
@@ -1763,9 +1771,26 @@ int amp_model_set_grad_overlap(amp_model* m, int mode) {
     return AMP_OK;
 }
 
+int amp_model_grads_exchanged(amp_model* m, int* exchanged) {
+    AMP_REQUIRE(m && exchanged, "amp_model_grads_exchanged: null argument");
+    *exchanged = m->grads_valid && m->issued_mask == (1u << AMP_GRAD_BUCKETS) - 1u;
+    return AMP_OK;
+}
+
+int amp_model_broadcast_params(amp_model* m, int root) {
+    AMP_REQUIRE(m && m->finalized && m->ctx->comm, "amp_model_broadcast_params: needs a finalized model and a communicator on the context");
+    // parameters (conv weights, FrozenBN scale / shift, biases: the whole arena) and, when training, the SGD momentum: what DDP's
+    // constructor does with rank 0's state_dict.  The f16x3 operand copies are derived data: refreshed before their next use.
+    AMP_TRY(amp_comm_broadcast(m->ctx, m->parena, m->parena_used * sizeof(float), root));
+    if (m->varena) AMP_TRY(amp_comm_broadcast(m->ctx, m->varena, m->parena_used * sizeof(float), root));
+    m->split_stale = true;
+    return AMP_OK;
+}
+
 int amp_model_allreduce_grads(amp_model* m) {
     AMP_REQUIRE(m && m->garena && m->ctx->comm, "amp_model_allreduce_grads: needs cfg.train_enable and a communicator on the context");
     AMP_REQUIRE(m->grads_valid, "amp_model_allreduce_grads: no gradients (call amp_model_forward_backward first)");
+    AMP_REQUIRE(m->issued_mask == 0, "amp_model_allreduce_grads: these gradients were already exchanged (buckets 0x%x); a second SUM would count them twice", m->issued_mask);
     const int keep = m->grad_overlap;
     m->grad_overlap = 1;
     int st = AMP_OK;
@@ -1891,33 +1916,87 @@ int amp_model_momentum_arena(amp_model* m, float** vel_dev, size_t* nfloats) {
 
 static int train_entry(amp_model* m, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const amp_gt* gt,
                        unsigned int seed, float losses_h[5], int backward) {
-    AMP_REQUIRE(m && imgs_bgr && gt && losses_h, "amp_model_forward_losses: null argument");
+    AMP_REQUIRE(m && losses_h, "amp_model_forward_losses: null argument");
     AMP_REQUIRE(m->finalized, "amp_model_forward_losses: call amp_model_finalize after loading every tensor");
     AMP_REQUIRE(m->cfg.train_enable, "amp_model_forward_losses: the model was created with cfg.train_enable = 0");
-    AMP_REQUIRE(gt->B == B && gt->gt_off && gt->boxes && gt->classes && gt->poly_off && gt->poly_xy, "amp_model_forward_losses: incomplete ground truth");
-    const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
-    AMP_REQUIRE(B >= 1 && B <= m->cfg.max_batch && Hp <= m->cfg.max_h && Wp <= m->cfg.max_w, "amp_model_forward_losses: batch exceeds the model capacity");
     AMP_HIP_CHECK(hipSetDevice(m->ctx->device));
     const uint8_t* imgs_d = imgs_bgr;
-    if (imgs_on_host) {
-        AMP_TRY(stage_images(m, imgs_bgr, (size_t)B * H * W * 3));
-        imgs_d = m->img_stage;
-    }
+    // everything that can fail from here on -- bad arguments included -- fails INSIDE the collective protocol below
+    auto prepare = [&]() -> int {
+        AMP_REQUIRE(imgs_bgr && gt, "amp_model_forward_losses: null argument");
+        AMP_REQUIRE(gt->B == B && gt->gt_off && gt->boxes && gt->classes && gt->poly_off && gt->poly_xy, "amp_model_forward_losses: incomplete ground truth");
+        const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+        AMP_REQUIRE(B >= 1 && B <= m->cfg.max_batch && Hp <= m->cfg.max_h && Wp <= m->cfg.max_w, "amp_model_forward_losses: batch exceeds the model capacity");
+        if (imgs_on_host) {
+            AMP_TRY(stage_images(m, imgs_bgr, (size_t)B * H * W * 3));
+            imgs_d = m->img_stage;
+        }
+        return AMP_OK;
+    };
     // training: forward and data-gradient convolutions follow the context's mode (AMP_CONV_F16X3: weights are split per call, they
     // change every step); weight gradients are fp32 MFMA
     const int mode = m->ctx->conv_mode;
-    int st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
-    m->ctx->conv_mode = mode;
-    if (st == AMP_OK && mode == AMP_CONV_F16X3) {   // an activation beyond the fp16 range: the step again, entirely on fp32 MFMA
+    // With a communicator of more than one rank the backward entry is a COLLECTIVE protocol: every rank issues the same sequence of
+    // RCCL calls whatever happens locally.  A rank whose step failed (e.g. AMP_ERR_NOMEM) still hands the buckets it had not reached
+    // to RCCL (the step is thrown away by everyone) and then takes part in the MAX over {0 fine, 1 range flag, 2 failed}, so the other
+    // ranks neither block in a collective nobody joins nor apply an update one rank does not have.
+    int world = 0;
+    (void)amp_comm_info(m->ctx, nullptr, &world, nullptr);
+    const bool collective = backward && world > 1;
+    if (backward) { m->issued_mask = 0; m->grads_valid = false; }
+    auto finish_collectives = [&](int status) -> int {      // after a failed run_train: the buckets this rank did not reach
+        if (!collective || status == AMP_OK || m->grad_overlap == 0) return AMP_OK;
+        AMP_TRY(amp::comm_wait_done(m->ctx));
+        for (int b = 0; b < AMP_GRAD_BUCKETS; ++b)
+            if (!(m->issued_mask >> b & 1)) AMP_TRY(issue_bucket(m, b));
+        return amp::comm_mark_producer_end(m->ctx);
+    };
+    auto agree = [&](int status, int* verdict) -> int {     // verdict = MAX over the ranks of {range flag, 2 if the rank failed}
+        *verdict = 0;
+        if (status != AMP_OK) {
+            const int two = 2;
+            (void)hipMemcpyAsync(m->ctx->d_conv_flag, &two, sizeof(int), hipMemcpyHostToDevice, m->ctx->stream);
+            (void)hipStreamSynchronize(m->ctx->stream);
+        }
+        if (collective) AMP_TRY(amp::comm_agree_flag(m->ctx, m->ctx->d_conv_flag));
         int flag = 0;
-        // with a communicator every rank takes the SAME decision (MAX of the flag): the re-run issues collectives too
-        if (backward) AMP_TRY(amp::comm_agree_flag(m->ctx, m->ctx->d_conv_flag));
-        if (amp_conv_range_flag(m->ctx, 1, &flag) == AMP_OK && flag) {
+        if (collective || mode == AMP_CONV_F16X3) AMP_TRY(amp_conv_range_flag(m->ctx, 1, &flag));
+        *verdict = flag;
+        return AMP_OK;
+    };
+    std::string first_error;
+    int st = prepare();
+    if (st == AMP_OK) st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
+    m->ctx->conv_mode = mode;
+    if (st != AMP_OK) first_error = amp_last_error();
+    if (collective || (st == AMP_OK && mode == AMP_CONV_F16X3)) {
+        AMP_TRY(finish_collectives(st));
+        int verdict = 0;
+        AMP_TRY(agree(st, &verdict));
+        if (verdict >= 2) {
+            m->grads_valid = false;
+            if (st != AMP_OK) { amp::set_error("%s", first_error.c_str()); return st; }
+            amp::set_error("amp_model_forward_backward: another rank's step failed; this rank's gradients were discarded");
+            return AMP_ERR_STATE;
+        }
+        if (verdict == 1 && mode == AMP_CONV_F16X3) {   // an activation beyond the fp16 range (on any rank): the step again, entirely on fp32 MFMA
             if (m->f32_reruns++ == 0)
                 fprintf(stderr, "[ampis_hip] an activation exceeded the fp16 range of AMP_CONV_F16X3; re-running the step in AMP_CONV_F32\n");
             m->ctx->conv_mode = AMP_CONV_F32;
+            if (backward) { m->issued_mask = 0; m->grads_valid = false; }
             st = run_train(m, imgs_d, B, H, W, gt, seed, losses_h, backward != 0);
             m->ctx->conv_mode = mode;
+            if (collective) {                            // the re-run issued collectives too: agree on ITS outcome
+                if (st != AMP_OK) first_error = amp_last_error();
+                AMP_TRY(finish_collectives(st));
+                AMP_TRY(agree(st, &verdict));
+                if (verdict >= 2) {
+                    m->grads_valid = false;
+                    if (st != AMP_OK) { amp::set_error("%s", first_error.c_str()); return st; }
+                    amp::set_error("amp_model_forward_backward: another rank's step failed; this rank's gradients were discarded");
+                    return AMP_ERR_STATE;
+                }
+            }
         }
     }
     return st;
@@ -1929,22 +2008,36 @@ int amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B) {
     return AMP_OK;
 }
 
-int amp_model_get_tensor(amp_model* m, const char* name_c, int want_grad, float* out, size_t cap) {
-    AMP_REQUIRE(m && name_c && out, "amp_model_get_tensor: null argument");
-    AMP_REQUIRE(m->finalized, "amp_model_get_tensor: model not finalized");
-    AMP_REQUIRE(!want_grad || m->garena, "amp_model_get_tensor: no gradient arena (cfg.train_enable = 0)");
+// One tensor between the host (detectron2 / torch layout) and an arena (stored layout).  kind: 0 parameters, 1 gradients, 2 SGD momentum.
+// put = false: arena -> out; put = true: out -> arena (momentum only: parameters go through amp_model_load_tensor + finalize).  The
+// layout loops are written once; `mv` copies in the direction asked for.
+static int xfer_tensor(amp_model* m, const char* name_c, int kind, float* out, size_t cap, bool put) {
+    const char* fn = put ? "amp_model_set_momentum_tensor" : "amp_model_get_tensor";
+    AMP_REQUIRE(m && name_c && out, "%s: null argument", fn);
+    AMP_REQUIRE(m->finalized, "%s: model not finalized", fn);
+    AMP_REQUIRE(kind >= 0 && kind <= 2, "%s: kind %d (0 parameter, 1 gradient, 2 momentum)", fn, kind);
+    AMP_REQUIRE(kind != 1 || m->garena, "%s: no gradient arena (cfg.train_enable = 0)", fn);
+    AMP_REQUIRE(kind != 2 || m->varena, "%s: no momentum arena (cfg.train_enable = 0)", fn);
     const std::string name(name_c);
     const std::string prefix = name.substr(0, name.rfind('.'));
     const bool is_w = ends_with(name, ".weight");
     const int K = m->cfg.num_classes;
-    AMP_REQUIRE(name.find(".norm.") == std::string::npos, "amp_model_get_tensor: FrozenBN statistics have no gradient / are kept on the host");
+    AMP_REQUIRE(name.find(".norm.") == std::string::npos, "%s: FrozenBN statistics have no gradient / are kept on the host", fn);
     AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    auto arena_ptr = [&](const float* dev) -> float* {
+        return kind == 1 ? m->garena + (dev - m->parena) : kind == 2 ? m->varena + (dev - m->parena) : const_cast<float*>(dev);
+    };
     auto fetch = [&](const float* dev, size_t n, std::vector<float>& h) -> int {
-        const float* src = want_grad ? m->garena + (dev - m->parena) : dev;
         h.resize(n);
-        AMP_HIP_CHECK(hipMemcpy(h.data(), src, n * 4, hipMemcpyDeviceToHost));
+        AMP_HIP_CHECK(hipMemcpy(h.data(), arena_ptr(dev), n * 4, hipMemcpyDeviceToHost));
         return AMP_OK;
     };
+    auto store = [&](const float* dev, const std::vector<float>& h) -> int {
+        if (!put) return AMP_OK;
+        AMP_HIP_CHECK(hipMemcpy(arena_ptr(dev), h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        return AMP_OK;
+    };
+    auto mv = [put](float& host_layout, float& stored) { if (put) stored = host_layout; else host_layout = stored; };
     std::vector<float> h;
     std::string key = prefix;
     int row0 = 0, rows = -1;   // row slice of a fused tensor
@@ -1954,50 +2047,60 @@ int amp_model_get_tensor(amp_model* m, const char* name_c, int want_grad, float*
     else if (prefix == "proposal_generator.rpn_head.anchor_deltas") { key = "proposal_generator.rpn_head.pred"; row0 = 3; rows = 12; }
     else if (prefix == "roi_heads.mask_head.predictor") { row0 = 0; rows = K; }
     auto it = m->conv.find(key);
-    AMP_REQUIRE(it != m->conv.end(), "amp_model_get_tensor: unknown tensor '%s'", name_c);
+    AMP_REQUIRE(it != m->conv.end(), "%s: unknown tensor '%s'", fn, name_c);
     const ConvW& cw = it->second;
     if (!is_w) {
-        AMP_REQUIRE(cw.shift, "amp_model_get_tensor: '%s' has no bias", name_c);
+        AMP_REQUIRE(cw.shift, "%s: '%s' has no bias", fn, name_c);
         AMP_TRY(fetch(cw.shift, (size_t)cw.cout, h));
-        const int n = (prefix == "roi_heads.mask_head.deconv") ? 256 : (rows >= 0 ? rows : cw.cout);
-        AMP_REQUIRE((size_t)n <= cap, "amp_model_get_tensor: output buffer too small");
-        memcpy(out, h.data() + row0, (size_t)n * 4);
-        return AMP_OK;
+        const bool deconv = prefix == "roi_heads.mask_head.deconv";
+        const int n = deconv ? 256 : (rows >= 0 ? rows : cw.cout);
+        AMP_REQUIRE((size_t)n <= cap, "%s: buffer too small", fn);
+        for (int j = 0; j < n; ++j) mv(out[j], h[row0 + j]);
+        if (put && deconv) for (int q = 1; q < 4; ++q) for (int co = 0; co < 256; ++co) h[q * 256 + co] = out[co];   // the bias is stored once per tap
+        return store(cw.shift, h);
     }
     if (cw.groups > 1) {   // window layout [O][KH][KW][64] -> grouped OIHW [O][O/G][KH][KW]
         const int cpg = cw.cout / cw.groups;
         AMP_TRY(fetch(cw.w, (size_t)cw.cout * cw.kh * cw.kw * 64, h));
-        AMP_REQUIRE(cap >= (size_t)cw.cout * cpg * cw.kh * cw.kw, "amp_model_get_tensor: output buffer too small");
+        AMP_REQUIRE(cap >= (size_t)cw.cout * cpg * cw.kh * cw.kw, "%s: buffer too small", fn);
         for (int o = 0; o < cw.cout; ++o) {
             const int j0 = (o / cpg) * cpg - (o & ~63);
             for (int i = 0; i < cpg; ++i) for (int y = 0; y < cw.kh; ++y) for (int x = 0; x < cw.kw; ++x)
-                out[(((size_t)o * cpg + i) * cw.kh + y) * cw.kw + x] = h[(((size_t)o * cw.kh + y) * cw.kw + x) * 64 + j0 + i];
+                mv(out[(((size_t)o * cpg + i) * cw.kh + y) * cw.kw + x], h[(((size_t)o * cw.kh + y) * cw.kw + x) * 64 + j0 + i]);
         }
-        return AMP_OK;
+        return store(cw.w, h);
     }
     const size_t kk = (size_t)cw.kh * cw.kw * cw.cin;
     AMP_TRY(fetch(cw.w, (size_t)cw.cout * kk, h));
     if (prefix == "backbone.bottom_up.stem.conv1") {
-        AMP_REQUIRE(cap >= (size_t)64 * 3 * 49, "amp_model_get_tensor: output buffer too small");
+        AMP_REQUIRE(cap >= (size_t)64 * 3 * 49, "%s: buffer too small", fn);
         for (int o = 0; o < 64; ++o) for (int i = 0; i < 3; ++i) for (int y = 0; y < 7; ++y) for (int x = 0; x < 7; ++x)
-            out[((o * 3 + i) * 7 + y) * 7 + x] = h[(((size_t)o * 7 + y) * 8 + x) * 4 + i];
+            mv(out[((o * 3 + i) * 7 + y) * 7 + x], h[(((size_t)o * 7 + y) * 8 + x) * 4 + i]);
     } else if (prefix == "roi_heads.box_head.fc1") {
-        AMP_REQUIRE(cap >= (size_t)1024 * 12544, "amp_model_get_tensor: output buffer too small");
+        AMP_REQUIRE(cap >= (size_t)1024 * 12544, "%s: buffer too small", fn);
         for (int o = 0; o < 1024; ++o) for (int ch = 0; ch < 256; ++ch) for (int p = 0; p < 49; ++p)
-            out[(size_t)o * 12544 + ch * 49 + p] = h[(size_t)o * 12544 + p * 256 + ch];
+            mv(out[(size_t)o * 12544 + ch * 49 + p], h[(size_t)o * 12544 + p * 256 + ch]);
     } else if (prefix == "roi_heads.mask_head.deconv") {
-        AMP_REQUIRE(cap >= (size_t)256 * 256 * 4, "amp_model_get_tensor: output buffer too small");
+        AMP_REQUIRE(cap >= (size_t)256 * 256 * 4, "%s: buffer too small", fn);
         for (int ci = 0; ci < 256; ++ci) for (int co = 0; co < 256; ++co) for (int ky = 0; ky < 2; ++ky) for (int kx = 0; kx < 2; ++kx)
-            out[(((size_t)ci * 256 + co) * 2 + ky) * 2 + kx] = h[((size_t)(ky * 2 + kx) * 256 + co) * 256 + ci];
+            mv(out[(((size_t)ci * 256 + co) * 2 + ky) * 2 + kx], h[((size_t)(ky * 2 + kx) * 256 + co) * 256 + ci]);
     } else if (rows >= 0) {
-        AMP_REQUIRE(cap >= (size_t)rows * kk, "amp_model_get_tensor: output buffer too small");
-        memcpy(out, h.data() + (size_t)row0 * kk, (size_t)rows * kk * 4);
+        AMP_REQUIRE(cap >= (size_t)rows * kk, "%s: buffer too small", fn);
+        for (size_t j = 0; j < (size_t)rows * kk; ++j) mv(out[j], h[(size_t)row0 * kk + j]);
     } else {   // [O][KH][KW][I] -> OIHW
-        AMP_REQUIRE(cap >= (size_t)cw.cout * kk, "amp_model_get_tensor: output buffer too small");
+        AMP_REQUIRE(cap >= (size_t)cw.cout * kk, "%s: buffer too small", fn);
         for (int o = 0; o < cw.cout; ++o) for (int i = 0; i < cw.cin; ++i) for (int y = 0; y < cw.kh; ++y) for (int x = 0; x < cw.kw; ++x)
-            out[(((size_t)o * cw.cin + i) * cw.kh + y) * cw.kw + x] = h[(((size_t)o * cw.kh + y) * cw.kw + x) * cw.cin + i];
+            mv(out[(((size_t)o * cw.cin + i) * cw.kh + y) * cw.kw + x], h[(((size_t)o * cw.kh + y) * cw.kw + x) * cw.cin + i]);
     }
-    return AMP_OK;
+    return store(cw.w, h);
+}
+
+int amp_model_get_tensor(amp_model* m, const char* name, int kind, float* out, size_t cap) {
+    return xfer_tensor(m, name, kind, out, cap, false);
+}
+
+int amp_model_set_momentum_tensor(amp_model* m, const char* name, const float* data, size_t n) {
+    return xfer_tensor(m, name, 2, const_cast<float*>(data), n, true);
 }
 
 int amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]) {

@@ -74,7 +74,7 @@ def _label_image_records(fmt, im_root, ann_root, pattern):
     """'binary' / 'label': one annotation image (or .npy) per micrograph; 'binary' is split into its 8-connected components (the
     default of skimage.measure.label), 'label' already carries one id per instance.  Yields (image path, annotation path, hw, masks)."""
     from scipy import ndimage
-    for img_path in sorted(im_root.glob(pattern)):
+    for img_path in im_root.glob(pattern):            # directory order, like the reference (ampis/data_utils.py:394-395): same image_id per file
         found = list(ann_root.glob("*{}*".format(img_path.stem)))
         assert len(found) == 1, f"There must be exactly 1 annotation file for, {img_path.name}, but {len(found)} were found"
         ann = np.load(str(found[0])) if found[0].suffix == ".npy" else _imread(found[0])

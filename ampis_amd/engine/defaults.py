@@ -199,28 +199,42 @@ class _Uploader:
     `nbuf` batches: the loader holds at most PREFETCH_DEPTH finished batches plus the one being collated, the trainer one."""
 
     def __init__(self, device, nbuf):
+        import threading
         self.ctx = _lib.Context(device)
         self.bufs = [(0, 0)] * nbuf       # (pointer, bytes)
         self.k = 0
+        self._lock = threading.Lock()     # close() may come from the training thread while the collating thread is uploading
 
     def __call__(self, imgs):
         imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
-        ptr, cap = self.bufs[self.k]
-        if cap < imgs.nbytes:
-            if ptr:
-                self.ctx.free(ptr)
-            ptr, cap = self.ctx.malloc(imgs.nbytes), imgs.nbytes
-            self.bufs[self.k] = (ptr, cap)
-        self.ctx.h2d(ptr, imgs)           # returns when the bytes are in HBM
-        self.k = (self.k + 1) % len(self.bufs)
-        return ptr, tuple(int(v) for v in imgs.shape[:3])
+        with self._lock:
+            if self.ctx is None:          # closed: the batch stays on the host (nobody will consume it)
+                return None
+            ptr, cap = self.bufs[self.k]
+            if cap < imgs.nbytes:
+                if ptr:
+                    self.ctx.free(ptr)
+                ptr, cap = self.ctx.malloc(imgs.nbytes), imgs.nbytes
+                self.bufs[self.k] = (ptr, cap)
+            self.ctx.h2d(ptr, imgs)           # returns when the bytes are in HBM
+            self.k = (self.k + 1) % len(self.bufs)
+            return ptr, tuple(int(v) for v in imgs.shape[:3])
 
     def close(self):
-        for ptr, _ in self.bufs:
-            if ptr:
-                self.ctx.free(ptr)
-        self.bufs = []
-        self.ctx.close()
+        with self._lock:
+            if self.ctx is None:
+                return
+            for ptr, _ in self.bufs:
+                if ptr:
+                    self.ctx.free(ptr)
+            self.bufs = []
+            self.ctx.close()
+            self.ctx = None
+
+
+def comm_backend_is_rccl():
+    from ..utils import comm
+    return comm.backend() == "rccl"
 
 
 class DefaultTrainer:
@@ -253,11 +267,50 @@ class DefaultTrainer:
         self._per_rank = int(cfg.SOLVER.IMS_PER_BATCH) // self.world_size
         from ..data import PREFETCH_DEPTH
         workers = int(cfg.DATALOADER.get("NUM_WORKERS", 0)) if "DATALOADER" in cfg else 0
-        self._uploader = _Uploader(dev, PREFETCH_DEPTH + 3) if workers > 0 else None      # batches arrive in HBM (48 MB / step otherwise copied by the training thread)
-        self.data_loader = build_detection_train_loader(cfg, rank=comm.get_rank(), world_size=self.world_size,
-                                                        seed=max(int(cfg.get("SEED", -1)), 0), upload=self._uploader)
+        self._dev, self._workers, self._loader_epoch = dev, workers, 0
+        self._uploader = self.data_loader = None
+        self._build_loader()
         self._hooks = []
+        self._need_broadcast = self.world_size > 1 and comm.backend() == "rccl"     # rank 0's weights and momentum win (DDP's constructor)
         self.register_hooks(self.build_hooks())
+
+    def _build_loader(self):
+        from ..data import build_detection_train_loader, PREFETCH_DEPTH
+        from ..utils import comm
+        # batches arrive in HBM (48 MB / step otherwise copied by the training thread)
+        self._uploader = _Uploader(self._dev, PREFETCH_DEPTH + 3) if self._workers > 0 else None
+        self.data_loader = build_detection_train_loader(self.cfg, rank=comm.get_rank(), world_size=self.world_size,
+                                                        seed=max(int(self.cfg.get("SEED", -1)), 0) + 7919 * self._loader_epoch, upload=self._uploader)
+        self._loader_epoch += 1
+
+    def close(self):
+        """Stop the loader threads and free what the trainer holds on the device (uploader ring, net, context).  train() releases the
+        loader and the uploader itself; the net stays until close() so that `trainer.model` can still be evaluated after training."""
+        self._release_loader()
+        if self._net is not None:
+            self._sync_params()
+            self._net.close()
+            self._net = None
+            self.model.net = None
+        from ..utils import comm
+        if comm._rccl_ctx is self.ctx:
+            comm.detach_rccl()
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    def _release_loader(self):
+        dl, self.data_loader = self.data_loader, None
+        if dl is not None and hasattr(dl, "close"):
+            dl.close()                       # generator: runs the loader's `finally` (stops the producer, shuts the pools down)
+        if self._uploader is not None:
+            self._uploader.close()           # serialised against an upload still running in the collating thread
+            self._uploader = None
+
+    def _broadcast_if_needed(self):
+        if self._need_broadcast and self._net is not None:
+            self._net.broadcast_params(0)
+            self._need_broadcast = False
 
     # ---- model / weights ----
     def _capacity_from_cfg(self):
@@ -307,11 +360,25 @@ class DefaultTrainer:
                              rpn_batch=int(c.MODEL.RPN.BATCH_SIZE_PER_IMAGE), roi_batch=int(c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE),
                              pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD), arch=self.arch)
         self._net.load_params(self.params)
-        if self._momentum is not None:
-            self._net.momentum(self._momentum)
-            self._momentum = None
+        self._restore_momentum()
+        self._broadcast_if_needed()
         self._cap = cap
         self.model.net = self._net
+
+    def _restore_momentum(self):
+        """self._momentum: a flat arena (carried over a re-created net of the same configuration) or a dict of per-parameter buffers
+        in torch layout (a checkpoint)."""
+        mom, self._momentum = self._momentum, None
+        if mom is None:
+            return
+        if isinstance(mom, dict) and set(mom) == {"arena"}:       # files written before the per-name format: this build's flat arena
+            mom = mom["arena"]
+        if isinstance(mom, dict):
+            unknown = self._net.load_momentum_dict(mom)
+            if unknown:
+                logger.warning(f"momentum buffers of {len(unknown)} tensors the model does not train were ignored: {', '.join(unknown[:6])}")
+        else:
+            self._net.momentum(mom)
 
     def _sync_params(self):
         if self._net is not None:
@@ -335,21 +402,21 @@ class DefaultTrainer:
             if resumed:
                 it = checkpoint.checkpoint_iteration(w)
                 self.start_iter = self.iter = (it + 1) if it is not None else 0
-                mom = checkpoint.checkpoint_momentum(w).get("arena")
-                if mom is not None:
-                    self._momentum = mom
+                mom = checkpoint.checkpoint_momentum(w)
+                if mom:
+                    self._momentum = mom            # per-parameter buffers, torch layout
         elif w:
             logger.warning(f"cfg.MODEL.WEIGHTS={w!r} needs a download; no network: training from the seeded random initialisation")
+        self._need_broadcast = self.world_size > 1 and comm_backend_is_rccl()
         if self._net is not None:
             self._net.load_params(self.params)
-            if self._momentum is not None:
-                self._net.momentum(self._momentum)
-                self._momentum = None
+            self._restore_momentum()
+            self._broadcast_if_needed()
 
     def save_checkpoint(self, path):
         self._sync_params()
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        mom = {"arena": self._net.momentum()} if self._net is not None else None
+        mom = self._net.momentum_dict() if self._net is not None else None      # under the parameters' names, torch layout
         checkpoint.save_checkpoint(path, self.params, iteration=self.iter, optimizer=mom)
         with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
             f.write(os.path.basename(path))
@@ -375,6 +442,8 @@ class DefaultTrainer:
 
     def run_step(self):
         from ..utils import comm
+        if self.data_loader is None:
+            self._build_loader()
         batch = next(self.data_loader)
         h = max(d["image_bgr"].shape[0] for d in batch)
         w = max(d["image_bgr"].shape[1] for d in batch)
@@ -413,6 +482,9 @@ class DefaultTrainer:
                 self.storage.step()
         finally:
             sys.setswitchinterval(switch)
-            for h in self._hooks:
-                h.after_train()
+            try:
+                for h in self._hooks:
+                    h.after_train()
+            finally:
+                self._release_loader()          # loader threads, pools and the uploader's device ring live for one train() only
         self._sync_params()

@@ -232,13 +232,49 @@ class MaskRCNN:
     def allreduce_grads(self):
         check(lib().amp_model_allreduce_grads(self._h), "amp_model_allreduce_grads")
 
-    def get_tensor(self, name, grad=False):
-        """Current value (or gradient) of a parameter in detectron2 / torch layout."""
+    def grads_exchanged(self):
+        """True when every bucket of the current gradients has been handed to RCCL (inside forward_backward, or by allreduce_grads)."""
+        x = C.c_int()
+        check(lib().amp_model_grads_exchanged(self._h, C.byref(x)), "amp_model_grads_exchanged")
+        return bool(x.value)
+
+    def broadcast_params(self, root=0):
+        """Rank `root`'s parameters and SGD momentum to every rank of the context's communicator (DDP's constructor broadcast)."""
+        check(lib().amp_model_broadcast_params(self._h, int(root)), "amp_model_broadcast_params")
+
+    def get_tensor(self, name, grad=False, momentum=False):
+        """Current value (or gradient, or SGD momentum buffer) of a parameter in detectron2 / torch layout."""
         from . import params as P
         shape = P.param_shapes(self.num_classes, self.arch)[name]
         out = np.empty(shape, dtype=np.float32)
-        check(lib().amp_model_get_tensor(self._h, name.encode(), int(bool(grad)), out.ctypes.data_as(C.c_void_p), out.size), "amp_model_get_tensor")
+        kind = 2 if momentum else int(bool(grad))
+        check(lib().amp_model_get_tensor(self._h, name.encode(), kind, out.ctypes.data_as(C.c_void_p), out.size), "amp_model_get_tensor")
         return out
+
+    def trainable_names(self):
+        """Tensors the SGD step updates: everything but FrozenBN statistics and the frozen stem / res2 (FREEZE_AT = 2)."""
+        from . import params as P
+        return [k for k in P.param_shapes(self.num_classes, self.arch)
+                if ".norm." not in k and not k.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2"))]
+
+    def momentum_dict(self):
+        """SGD momentum buffers under the parameters' names, torch layout: what a checkpoint stores (independent of the arena layout)."""
+        return {k: self.get_tensor(k, momentum=True) for k in self.trainable_names()}
+
+    def load_momentum_dict(self, bufs):
+        """Inverse of momentum_dict.  Sizes are validated; names the model does not train are reported, not loaded."""
+        from . import params as P
+        shapes = P.param_shapes(self.num_classes, self.arch)
+        train = set(self.trainable_names())
+        unknown = [k for k in bufs if k not in train]
+        for k, v in bufs.items():
+            if k not in train:
+                continue
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            if tuple(a.shape) != tuple(shapes[k]):
+                raise _lib.AmpError(f"momentum buffer {k!r}: checkpoint {tuple(a.shape)} vs model {tuple(shapes[k])}")
+            check(lib().amp_model_set_momentum_tensor(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), a.size), f"amp_model_set_momentum_tensor({k})")
+        return unknown
 
     def state_dict(self):
         """All trainable tensors + the FrozenBN statistics they were loaded with are not tracked here; returns the trainable part."""

@@ -131,11 +131,14 @@ def all_reduce_sum_(t):
 def all_reduce_gradients(model, ctx):
     """Make the gradient arena of `model` the SUM over all ranks; returns the 1/world factor the SGD step applies (DDP
     averages).  With the RCCL communicator the buckets were already handed to RCCL from inside amp_model_forward_backward
-    (they overlap the backward pass; amp_model_sgd_step waits for them on the device), so there is nothing left to do here."""
+    (they overlap the backward pass; amp_model_sgd_step waits for them on the device); with the overlap switched off
+    (`set_grad_overlap(False)`) they are handed over here, all at once."""
     ws = get_world_size()
     if ws == 1 and ctx.comm_info()[1] == 0:
         return 1.0
     if ctx.comm_info()[1] > 0:
+        if not model.grads_exchanged():          # set_grad_overlap(False): nothing was exchanged inside forward_backward
+            model.allreduce_grads()
         return 1.0 / ctx.comm_info()[1]
     if backend() != "staged":
         raise _lib.AmpError("world size > 1 but the context has no RCCL communicator: call comm.attach_rccl(ctx) "

@@ -408,8 +408,12 @@ int  amp_model_grad_arena(amp_model* m, float** grads_dev, size_t* nfloats);
 int  amp_model_momentum_arena(amp_model* m, float** vel_dev, size_t* nfloats);
 /* torch.optim.SGD step on every trainable tensor: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */
 int  amp_model_sgd_step(amp_model* m, float lr, float momentum, float weight_decay, float grad_scale);
-/* Gradient / current value of one tensor, converted back to the torch layout of detectron2's state_dict entry `name` (host). */
-int  amp_model_get_tensor(amp_model* m, const char* name, int want_grad, float* out_h, size_t capacity_floats);
+/* Current value (kind 0) / gradient (1) / SGD momentum (2) of one tensor, converted back to the torch layout of detectron2's
+ * state_dict entry `name` (host). */
+int  amp_model_get_tensor(amp_model* m, const char* name, int kind, float* out_h, size_t capacity_floats);
+/* The inverse for the momentum: the buffer of `name` in torch layout -> the momentum arena (resuming a checkpoint that stores the
+ * velocity under the parameters' names, independent of this build's arena layout). */
+int  amp_model_set_momentum_tensor(amp_model* m, const char* name, const float* data_h, size_t nfloats);
 /* Valid (h,w) of each image of the NEXT batches inside the common frame (host [B][2]); NULL = every image fills the frame. */
 int  amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
@@ -436,6 +440,12 @@ int amp_allreduce(amp_ctx* ctx, void* buf, size_t count, int dtype, int op);
 /* timing of the last gradient exchange: exposed_ms = from the end of the backward pass (context stream) to the end of the last
  * bucket (communication stream), 0 when the exchange finished first; span_ms = first bucket ready -> last bucket reduced */
 int amp_comm_stats(amp_ctx* ctx, float* exposed_ms, float* span_ms);
+/* per bucket of the last gradient exchange: microseconds on the communication stream from "inputs ready and stream free" to
+ * "reduced" (with peers: includes waiting for the slowest rank to arrive); -1 for a bucket that was not exchanged */
+int amp_comm_bucket_stats(amp_ctx* ctx, float us[/* AMP_GRAD_BUCKETS */ 7]);
+/* in-place broadcast of `bytes` of device memory from rank `root`, ordered after the context's stream and complete before its
+ * later work (ncclBroadcast on the communication stream) */
+int amp_comm_broadcast(amp_ctx* ctx, void* buf, size_t bytes, int root);
 
 /* The gradient arena is exchanged in AMP_GRAD_BUCKETS buckets, in the order the backward pass completes them:
  * 0 mask head, 1 box head, 2 RPN head, 3 FPN, 4 res5, 5 res4, 6 res3 (stem and res2 are frozen: -1).  Host-only helpers (no
@@ -453,7 +463,16 @@ int amp_model_grad_buckets(amp_model* m, int cap, int* out_bucket, size_t* out_o
  * amp_model_sgd_step waits for the last bucket on the device.  mode 0: nothing is exchanged inside forward_backward; the host
  * calls amp_model_allreduce_grads (all buckets at once) or reduces amp_model_grad_arena itself. */
 int amp_model_set_grad_overlap(amp_model* m, int mode);
-int amp_model_allreduce_grads(amp_model* m);
+int amp_model_allreduce_grads(amp_model* m);            /* refused when the current gradients were already exchanged */
+/* 1 when every bucket of the current gradients has been handed to RCCL (by forward_backward or by amp_model_allreduce_grads) */
+int amp_model_grads_exchanged(amp_model* m, int* exchanged);
+/* rank `root`'s parameters (the whole arena: weights, biases, FrozenBN scale / shift) and SGD momentum to every rank: what torch
+ * DDP's constructor does under DefaultTrainer (ampis/data_utils.py:135).  Call once after loading weights / resuming.
+ *
+ * amp_model_forward_backward on a communicator of more than one rank is a collective: every rank must call it for every step; a
+ * rank whose step fails still completes the step's RCCL sequence, and then EVERY rank returns an error for that step (the failing
+ * rank its own status, the others AMP_ERR_STATE) with the gradients discarded. */
+int amp_model_broadcast_params(amp_model* m, int root);
 
 #ifdef __cplusplus
 }

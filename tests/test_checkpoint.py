@@ -90,6 +90,36 @@ def test_caffe2_named_imagenet_backbone(tmp_path):
     assert all(n.endswith(("running_mean", "running_var")) for n in rep["missing"] if n.startswith("backbone.bottom_up."))
 
 
+def test_detectron2_named_heuristics_pkl_keeps_its_bn_statistics(tmp_path):
+    """A torchvision-converted ImageNet backbone (detectron2's convert-torchvision-to-d2.py output, ImageNetPretrained/torchvision/R-50.pkl):
+    detectron2 module names WITHOUT the backbone prefix, `matching_heuristics: True`, author not Caffe2.  detectron2 converts names only
+    for `__author__ == 'Caffe2'`; the heuristics switch only enables suffix matching, so running_mean / running_var must arrive intact."""
+    full = P.init_params(1, seed=4, style="spread")
+    pre = "backbone.bottom_up."
+    rng = np.random.default_rng(2)
+    model = {}
+    for k, v in full.items():
+        if k.startswith(pre):
+            model[k[len(pre):]] = rng.normal(0.3, 1.0, v.shape).astype(np.float32) if k.endswith(("running_mean", "running_var")) else v
+    model["stem.fc.weight"] = np.zeros((1000, 2048), np.float32)
+    with open(tmp_path / "R-50.pkl", "wb") as f:
+        pickle.dump({"model": model, "__author__": "torchvision", "matching_heuristics": True}, f)
+    init = P.init_params(1, seed=1, style="d2")
+    got, rep = checkpoint.load_checkpoint(tmp_path / "R-50.pkl", 1, init=init, with_report=True)
+    assert rep["source"] == "d2-suffix" and rep["renamed"] == 0 and rep["shape_mismatch"] == []
+    assert rep["unexpected"] == ["stem.fc.weight"]
+    assert not [n for n in rep["missing"] if n.startswith(pre)]
+    for k, v in model.items():
+        if k != "stem.fc.weight":
+            assert np.array_equal(got[pre + k], v), k
+    assert not np.all(got[pre + "stem.conv1.norm.running_mean"] == 0)          # the statistics of the file, not the FrozenBN defaults
+    # the same keys with exact names and no heuristics flag: nothing matches (detectron2 would not match them either)
+    with open(tmp_path / "plain.pkl", "wb") as f:
+        pickle.dump({"model": model, "__author__": "torchvision"}, f)
+    _, rep2 = checkpoint.load_checkpoint(tmp_path / "plain.pkl", 1, init=init, with_report=True)
+    assert rep2["source"] == "d2" and len(rep2["unexpected"]) == len(model)
+
+
 def test_c2_name_conversion_table():
     ren = checkpoint.convert_c2_backbone_names(["conv1_w", "res_conv1_bn_s", "res_conv1_bn_b", "res2_0_branch2a_w", "res2_0_branch2a_bn_s",
                                                 "res3_0_branch1_bn_b", "res4_22_branch2c_w", "res5_1_branch2b_bn_rm", "res5_1_branch2b_bn_riv", "fc1000_b"])

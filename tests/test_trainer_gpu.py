@@ -216,6 +216,11 @@ def test_finetune_one_class_from_an_80_class_checkpoint_with_larger_validation_i
     assert [i for _, i in tr2.storage.history("total_loss")] == [6, 7]
     # the first resumed step started from the stored velocity: with zero momentum the weights after it would differ
     assert tr2._momentum is None
+    from ampis_amd import checkpoint
+    stored = checkpoint.checkpoint_momentum(os.path.join(cfg.OUTPUT_DIR, open(os.path.join(cfg.OUTPUT_DIR, "last_checkpoint")).read().strip()))
+    assert "arena" not in stored and "roi_heads.box_head.fc1.weight" in stored and stored["roi_heads.box_head.fc1.weight"].shape == (1024, 12544)
+    tr.close(); tr2.close()
+    assert tr.ctx is None and tr._uploader is None and tr.data_loader is None
     DatasetCatalog.clear()
 
 
@@ -240,4 +245,16 @@ def test_momentum_survives_a_regrown_net(tmp_path):
     assert np.array_equal(b.momentum(), mom)
     with pytest.raises(_lib.AmpError):
         b.momentum(mom[:-1])
-    b.close(); ctx.close()
+    # the checkpoint form: per-parameter buffers in torch layout, independent of the arena layout
+    a2 = MaskRCNN(ctx, K, max_batch=2, max_h=128, max_w=160, max_out_hw=160, train=True, max_gt=512, max_poly_doubles=512 * 64)
+    a2.load_params(full)
+    md = b.momentum_dict()
+    shapes = P.param_shapes(K)
+    assert set(md) == set(b.trainable_names()) and all(md[k].shape == tuple(shapes[k]) for k in md)
+    assert not any(k.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2")) or ".norm." in k for k in md)
+    assert np.abs(md["roi_heads.box_head.fc1.weight"]).max() > 0 and np.abs(md["proposal_generator.rpn_head.anchor_deltas.weight"]).max() > 0
+    assert a2.load_momentum_dict(dict(md, **{"backbone.bottom_up.stem.conv1.weight": np.zeros((64, 3, 7, 7), np.float32)})) == ["backbone.bottom_up.stem.conv1.weight"]
+    assert np.array_equal(a2.momentum(), mom)                      # every layout transform inverted exactly, padding untouched
+    with pytest.raises(_lib.AmpError):
+        a2.load_momentum_dict({"roi_heads.box_head.fc2.bias": np.zeros(7, np.float32)})
+    a2.close(); b.close(); ctx.close()
