@@ -143,6 +143,7 @@ def _declare(L):
         "amp_rle_iou": ([vp, i, vp, i, i, C.POINTER(C.c_double)], i),
         "amp_rle_iou_matrix": ([vp, vp, vp, i, vp, vp, vp, i, vp, i, vp], i),
         "amp_rle_merge2": ([vp, i, vp, i, i, vp, i, C.POINTER(i)], i),
+        "amp_rle_pair_overlap": ([vp, vp, vp, vp, vp, vp, vp, vp, i, vp, vp, vp], i),
         "amp_rle_from_polygon": ([vp, i, i, i, vp, i, C.POINTER(i)], i),
         "amp_model_cfg_default": ([C.POINTER(ModelCfg)], i),
         "amp_model_create": ([vp, C.POINTER(ModelCfg), C.POINTER(vp)], i),
@@ -181,6 +182,7 @@ def _declare(L):
         "amp_allreduce": ([vp, vp, C.c_size_t, i, i], i),
         "amp_comm_stats": ([vp, C.POINTER(f), C.POINTER(f)], i),
         "amp_comm_bucket_stats": ([vp, C.POINTER(f)], i),
+        "amp_comm_wait": ([vp], i),
         "amp_comm_broadcast": ([vp, vp, C.c_size_t, i], i),
         "amp_grad_bucket_of": ([C.c_char_p], i),
         "amp_plan_grad_buckets": ([i, vp, vp, vp, C.c_size_t, i, vp, vp, vp, C.POINTER(i)], i),
@@ -289,6 +291,10 @@ class Context:
         e, s = C.c_float(), C.c_float()
         check(lib().amp_comm_stats(self._h, C.byref(e), C.byref(s)), "amp_comm_stats")
         return {"exposed_ms": e.value, "span_ms": s.value}
+
+    def comm_wait(self):
+        """The context's stream waits for every collective issued so far (before reading the gradient arena after an exchange)."""
+        check(lib().amp_comm_wait(self._h), "amp_comm_wait")
 
     def comm_bucket_stats(self):
         """Microseconds of each of the 7 gradient buckets of the last exchange on the communication stream (-1: not exchanged)."""

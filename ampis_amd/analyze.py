@@ -1,8 +1,20 @@
-"""The evaluation metric AMPIS defines on the hot path's output -- "mask IoU vs ref" of the benchmark metric:
-mirror of ampis/analyze.py:54-112 (_piecewise_iou), :115-181 (_piecewise_rle_match), :184-223 (rle_instance_matcher) and
-:226-339 (det_seg_scores), same names / arguments / result keys, running on the C-ABI RLE codec (ampis_amd.rle).  Quirks kept on
-purpose: strict `>` against iou_thresh, several ground-truth instances may match the same prediction, division by zero when
-there are no detections."""
+"""Instance matching and detection / segmentation scores on RLE masks -- the "mask IoU vs ref" half of the benchmark metric
+(SURVEY.md §8 f3).  Same entry points, arguments and result keys as ampis/analyze.py (`rle_instance_matcher` :184-223,
+`det_seg_scores` :226-339), so notebooks call it unchanged; the computation is laid out for the C-ABI RLE codec instead of for
+pycocotools:
+
+  * ONE `amp_rle_iou_matrix` call gives every (ground truth, prediction) IoU.  (The reference walks 80-wide blocks because
+    pycocotools.mask.iou has a size limit, ampis/analyze.py:54-112; the C routine has none, so there is nothing to walk.)
+  * The matching rule is stated as array semantics rather than as a loop:
+      - a ground-truth instance g is assigned the prediction of maximal IoU, the FIRST one among equals (lowest index);
+      - g is a true positive iff that IoU is strictly greater than `iou_thresh`, otherwise a false negative;
+      - assignment is not exclusive: two ground-truth instances may take the same prediction (a prediction covering two particles
+        counts as two true positives -- the reference's behaviour);
+      - a prediction no ground-truth instance took is a false positive.
+  * Pixel-level scores come from ONE `amp_rle_pair_overlap` call over the matched pairs (|g and p|, |g minus p|, |p minus g|) instead
+    of a merge + three area calls per pair.
+With no prediction at all the detection precision is 0/0: like the reference this raises ZeroDivisionError.
+The independent checker is oracle/matcher.py (a loop-for-loop restatement of the reference, pinned by its known-answer test)."""
 import numpy as np
 
 from . import rle
@@ -24,60 +36,40 @@ def masks_to_rle(masks, size=None):
     raise NotImplementedError(f"unsupported mask type {type(masks)}")
 
 
-def _piecewise_iou(a, b, interval=80):
-    imax, jmax = len(a), len(b)
-    target = np.zeros((imax, jmax))
-    n_a = imax // interval + int(bool(imax % interval))
-    n_b = jmax // interval + int(bool(jmax % interval))
-    crowd = np.zeros(interval, bool)
-    for i in range(n_a):
-        i1, i2 = interval * i, min(interval * i + interval, imax)
-        for j in range(n_b):
-            j1, j2 = interval * j, min(interval * j + interval, jmax)
-            target[i1:i2, j1:j2] = rle.iou(b[j1:j2], a[i1:i2], crowd[: i2 - i1]).T
-    return target
+def iou_matrix(gt, pred):
+    """[len(gt), len(pred)] float64 IoU of every ground-truth / prediction pair (no crowd regions), one C call."""
+    if len(gt) == 0 or len(pred) == 0:
+        return np.zeros((len(gt), len(pred)))
+    return np.ascontiguousarray(rle.iou(pred, gt, np.zeros(len(gt), bool)).T)
 
 
-def _piecewise_rle_match(gt, pred, iou_thresh=0.5, interval=80):
-    jmax = len(pred)
-    tp, fn, iou = [], [], []
-    matched = np.zeros(len(pred), bool)
-    n_seg = jmax // interval + int(jmax % interval > 0)
-    for gi, g in enumerate(gt):
-        best, arg = 0.0, -1
-        for j in range(n_seg):
-            j0 = interval * j
-            s = rle.iou(pred[j0:j0 + interval], [g], [False])[:, 0]
-            k = int(np.argmax(s))
-            if s[k] > best:
-                best, arg = s[k], k + j0
-        if best > iou_thresh:
-            tp.append([gi, arg])
-            iou.append(best)
-            matched[arg] = True
-        else:
-            fn.append(gi)
-    fp = np.array([x for x, mm in enumerate(matched) if not mm], int)
-    return {"tp": np.asarray(tp, int), "fn": np.asarray(fn, int), "fp": fp, "iou": np.asarray(iou)}
+def match_instances(iou, iou_thresh=0.5):
+    """The matching rule of the module docstring on a [G, P] IoU matrix -> {'tp': [n,2] (gt, pred) index pairs in gt order,
+    'fn': gt indices, 'fp': pred indices, 'iou': IoU of each true positive}."""
+    assert iou_thresh >= 0, "iou_thresh must not be negative"
+    G, P = iou.shape
+    if P == 0:
+        return {"tp": np.zeros((0, 2), int), "fn": np.arange(G), "fp": np.zeros(0, int), "iou": np.zeros(0)}
+    taken = iou.argmax(axis=1)                               # first maximum of each row
+    best = iou[np.arange(G), taken]
+    hit = best > iou_thresh                                  # strict
+    unclaimed = np.ones(P, bool)
+    unclaimed[taken[hit]] = False
+    return {"tp": np.stack([np.flatnonzero(hit), taken[hit]], axis=1).astype(int).reshape(-1, 2), "fn": np.flatnonzero(~hit),
+            "fp": np.flatnonzero(unclaimed), "iou": best[hit]}
 
 
 def rle_instance_matcher(gt, pred, iou_thresh=0.5, size=None):
-    return _piecewise_rle_match(masks_to_rle(gt, size), masks_to_rle(pred, size), iou_thresh)
+    gt, pred = masks_to_rle(gt, size), masks_to_rle(pred, size)
+    return match_instances(iou_matrix(gt, pred), iou_thresh)
 
 
 def det_seg_scores(gt, pred, iou_thresh=0.5, size=None):
-    gtm, prm = masks_to_rle(gt, size), masks_to_rle(pred, size)
-    res = rle_instance_matcher(gtm, prm, iou_thresh=iou_thresh, size=size)
-    matches = np.asarray(res["tp"])
-    tp, fn, fp = len(matches), len(res["fn"]), len(res["fp"])
-    det_precision = tp / (tp + fp)
-    det_recall = tp / (tp + fn)
-    g_tp = [gtm[i[0]] for i in matches]
-    p_tp = [prm[i[1]] for i in matches]
-    seg_tp = np.array([rle.area(rle.merge([a, b], intersect=True)) for a, b in zip(g_tp, p_tp)], np.int64)
-    ga = np.array([rle.area(m) for m in g_tp], np.int64)
-    pa = np.array([rle.area(m) for m in p_tp], np.int64)
-    seg_fp, seg_fn = pa - seg_tp, ga - seg_tp
-    return {"det_precision": det_precision, "det_recall": det_recall, "seg_precision": seg_tp / (seg_tp + seg_fp),
-            "seg_recall": seg_tp / (seg_tp + seg_fn), "det_tp": matches, "det_fn": res["fn"], "det_fp": res["fp"], "seg_tp": seg_tp,
-            "seg_fn": seg_fn, "seg_fp": seg_fp, "det_tp_iou": res["iou"]}
+    gt, pred = masks_to_rle(gt, size), masks_to_rle(pred, size)
+    m = match_instances(iou_matrix(gt, pred), iou_thresh)
+    n_tp, n_fn, n_fp = len(m["tp"]), len(m["fn"]), len(m["fp"])
+    both, gt_only, pred_only = rle.pair_overlap(gt, pred, m["tp"])       # per matched pair: pixels in both / missed / spurious
+    with np.errstate(divide="ignore", invalid="ignore"):
+        seg_precision, seg_recall = both / (both + pred_only), both / (both + gt_only)
+    return {"det_precision": n_tp / (n_tp + n_fp), "det_recall": n_tp / (n_tp + n_fn), "seg_precision": seg_precision, "seg_recall": seg_recall,
+            "det_tp": m["tp"], "det_fn": m["fn"], "det_fp": m["fp"], "seg_tp": both, "seg_fn": gt_only, "seg_fp": pred_only, "det_tp_iou": m["iou"]}

@@ -282,6 +282,11 @@ int amp_comm_stats(amp_ctx* ctx, float* exposed_ms, float* span_ms) {
     return AMP_OK;
 }
 
+int amp_comm_wait(amp_ctx* ctx) {
+    AMP_REQUIRE(ctx, "amp_comm_wait: null ctx");
+    return amp::comm_wait_done(ctx);
+}
+
 int amp_comm_bucket_stats(amp_ctx* ctx, float us[AMP_GRAD_BUCKETS]) {
     AMP_REQUIRE(ctx && ctx->comm && us, "amp_comm_bucket_stats: no communicator on this context, or null argument");
     amp_comm* c = ctx->comm;

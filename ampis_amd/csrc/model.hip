@@ -2023,6 +2023,7 @@ static int xfer_tensor(amp_model* m, const char* name_c, int kind, float* out, s
     const bool is_w = ends_with(name, ".weight");
     const int K = m->cfg.num_classes;
     AMP_REQUIRE(name.find(".norm.") == std::string::npos, "%s: FrozenBN statistics have no gradient / are kept on the host", fn);
+    AMP_TRY(amp::comm_wait_done(m->ctx));      // a gradient read after an exchange sees the reduced values
     AMP_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     auto arena_ptr = [&](const float* dev) -> float* {
         return kind == 1 ? m->garena + (dev - m->parena) : kind == 2 ? m->varena + (dev - m->parena) : const_cast<float*>(dev);

@@ -217,6 +217,25 @@ int amp_rle_iou_matrix(const uint32_t* dpool, const unsigned long long* doff, co
 }
 
 // out = A & B (intersect != 0) or A | B, both over the same h*w. Returns the number of runs in *m_out.
+int amp_rle_pair_overlap(const uint32_t* apool, const unsigned long long* aoff, const int* alen, const uint32_t* bpool,
+                         const unsigned long long* boff, const int* blen, const int* pair_a, const int* pair_b, int npairs,
+                         unsigned long long* inter, unsigned long long* only_a, unsigned long long* only_b) {
+    AMP_REQUIRE(npairs >= 0 && (npairs == 0 || (apool && aoff && alen && bpool && boff && blen && pair_a && pair_b && inter && only_a && only_b)),
+                "amp_rle_pair_overlap: bad argument");
+    for (int p = 0; p < npairs; ++p) {
+        const int ia = pair_a[p], ib = pair_b[p];
+        AMP_REQUIRE(ia >= 0 && ib >= 0 && alen[ia] > 0 && blen[ib] > 0, "amp_rle_pair_overlap: pair %d names an empty run list", p);
+        unsigned long long both = 0, a = 0, b = 0;      // one pass over the two run lists: the three pixel classes of the pair
+        rle_zip(apool + aoff[ia], alen[ia], bpool + boff[ib], blen[ib], [&](unsigned long long c, bool va, bool vb) {
+            if (va && vb) both += c;
+            else if (va) a += c;
+            else if (vb) b += c;
+        });
+        inter[p] = both; only_a[p] = a; only_b[p] = b;
+    }
+    return AMP_OK;
+}
+
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out) {
     AMP_REQUIRE(A && B && out && m_out && ka > 0 && kb > 0, "amp_rle_merge2: bad argument");
     int m = 0;

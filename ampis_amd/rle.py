@@ -109,6 +109,23 @@ def iou(dt, gt, iscrowd):
     return out
 
 
+def pair_overlap(a, b, pairs):
+    """For index pairs (i, j): |a[i] AND b[j]|, |a[i] minus b[j]|, |b[j] minus a[i]| as three int64 arrays, one C call
+    (amp_rle_pair_overlap)."""
+    pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    n = len(pairs)
+    out = [np.zeros(n, dtype=np.uint64) for _ in range(3)]
+    if n:
+        ap, ao, al = _pool([_counts(x) for x in a])
+        bp, bo, bl = _pool([_counts(x) for x in b])
+        assert pairs[:, 0].max() < len(a) and pairs[:, 1].max() < len(b) and pairs.min() >= 0
+        pa, pb = np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        check(lib().amp_rle_pair_overlap(vp(ap), vp(ao), vp(al), vp(bp), vp(bo), vp(bl), vp(pa), vp(pb), n, vp(out[0]), vp(out[1]), vp(out[2])),
+              "amp_rle_pair_overlap")
+    return tuple(o.astype(np.int64) for o in out)
+
+
 def merge(rles, intersect=False):
     assert len(rles) >= 1
     h, w = rles[0]["size"]

@@ -317,6 +317,11 @@ int amp_rle_iou(const uint32_t* dt, int md, const uint32_t* gt, int mg, int iscr
 int amp_rle_iou_matrix(const uint32_t* dpool, const unsigned long long* doff, const int* dlen, int nd, const uint32_t* gpool,
                        const unsigned long long* goff, const int* glen, int ng, const unsigned char* iscrowd /* [ng] or NULL */, int h,
                        double* out);
+/* Pixel classes of `npairs` mask pairs (a = apool run list pair_a[p], b = bpool run list pair_b[p]) in one call: |a AND b|, |a \ b|,
+ * |b \ a|.  Replaces the per-match pycocotools.mask.merge(intersect=True) + area calls of det_seg_scores (ampis/analyze.py:315-321). */
+int amp_rle_pair_overlap(const uint32_t* apool, const unsigned long long* aoff, const int* alen, const uint32_t* bpool,
+                         const unsigned long long* boff, const int* blen, const int* pair_a, const int* pair_b, int npairs,
+                         unsigned long long* inter, unsigned long long* only_a, unsigned long long* only_b);
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out);
 /* polygon (k vertices, flat xy) -> runs of an h x w mask (pycocotools rleFrPoly / frPyObjects) */
 int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, int cap, int* m_out);
@@ -440,6 +445,9 @@ int amp_allreduce(amp_ctx* ctx, void* buf, size_t count, int dtype, int op);
 /* timing of the last gradient exchange: exposed_ms = from the end of the backward pass (context stream) to the end of the last
  * bucket (communication stream), 0 when the exchange finished first; span_ms = first bucket ready -> last bucket reduced */
 int amp_comm_stats(amp_ctx* ctx, float* exposed_ms, float* span_ms);
+/* the context's stream waits (on the device) for every collective issued so far: call it before reading the gradient arena through
+ * amp_model_grad_arena after an exchange (amp_model_sgd_step and amp_model_get_tensor do it themselves); no-op without a communicator */
+int amp_comm_wait(amp_ctx* ctx);
 /* per bucket of the last gradient exchange: microseconds on the communication stream from "inputs ready and stream free" to
  * "reduced" (with peers: includes waiting for the slowest rank to arrive); -1 for a bucket that was not exchanged */
 int amp_comm_bucket_stats(amp_ctx* ctx, float us[/* AMP_GRAD_BUCKETS */ 7]);

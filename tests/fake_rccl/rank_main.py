@@ -68,7 +68,7 @@ def main(out_path):
     def arena():
         p, nf = model.grad_arena()
         g = np.empty(nf, dtype=np.float32)
-        ctx.sync(); ctx.d2h(g, p)
+        ctx.comm_wait(); ctx.sync(); ctx.d2h(g, p)       # the arena is read after the exchange, not beside it
         return g
 
     def gathered(x):

@@ -102,8 +102,8 @@ def test_det_seg_scores_reference_kat_and_oracle():
         blocks.append(m)
     gt = [rle.encode(m) for m in blocks]
     pred = [gt[2], gt[1], gt[3]]
-    assert np.array_equal(analyze._piecewise_iou(gt, pred), np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0], [0, 0, 1]], float))   # analyze.py:719-722
-    res = analyze._piecewise_rle_match(gt, pred)
+    assert np.array_equal(analyze.iou_matrix(gt, pred), np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0], [0, 0, 1]], float))   # analyze.py:719-722
+    res = analyze.rle_instance_matcher(gt, pred)
     assert res["tp"].tolist() == [[1, 1], [2, 0], [3, 2]] and res["fn"].tolist() == [0] and res["fp"].tolist() == []       # analyze.py:725-728
     sc = analyze.det_seg_scores(gt, pred)
     assert sc["det_precision"] == 1.0 and sc["det_recall"] == 0.75 and sc["seg_tp"].tolist() == [4, 4, 4]
@@ -116,6 +116,36 @@ def test_det_seg_scores_reference_kat_and_oracle():
     assert a["det_tp"].tolist() == ref["tp"].tolist() and np.allclose(a["det_tp_iou"], ref["iou"])
     for (gi, pi), tp, fn, fp in zip(a["det_tp"], a["seg_tp"], a["seg_fn"], a["seg_fp"]):
         assert tp == (g[gi] & p[pi]).sum() and fn == (g[gi] & ~p[pi]).sum() and fp == (~g[gi] & p[pi]).sum()
+    # exact IoU ties, shared predictions, thresholds that sit ON an IoU, more than 80 masks a side (the reference's block size):
+    # the product (array semantics, one C call) against the loop-for-loop restatement of the reference in oracle/matcher.py
+    for trial in range(12):
+        r = np.random.default_rng(100 + trial)
+        H, W = 24, 36
+        cells = [(y, x) for y in range(0, H, 6) for x in range(0, W, 6)]                     # 24 disjoint 6x6 cells
+        def blob(ks):
+            m = np.zeros((H, W), bool)
+            for k in ks:
+                y, x = cells[k]
+                m[y:y + 6, x:x + 6] = True
+            return m
+        n_g, n_p = (int(r.integers(1, 30)), int(r.integers(1, 30))) if trial < 10 else (int(r.integers(90, 130)), int(r.integers(85, 170)))
+        gm = [blob(r.choice(24, size=int(r.integers(1, 4)), replace=False)) for _ in range(n_g)]
+        pm_ = [blob(r.choice(24, size=int(r.integers(1, 4)), replace=False)) for _ in range(n_p)]   # unions of whole cells: IoUs are k/n, ties everywhere
+        pm_ += [m.copy() for m in pm_[:3]]                                                      # exact duplicates: first-maximum rule
+        ge, pe = [orle.encode(m) for m in gm], [orle.encode(m) for m in pm_]
+        for thr in (0.0, 0.25, 1 / 3, 0.5, 2 / 3, 0.999, 1.0):
+            got = analyze.rle_instance_matcher(ge, pe, iou_thresh=thr)
+            want = matcher.piecewise_rle_match(ge, pe, orle.iou, thr)
+            for k in ("tp", "fn", "fp"):
+                assert got[k].tolist() == want[k].tolist(), (trial, thr, k)
+            assert np.array_equal(got["iou"], want["iou"])
+            assert got["tp"].shape == (len(got["iou"]), 2)
+        assert np.array_equal(analyze.iou_matrix(ge, pe), matcher.piecewise_iou(ge, pe, orle.iou))
+    # no predictions: every ground truth is a false negative, and the detection precision is 0/0 as in the reference
+    res = analyze.rle_instance_matcher(gt, [])
+    assert res["tp"].shape == (0, 2) and res["fn"].tolist() == [0, 1, 2, 3] and res["fp"].tolist() == []
+    with pytest.raises(ZeroDivisionError):
+        analyze.det_seg_scores(gt, [])
     # polygon ground truth needs size
     from ampis_amd.structures import PolygonMasks
     pm = PolygonMasks([[[1, 1, 8, 1, 8, 8, 1, 8]]])
