@@ -22,14 +22,14 @@ def install_as_detectron2():
     from . import config, data, engine, model_zoo, rle, structures
     from .engine import defaults, hooks
     from .structures import boxes, instances, masks
-    from .utils import comm, logger
+    from .utils import comm, logger, visualizer
 
     root = types.ModuleType("detectron2")
     root.__doc__ = "ampis_amd façade registered as detectron2"
     root.__path__ = []
     utils = types.ModuleType("detectron2.utils")
     utils.__path__ = []
-    utils.comm, utils.logger = comm, logger
+    utils.comm, utils.logger, utils.visualizer = comm, logger, visualizer
     root.config, root.data, root.engine, root.model_zoo, root.structures, root.utils = config, data, engine, model_zoo, structures, utils
     mods = {
         "detectron2": root, "detectron2.config": config, "detectron2.data": data, "detectron2.engine": engine,
@@ -37,6 +37,7 @@ def install_as_detectron2():
         "detectron2.structures": structures, "detectron2.structures.boxes": boxes,
         "detectron2.structures.instances": instances, "detectron2.structures.masks": masks,
         "detectron2.utils": utils, "detectron2.utils.comm": comm, "detectron2.utils.logger": logger,
+        "detectron2.utils.visualizer": visualizer,
     }
     for k, v in mods.items():
         sys.modules.setdefault(k, v)

@@ -13,6 +13,23 @@ class BoxMode(IntEnum):
     XYWH_REL = 3
     XYWHA_ABS = 4
 
+    @staticmethod
+    def convert(box, from_mode, to_mode):
+        """XYXY_ABS <-> XYWH_ABS of one box (list / tuple) or an [N, 4] array; the other modes need the image size and are not used by
+        AMPIS (ampis/data_utils.py:426,472,518 write XYXY_ABS only)."""
+        import numpy as np
+        from_mode, to_mode = BoxMode(from_mode), BoxMode(to_mode)
+        if from_mode == to_mode:
+            return box
+        assert {from_mode, to_mode} == {BoxMode.XYXY_ABS, BoxMode.XYWH_ABS}, "only XYXY_ABS <-> XYWH_ABS"
+        single = isinstance(box, (list, tuple))
+        a = np.array(box, dtype=np.float64).reshape(-1, 4)
+        if to_mode == BoxMode.XYWH_ABS:
+            a[:, 2:] -= a[:, :2]
+        else:
+            a[:, 2:] += a[:, :2]
+        return type(box)(a[0].tolist()) if single else a
+
 
 class Boxes:
     def __init__(self, tensor):

@@ -183,3 +183,31 @@ def test_bench_reads_the_pmc_summary_of_its_own_leg():
     rp = b.rocprof_reported("infer")
     assert rp and rp["source"] == src and any(k.startswith("roi_align") for k in rp["kernels"])
     assert all(v["hbm_GBps"] is not None for v in rp["kernels"].values())
+
+
+def test_visualizer_members_ampis_calls():
+    """detectron2.utils.visualizer.Visualizer as ampis/visualize.py:154-164,291,326-328 uses it: RLE dicts, polygons and bool arrays in,
+    uint8 image out; mask pixels are blended, everything else keeps the input; draw_dataset_dict / draw_instance_predictions."""
+    from ampis_amd import rle
+    from ampis_amd.structures import Boxes, BoxMode, Instances
+    from ampis_amd.utils.visualizer import Visualizer
+    img = np.full((60, 80, 3), 100, np.uint8)
+    m0 = np.zeros((60, 80), bool); m0[10:30, 10:40] = True
+    m1 = np.zeros((60, 80), bool); m1[35:55, 50:75] = True
+    boxes = np.array([[10, 10, 39, 29], [50, 35, 74, 54]], np.float32)
+    out = Visualizer(img, {"thing_classes": ["a"]}, scale=1).overlay_instances(boxes=boxes, masks=[rle.encode(m0), rle.encode(m1)],
+                                                                               labels=["", ""], assigned_colors=np.array([[1, 0, 0], [0, 1, 0]])).get_image()
+    assert out.shape == img.shape and out.dtype == np.uint8
+    assert np.array_equal(out[~(m0 | m1)], img[~(m0 | m1)])                    # boxes coincide with the masks' extents here
+    assert out[20, 20, 0] > 150 and out[20, 20, 1] < 100 and out[45, 60, 1] > 150   # red fill, green fill
+    # same picture from bool arrays and from polygons
+    out2 = Visualizer(img, None).overlay_instances(masks=np.stack([m0, m1]), assigned_colors=np.array([[1, 0, 0], [0, 1, 0]])).get_image()
+    assert np.array_equal(out2[20:25, 20:25], out[20:25, 20:25])
+    dd = {"annotations": [{"bbox": [10, 10, 30, 20], "bbox_mode": BoxMode.XYWH_ABS, "segmentation": [[10, 10, 40, 10, 40, 30, 10, 30]], "category_id": 0}]}
+    out3 = Visualizer(img, {"thing_classes": [""]}).draw_dataset_dict(dd).get_image()
+    assert (out3[12:28, 12:38] != 100).any() and np.array_equal(out3[40:, :], img[40:, :])
+    inst = Instances((60, 80), pred_boxes=Boxes(boxes), scores=np.array([0.9, 0.8], np.float32), pred_classes=np.array([0, 0]),
+                     pred_masks=[rle.encode(m0), rle.encode(m1)])
+    out4 = Visualizer(img, {"thing_classes": ["p"]}, scale=2).draw_instance_predictions(inst).get_image()
+    assert out4.shape == (120, 160, 3) and (out4 != 100).any()
+    assert BoxMode.convert([10, 10, 30, 20], BoxMode.XYWH_ABS, BoxMode.XYXY_ABS) == [10.0, 10.0, 40.0, 30.0]

@@ -123,3 +123,199 @@ def test_install_refuses_to_shadow_a_real_detectron2(tmp_path):
     code = f"import sys; sys.path.insert(0, {str(tmp_path)!r}); sys.path.insert(0, {ROOT!r}); import ampis_amd\ntry:\n    ampis_amd.install_as_detectron2()\nexcept RuntimeError as e:\n    print('REFUSED', e)\n"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "REFUSED" in r.stdout, r.stdout + r.stderr
+
+
+# ---- every import / from line of the six reference modules, executed on the façade ------------------------------------
+# The lines are facts about the API surface, listed by module; relative imports of the package itself are exercised by the second test.
+PREAMBLE = textwrap.dedent('''
+    import os, sys, types
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, ROOT)
+    import ampis_amd
+    ampis_amd.install_as_detectron2()
+    # stand-ins for the two image libraries this image lacks (skimage, cv2): importable, nothing more
+    def _stub(name, **attrs):
+        if name in sys.modules:
+            return sys.modules[name]
+        m = types.ModuleType(name); m.__dict__.update(attrs); m.__path__ = []
+        sys.modules[name] = m
+        return m
+    import importlib.util
+    if importlib.util.find_spec("skimage") is None:
+        sk = _stub("skimage")
+        sk.io = _stub("skimage.io"); sk.measure = _stub("skimage.measure"); sk.draw = _stub("skimage.draw", polygon2mask=lambda shape, poly: None)
+    if importlib.util.find_spec("cv2") is None:
+        def _imread(p, *a):
+            import numpy as np
+            from PIL import Image
+            return np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1].copy()
+        _stub("cv2", imread=_imread)
+''')
+
+IMPORT_LINES = textwrap.dedent('''
+    # ampis/data_utils.py:11-29
+    import datetime, json, pickle, logging, time
+    import numpy as np
+    from pathlib import Path
+    import pycocotools.mask as RLE
+    import skimage
+    import skimage.io
+    import skimage.measure
+    import torch
+    from detectron2.data import DatasetMapper, build_detection_test_loader
+    from detectron2.engine.hooks import HookBase
+    from detectron2.engine.defaults import DefaultTrainer
+    import detectron2.utils.comm as comm
+    from detectron2.utils.logger import log_every_n_seconds
+    from detectron2.structures import BoxMode
+    # ampis/structures.py:8-19
+    import copy
+    import pandas as pd
+    from skimage.draw import polygon2mask
+    from typing import List, Union
+    from detectron2.structures import Boxes, BitMasks, PolygonMasks, Instances
+    # ampis/analyze.py:9-14
+    import pycocotools.mask as rle
+    from detectron2.structures import Instances
+    # ampis/visualize.py:7-14
+    import colorsys
+    import cv2
+    import matplotlib.pyplot as plt
+    from detectron2.data import MetadataCatalog
+    from detectron2.utils.visualizer import Visualizer
+    # ampis/applications/powder.py:14-22
+    import skimage.io
+    from detectron2.structures import Instances
+    import ampis_amd.utils.visualizer, ampis_amd.engine.defaults
+    assert Visualizer is ampis_amd.utils.visualizer.Visualizer and DefaultTrainer is ampis_amd.engine.defaults.DefaultTrainer
+    assert callable(log_every_n_seconds) and BoxMode.XYXY_ABS == 0
+    print("IMPORT LINES OK")
+''')
+
+
+def test_every_import_line_of_the_six_reference_modules_resolves_on_the_facade(tmp_path):
+    script = f"ROOT = {ROOT!r}\n" + PREAMBLE + IMPORT_LINES
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0 and "IMPORT LINES OK" in r.stdout, r.stderr[-3000:]
+
+
+REFERENCE = "/root/reference"
+
+REFERENCE_RUN = textwrap.dedent('''
+    import pickle
+    import numpy as np
+    sys.path.insert(0, REFERENCE)
+    for _alias, _t in (("int", int), ("float", float), ("bool", bool)):    # the reference targets numpy < 1.24 (env.yml): the aliases numpy 2 removed
+        if not hasattr(np, _alias):
+            setattr(np, _alias, _t)
+    import ampis                                                            # the reference package itself, unmodified
+    from ampis import analyze, data_utils, structures, visualize, applications
+    import ampis_amd.engine, ampis_amd.analyze as product, ampis_amd.data_utils as product_du, ampis_amd.rle as prle
+    assert data_utils.DefaultTrainer is ampis_amd.engine.DefaultTrainer and issubclass(data_utils.AmpisTrainer, ampis_amd.engine.DefaultTrainer)
+    assert issubclass(data_utils.LossEvalHook, ampis_amd.engine.HookBase)
+
+    # (1) the reference's own known-answer test (analyze.py:702-728) runs on the C-ABI codec
+    enc = lambda a: prle.encode(np.asfortranarray(np.array(a, np.uint8)))
+    m1 = enc([[1, 1, 0, 0], [1, 1, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]]); m2 = enc([[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 0, 0], [0, 0, 0, 0]])
+    m3 = enc([[0, 0, 0, 0], [0, 0, 0, 0], [1, 1, 0, 0], [1, 1, 0, 0]]); m4 = enc([[0, 0, 0, 0], [0, 0, 0, 0], [0, 0, 1, 1], [0, 0, 1, 1]])
+    gt, pred = [m1, m2, m3, m4], [m3, m2, m4]
+    assert np.all(analyze._piecewise_iou(gt, pred) == np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0], [0, 0, 1]]))
+    match = analyze._piecewise_rle_match(gt, pred)
+    assert np.all(match["tp"] == np.array([[1, 1], [2, 0], [3, 2]])) and np.all(match["fn"] == np.array([0])) and len(match["fp"]) == 0
+
+    # (2) the product's evaluation harness against the REFERENCE's, on random masks with exact ties and > 80 masks a side
+    for trial in range(6):
+        r = np.random.default_rng(trial)
+        H, W = 24, 36
+        cells = [(y, x) for y in range(0, H, 6) for x in range(0, W, 6)]
+        def blob(ks):
+            m = np.zeros((H, W), np.uint8)
+            for k in ks:
+                m[cells[k][0]:cells[k][0] + 6, cells[k][1]:cells[k][1] + 6] = 1
+            return m
+        ng, npred = (int(r.integers(1, 30)), int(r.integers(1, 30))) if trial < 4 else (100, 170)
+        g = [enc(blob(r.choice(24, size=int(r.integers(1, 4)), replace=False))) for _ in range(ng)]
+        p = [enc(blob(r.choice(24, size=int(r.integers(1, 4)), replace=False))) for _ in range(npred)]
+        p += p[:2]
+        assert np.array_equal(product.iou_matrix(g, p), analyze._piecewise_iou(g, p))
+        for thr in (0.0, 1 / 3, 0.5, 0.999):
+            a, b = product.rle_instance_matcher(g, p, iou_thresh=thr), analyze._piecewise_rle_match(g, p, iou_thresh=thr)
+            assert all(np.array_equal(np.asarray(a[k]).reshape(-1), np.asarray(b[k]).reshape(-1)) for k in ("tp", "fn", "fp", "iou")), (trial, thr)
+        gi = structures.InstanceSet(); gi.instances = structures.Instances((H, W), masks=structures.RLEMasks(g))
+        pi = structures.InstanceSet(); pi.instances = structures.Instances((H, W), masks=structures.RLEMasks(p))
+        want = analyze.det_seg_scores(gi, pi, size=(H, W))
+        got = product.det_seg_scores(g, p, size=(H, W))
+        for k in want:
+            assert np.allclose(np.asarray(got[k], float).reshape(-1), np.asarray(want[k], float).reshape(-1), equal_nan=True), k
+
+    # (3) InstanceSet.read_from_model_out (structures.py:312-371) and the filters on the reference's own pickle cut
+    with open(FIXTURE, "rb") as f:
+        outs = pickle.load(f)
+    iset = structures.InstanceSet().read_from_model_out(outs, inplace=False)
+    assert len(iset.instances) == 12 and iset.dataset_class == "Train" and isinstance(iset.instances.masks, structures.RLEMasks)
+    assert iset.instances.colors.shape == (12, 3)
+    areas = structures.mask_areas(iset.instances.masks)
+    assert np.array_equal(np.asarray(areas), prle.area(iset.instances.masks.rle))
+    small = iset.filter_mask_size(min_thresh=float(np.sort(areas)[3]), max_thresh=float(np.sort(areas)[-1]) + 1)
+    assert 0 < len(small) < 12 and isinstance(small.masks, structures.RLEMasks)      # returns an Instances (structures.py:374-438)
+    trimmed = iset.copy()
+    trimmed.remove_edge_instances()                                                   # in place (structures.py:445-472)
+    assert len(trimmed.instances) <= 12
+
+    # (4) compress_pred / format_outputs of the reference on the façade's Instances == the product's mirror
+    from detectron2.structures import Instances, Boxes
+    import torch
+    dense = np.stack([prle.decode(m).astype(bool) for m in outs["pred"]["instances"].pred_masks[:3]])
+    def fresh():
+        return Instances((1024, 1536), pred_boxes=Boxes(torch.as_tensor(outs["pred"]["instances"].pred_boxes[:3])), scores=torch.as_tensor(outs["pred"]["instances"].scores[:3]),
+                         pred_classes=torch.as_tensor(outs["pred"]["instances"].pred_classes[:3]), pred_masks=torch.as_tensor(dense))
+    a = data_utils.format_outputs("x.png", "d_Train", {"instances": fresh()})
+    b = product_du.format_outputs("x.png", "d_Train", {"instances": fresh()})
+    ia, ib = a["pred"]["instances"], b["pred"]["instances"]
+    assert [m["counts"] for m in ia.pred_masks] == [m["counts"] for m in ib.pred_masks] == [m["counts"] for m in outs["pred"]["instances"].pred_masks[:3]]
+    assert np.array_equal(ia.pred_boxes, ib.pred_boxes) and np.array_equal(ia.scores, ib.scores) and ia.pred_classes.dtype == ib.pred_classes.dtype
+
+    # (5) dataset ingestion: the reference's get_ddicts('via2') against the product's on the reference's four VIA projects
+    #     (sizes are declared in the files' attributes, so no image is read)
+    via_dir = os.path.join(REFERENCE, "examples", "powder", "data", "via_2.0.8")
+    os.chdir(via_dir)
+    n_inst = 0
+    for js in sorted(f for f in os.listdir(".") if f.endswith(".json")):
+        ref_dd = data_utils.get_ddicts("via2", js, dataset_class="Train")
+        mine = product_du.get_ddicts("via2", js, dataset_class="Train")
+        assert len(mine) == len(ref_dd) > 0
+        for x, y in zip(mine, ref_dd):
+            assert set(x) == set(y), (set(x) ^ set(y))
+            for k in y:
+                if k != "annotations":
+                    assert x[k] == y[k], (js, k, x[k], y[k])
+            for ax_, ay in zip(x["annotations"], y["annotations"]):
+                assert set(ax_) == set(ay)
+                assert np.array_equal(np.asarray(ax_["bbox"]), np.asarray(ay["bbox"])) and ax_["bbox_mode"] == ay["bbox_mode"]
+                assert ax_["category_id"] == ay["category_id"] and len(ax_["segmentation"]) == len(ay["segmentation"]) == 1
+                assert np.array_equal(np.asarray(ax_["segmentation"][0], float), np.asarray(ay["segmentation"][0], float))
+                n_inst += 1
+    assert n_inst > 2000
+    print("VIA PARITY", n_inst)
+
+    # (6) the visualisation calls of notebook cells 16 / 28 on the façade's Visualizer
+    img = np.full((1024, 1536, 3), 90, np.uint8)
+    out_img = visualize.display_iset(img, iset, metadata={"thing_classes": ["particle"]}, get_img=True, apply_correction=True)
+    assert out_img.shape == img.shape and out_img.dtype == np.uint8 and (out_img != img).any()
+    keep = np.logical_or.reduce([prle.decode(m).astype(bool) for m in iset.instances.masks.rle])
+    assert np.array_equal(out_img[~keep], img[~keep])                       # apply_correction: pixels outside every mask are the image's
+    print("REFERENCE RUN OK")
+''')
+
+
+def test_the_reference_package_itself_imports_and_runs_on_the_facade(tmp_path):
+    """Here (where /root/reference exists; skipped elsewhere): `import ampis` -- the reference, unmodified -- with the façade installed,
+    then its own KAT, its evaluation harness against the product's, read_from_model_out + filters on its own pickle cut,
+    compress_pred / format_outputs against the product's mirror, and display_iset through the façade's Visualizer."""
+    import pytest
+    if not os.path.isdir(os.path.join(REFERENCE, "ampis")):
+        pytest.skip("the reference tree is not on this machine")
+    fixture = os.path.join(ROOT, "tests", "golden", "particle_results_subset.pickle")
+    script = f"ROOT = {ROOT!r}\nFIXTURE = {fixture!r}\nREFERENCE = {REFERENCE!r}\n" + PREAMBLE + REFERENCE_RUN
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and "REFERENCE RUN OK" in r.stdout, (r.stdout[-1500:] + r.stderr[-4000:])
