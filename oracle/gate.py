@@ -16,7 +16,14 @@ north_star: outputs match the reference CPU path "within a stated fp32 tolerance
      with that constant).  So the oracle's own pasted probability at a differing pixel (detectron2 _do_paste_mask, re-evaluated
      here) must satisfy  |p - 0.5| < PROB_NOISE + 2 d 28 (1/w + 1/h) max_step,  and never more than TIE_CAP;
   4. a mask without tie pixels is therefore bit-identical (IoU = 1): "IoU >= 0.999 for every mask that has no threshold tie"
-     holds by construction.  Tie pixels are counted and reported (tie_pixels, worst_margin, iou_below).
+     holds by construction -- and is asserted (identical + tie_masks == instances, every identical mask has IoU 1).
+What the rule RELAXES against the north star's bare numbers, and how much of it a run used, is part of the returned statistics
+and of summary(), which every end-to-end test prints and smoke() reports:
+  * box_rel_used: instances whose box passed only through the relative term (|d| >= 1e-3 px; possible only above 333 px);
+  * tie_pixels_beyond_noise: differing pixels whose margin exceeds the fixed PROB_NOISE, i.e. that needed the box-movement term;
+  * iou_below / iou_min: masks whose IoU against the oracle's is below 0.999 (a single tied pixel does that to a mask of fewer
+    than 1000 pixels) and the lowest IoU seen; assert_bounds() caps their share at the level a test measured, so a regression shows;
+  * max_tie_pixels: the most differing pixels in any one mask.
 """
 import numpy as np
 import torch
@@ -39,12 +46,16 @@ def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_to
     assert np.all(np.diff(hip["scores"]) <= 0), "scores must be sorted descending"
     used = set()
     bad = []
-    st = dict(instances=len(rb), identical=0, tie_masks=0, tie_pixels=0, worst_margin=0.0, worst_box=0.0, worst_score=0.0, iou_below=0)
+    st = new_stats()
+    st["instances"] = len(rb)
     for i in range(len(rb)):
         d = np.abs(hip["boxes"] - rb[i]).max(axis=1)
         j = int(np.argmin(d))
         bw, bh = float(rb[i][2] - rb[i][0]), float(rb[i][3] - rb[i][1])
         st["worst_box"] = max(st["worst_box"], float(d[j]))
+        if max(bw, bh) <= 333.0:
+            st["worst_box_le333"] = max(st["worst_box_le333"], float(d[j]))
+        st["box_rel_used"] += int(box_tol <= d[j] < BOX_REL * max(bw, bh))
         if not d[j] < max(box_tol, BOX_REL * max(bw, bh)):
             bad.append(f"instance {i} ({bw:.0f}x{bh:.0f} px): nearest HIP box is {d[j]:.3e} px away")
             continue
@@ -86,18 +97,61 @@ def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_to
             continue
         st["tie_masks"] += 1
         st["tie_pixels"] += nd
+        st["tie_pixels_beyond_noise"] += int((margin >= PROB_NOISE).sum())
+        st["max_tie_pixels"] = max(st["max_tie_pixels"], nd)
         st["worst_margin"] = max(st["worst_margin"], worst)
         u = int((gm | rm[i]).sum())
-        st["iou_below"] += int(u > 0 and (gm & rm[i]).sum() / u < 0.999)
+        iou = float((gm & rm[i]).sum()) / u if u > 0 else 1.0
+        st["iou_min"] = min(st["iou_min"], iou)
+        if iou < 0.999:
+            st["iou_below"] += 1
+            st["iou_below_area_max"] = max(st["iou_below_area_max"], int(rm[i].sum()))
     assert not bad, f"{len(bad)} of {len(rb)} instances violate the gate: " + "; ".join(bad[:6]) + f" | {st}"
+    # rule 4 as a check: every instance is either bit-identical (IoU 1) or a counted tie mask
+    assert st["identical"] + st["tie_masks"] == st["instances"], st
+    return st
+
+
+_SUM = ("instances", "identical", "tie_masks", "tie_pixels", "tie_pixels_beyond_noise", "iou_below", "box_rel_used")
+_MAX = ("worst_margin", "worst_box", "worst_box_le333", "worst_score", "max_tie_pixels", "iou_below_area_max")
+
+
+def new_stats():
+    st = {k: 0 for k in _SUM}
+    st.update({k: 0.0 for k in _MAX})
+    st["max_tie_pixels"] = st["iou_below_area_max"] = 0
+    st["iou_min"] = 1.0
     return st
 
 
 def merge(stats):
-    out = dict(instances=0, identical=0, tie_masks=0, tie_pixels=0, worst_margin=0.0, worst_box=0.0, worst_score=0.0, iou_below=0)
+    out = new_stats()
     for s in stats:
-        for k in ("instances", "identical", "tie_masks", "tie_pixels", "iou_below"):
+        for k in _SUM:
             out[k] += s[k]
-        for k in ("worst_margin", "worst_box", "worst_score"):
+        for k in _MAX:
             out[k] = max(out[k], s[k])
+        out["iou_min"] = min(out["iou_min"], s["iou_min"])
     return out
+
+
+def summary(st):
+    """One line with everything the gate measured, relaxations included (printed by every end-to-end test and by smoke())."""
+    n = max(st["instances"], 1)
+    return (f"gate: {st['instances']} instances | boxes worst {st['worst_box']:.2e} px (<= 333 px: {st['worst_box_le333']:.2e}), "
+            f"{st['box_rel_used']} passed only through the {BOX_REL:.0e} x side term | scores worst {st['worst_score']:.1e} | masks "
+            f"{st['identical']} bit-identical, {st['tie_masks']} with threshold ties ({st['tie_pixels']} px, at most {st['max_tie_pixels']} in one mask, "
+            f"{st['tie_pixels_beyond_noise']} beyond the fixed {PROB_NOISE:.0e} noise margin, worst |p-0.5| {st['worst_margin']:.1e}) | IoU < 0.999: "
+            f"{st['iou_below']} masks = {100.0 * st['iou_below'] / n:.2f} % (largest such mask {st['iou_below_area_max']} px, lowest IoU {st['iou_min']:.4f})")
+
+
+def assert_bounds(st, iou_below_share, box_rel_used=0, iou_min=0.0, max_tie_pixels=None):
+    """The measured level of each relaxation, as a cap: a regression (more small masks flipped, boxes drifting into the relative term)
+    fails here even though the per-instance rule still holds."""
+    n = max(st["instances"], 1)
+    assert st["iou_below"] <= iou_below_share * n + 1e-9, f"{st['iou_below']} of {n} masks below IoU 0.999 (cap {iou_below_share:.3f}): {summary(st)}"
+    assert st["box_rel_used"] <= box_rel_used, f"{st['box_rel_used']} boxes needed the relative term (cap {box_rel_used}): {summary(st)}"
+    assert st["worst_box_le333"] < BOX_TOL, f"a box of at most 333 px is {st['worst_box_le333']:.2e} px off: the bare 1e-3 px must hold there"
+    assert st["iou_min"] >= iou_min, summary(st)
+    if max_tie_pixels is not None:
+        assert st["max_tie_pixels"] <= max_tie_pixels, summary(st)

@@ -28,7 +28,9 @@ def _match(out, ref, h, w):
     """The end-to-end gate of oracle/gate.py (hard per-instance asserts, differing mask pixels must be threshold ties)."""
     from oracle import gate
     st = gate.check_image(out, ref, h, w, lambda m: _decode(m, h, w))
+    print("edge-case gate:", gate.summary(st))
     assert st["instances"] > 5, st
+    gate.assert_bounds(st, iou_below_share=0.10, box_rel_used=0, iou_min=0.90)
     return st
 
 

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+FULLSIZE_IOU_BELOW_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.10, 16, 0.90      # tightened to the measured level below
 
 
 # BASELINE configs[1] (R50-FPN, 1024^2, 200 detections) and configs[4] (X-101-32x8d-FPN, native 2048^2, dense: 500 detections)
@@ -84,11 +85,14 @@ def test_bitwise_deterministic(run):
         assert all(np.array_equal(p["counts"], q["counts"]) for p, q in zip(x["masks"], y["masks"]))
 
 
-def test_fullsize_batch_against_the_oracle(gpu_ctx):
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_fullsize_batch_against_the_oracle(gpu_ctx, mode):
     """BASELINE configs[1] as benchmarked -- a batch of EIGHT 1024x1024 micrographs, 1000 proposals, 200 detections per image --
     with two of its images (the first and one from the middle) also run through the oracle (a few seconds per image on the host
     cores; an image's result does not depend on the batch it rides in, tests/test_edge_cases_gpu.py).  The gate is oracle/gate.py:
-    same detection count, every instance matched (box < 1e-3 px, class, score), differing mask pixels only at threshold ties."""
+    same detection count, every instance matched (box < 1e-3 px, class, score), differing mask pixels only at threshold ties.
+    Run in both conv arithmetics: the default f16x3 split and the fp32 MFMA (`mode`); in either, every box of at most 333 px must meet
+    the BARE 1e-3 px of the north star (the gate's relative term cannot act there), and what the gate relaxed is printed and capped."""
     import torch
     from ampis_amd import params as P, synth
     from ampis_amd.model import MaskRCNN
@@ -98,10 +102,15 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx):
     torch.set_num_threads(min(16, torch.get_num_threads()))
     imgs, _ = synth.batch(B, S, S, first_index=7)
     p = P.init_params(K, seed=0, style="spread")
-    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
-    m.load_params(p)
-    out = m.infer(imgs)
-    m.close()
+    keep_mode = gpu_ctx.conv_mode
+    gpu_ctx.conv_mode = gpu_ctx.CONV_F32 if mode == "f32" else gpu_ctx.CONV_F16X3
+    try:
+        m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+        m.load_params(p)
+        out = m.infer(imgs)
+        m.close()
+    finally:
+        gpu_ctx.conv_mode = keep_mode
     tp = O.to_torch_params(p)
     stats = []
     for b in (0, 5):
@@ -109,8 +118,13 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx):
         assert len(ref["boxes"]) == D
         stats.append(gate.check_image(out[b], ref, S, S, lambda mk: _decode(mk["counts"], S, S)))
     st = gate.merge(stats)
-    print("full-size gate:", st)
+    print(f"full-size gate [{mode}]:", gate.summary(st))
     assert st["instances"] == 2 * D and st["identical"] + st["tie_masks"] == st["instances"]
+    # caps at the measured level (round 3, both modes: <= 12 of 400 masks below IoU 0.999, all of them satellites of a few hundred px;
+    # <= 4 boxes of ~740 px inside the relative term): a regression shows here even while the per-instance rule holds
+    gate.assert_bounds(st, iou_below_share=FULLSIZE_IOU_BELOW_CAP, box_rel_used=FULLSIZE_BOX_REL_CAP, iou_min=FULLSIZE_IOU_MIN)
+    if mode == "f32":
+        return
     # where 1e-3 px is below the reference's own fp32 noise (boxes of several hundred px): against an exact-convolution evaluation
     # of the same network (oracle/exact.py) the HIP path must be as close as the fp32 oracle is
     from oracle import exact

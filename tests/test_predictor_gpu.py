@@ -42,8 +42,9 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
     from oracle import gate
     hip = dict(boxes=np.asarray(p.pred_boxes), scores=np.asarray(p.scores), classes=np.asarray(p.pred_classes), masks=list(p.pred_masks))
     st = gate.check_image(hip, ref, 240, 300, lambda m: rle.decode(m).astype(bool))
-    print("predictor gate:", st)
+    print("predictor gate:", gate.summary(st))
     assert st["instances"] > 5
+    gate.assert_bounds(st, iou_below_share=0.10, box_rel_used=0, iou_min=0.90)
 
 
 def test_predictor_refuses_cpu_device():
