@@ -44,7 +44,9 @@ class ModelCfg(C.Structure):
 
 class Gt(C.Structure):
     _fields_ = [("B", C.c_int), ("gt_off", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
-                ("classes", C.POINTER(C.c_int)), ("poly_off", C.POINTER(C.c_int)), ("poly_xy", C.POINTER(C.c_double))]
+                ("classes", C.POINTER(C.c_int)), ("poly_off", C.POINTER(C.c_int)), ("poly_xy", C.POINTER(C.c_double)),
+                ("inst_poly_off", C.POINTER(C.c_int)), ("rle_off", C.POINTER(C.c_ulonglong)), ("rle_counts", C.POINTER(C.c_uint32)),
+                ("rle_hw", C.POINTER(C.c_int))]
 
 
 class ProfSummary(C.Structure):
@@ -160,6 +162,8 @@ def _declare(L):
         "amp_roi_sample": ([vp, i, vp, vp, i, vp, vp, vp, i, i, f, f, C.c_uint, vp, vp, vp, i, vp, vp, vp, vp, vp, i], i),
         "amp_box_loss": ([vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, C.POINTER(f), i, vp], i),
         "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_mask_targets_bitmask": ([vp, i, vp, vp, vp, vp, vp, vp, C.c_size_t, i, vp, vp], i),
+        "amp_mask_target_loss_fmt": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_model_forward_backward": ([vp, vp, i, i, i, i, C.POINTER(Gt), C.c_uint, C.POINTER(f)], i),
         "amp_model_grad_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),
         "amp_model_momentum_arena": ([vp, C.POINTER(vp), C.POINTER(C.c_size_t)], i),

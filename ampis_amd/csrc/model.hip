@@ -126,6 +126,9 @@ struct amp_model {
     std::vector<int> gb_bucket;
     std::vector<size_t> gb_off, gb_n;
     int grad_overlap = -1;              // -1: on when the context has a communicator; 0 / 1: amp_model_set_grad_overlap
+    unsigned int* bm_scratch = nullptr; // window bit maps of amp_mask_targets_bitmask (bitmask ground truth), grown on demand
+    size_t bm_words = 0;
+    int* bm_flag = nullptr;
     unsigned issued_mask = 0;           // buckets of the current gradients already handed to RCCL (bit b); all set = exchanged
 };
 
@@ -780,7 +783,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     m->saving = false;
     AMP_TRY(trunk_status);
     const int total_gt = dry ? c.max_gt : gt->gt_off[B];
-    const int npoly = dry ? c.max_poly_doubles : gt->poly_off[total_gt];
+    const int npoly = dry ? c.max_poly_doubles : gt->poly_off[gt->inst_poly_off ? gt->inst_poly_off[total_gt] : total_gt];
     AMP_REQUIRE(total_gt <= c.max_gt && npoly <= c.max_poly_doubles, "amp_model_forward_losses: %d instances / %d polygon doubles exceed cfg.max_gt / max_poly_doubles", total_gt, npoly);
     int A = 0;
     for (int l = 0; l < 5; ++l) A += T.fh[l] * T.fw[l] * 3;
@@ -788,8 +791,15 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(d_gt_boxes, float, (size_t)std::max(total_gt, 1) * 4);
     AMP_ALLOC(d_gt_cls, int, (size_t)std::max(total_gt, 1));
     AMP_ALLOC(d_gt_off, int, (size_t)B + 1);
-    AMP_ALLOC(d_poly_off, int, (size_t)total_gt + 1);
+    // polygons: one per instance (gt->inst_poly_off == NULL) or a range of polygons per instance; bitmask instances carry run lengths
+    const int n_polys = dry ? c.max_gt : (gt->inst_poly_off ? gt->inst_poly_off[total_gt] : total_gt);
+    const size_t n_runs = (dry || !gt->rle_off) ? 0 : (size_t)gt->rle_off[total_gt];
+    AMP_REQUIRE(dry || n_polys <= c.max_gt, "amp_model_forward_losses: %d polygons exceed cfg.max_gt", n_polys);
+    AMP_ALLOC(d_poly_off, int, (size_t)std::max(n_polys, total_gt) + 1);
+    AMP_ALLOC(d_inst_poly_off, int, (size_t)total_gt + 1);
     AMP_ALLOC(d_poly_xy, double, (size_t)std::max(npoly, 1));
+    AMP_ALLOC(d_rle_off, unsigned long long, (size_t)total_gt + 1);
+    AMP_ALLOC(d_rle_hw, int, (size_t)std::max(total_gt, 1) * 2);
     AMP_ALLOC(match_val, float, (size_t)B * A);
     AMP_ALLOC(match_idx, int, (size_t)B * A);
     AMP_ALLOC(gt_best, unsigned int, (size_t)std::max(total_gt, 1));
@@ -808,7 +818,13 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     }
     if (!dry) {
         AMP_HIP_CHECK(hipMemcpyAsync(d_gt_off, gt->gt_off, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-        AMP_HIP_CHECK(hipMemcpyAsync(d_poly_off, gt->poly_off, (size_t)(total_gt + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        AMP_HIP_CHECK(hipMemcpyAsync(d_poly_off, gt->poly_off, (size_t)(n_polys + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (gt->inst_poly_off) AMP_HIP_CHECK(hipMemcpyAsync(d_inst_poly_off, gt->inst_poly_off, (size_t)(total_gt + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (gt->rle_off) {
+            AMP_REQUIRE(gt->rle_counts && gt->rle_hw, "amp_model_forward_losses: amp_gt.rle_off without rle_counts / rle_hw");
+            AMP_HIP_CHECK(hipMemcpyAsync(d_rle_off, gt->rle_off, (size_t)(total_gt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (total_gt) AMP_HIP_CHECK(hipMemcpyAsync(d_rle_hw, gt->rle_hw, (size_t)total_gt * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
         if (total_gt) {
             AMP_HIP_CHECK(hipMemcpyAsync(d_gt_boxes, gt->boxes, (size_t)total_gt * 16, hipMemcpyHostToDevice, ctx->stream));
             AMP_HIP_CHECK(hipMemcpyAsync(d_gt_cls, gt->classes, (size_t)total_gt * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -901,6 +917,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     }
     if (dry && !backward) return AMP_OK;
     std::vector<float> h_mpart(N);
+    int bm_overflow = 0;
     if (N > 0 && !dry) {
         std::vector<int> hb(N), hc(N), hp(N);
         for (int b = 0; b < B; ++b) {
@@ -927,8 +944,32 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
-        AMP_TRY(amp_mask_target_loss(ctx, N, Kp, mlogits, d_mlogits, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, m_partial, m_targets));
+        if (n_runs) {
+            // bitmask ground truth: BitMasks.crop_and_resize from the run lengths.  The runs travel in a buffer of their own (their
+            // size is data-dependent: not part of the workspace plan), the window bit maps in a scratch of <= 256 frame-sized slots.
+            const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+            for (int i = 0; i < total_gt; ++i)
+                AMP_REQUIRE(gt->rle_off[i + 1] == gt->rle_off[i] || (gt->rle_hw[2 * i] >= 1 && gt->rle_hw[2 * i] <= Hp && gt->rle_hw[2 * i + 1] >= 1 && gt->rle_hw[2 * i + 1] <= Wp),
+                            "amp_model_forward_losses: the bitmask of instance %d is %dx%d, the frame %dx%d", i, gt->rle_hw[2 * i], gt->rle_hw[2 * i + 1], Hp, Wp);
+            const size_t slot = (size_t)Wp * (Hp / 32 + 1);
+            const int nslots = std::min(N, 256);
+            const size_t need = slot * nslots + (n_runs + 63) / 64 * 64;
+            if (m->bm_words < need) {
+                AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (m->bm_scratch) AMP_HIP_CHECK(hipFree(m->bm_scratch));
+                m->bm_scratch = nullptr; m->bm_words = 0;
+                AMP_HIP_CHECK(hipMalloc(&m->bm_scratch, need * sizeof(unsigned int)));
+                m->bm_words = need;
+            }
+            if (!m->bm_flag) { AMP_HIP_CHECK(hipMalloc(&m->bm_flag, sizeof(int))); AMP_HIP_CHECK(hipMemsetAsync(m->bm_flag, 0, sizeof(int), ctx->stream)); }
+            unsigned int* d_runs = m->bm_scratch + slot * nslots;
+            AMP_HIP_CHECK(hipMemcpyAsync(d_runs, gt->rle_counts, n_runs * sizeof(unsigned int), hipMemcpyHostToDevice, ctx->stream));
+            AMP_TRY(amp_mask_targets_bitmask(ctx, N, m_rois, m_poly, d_rle_off, d_runs, d_rle_hw, m->bm_scratch, slot, nslots, m_targets, m->bm_flag));
+        }
+        AMP_TRY(amp_mask_target_loss_fmt(ctx, N, Kp, mlogits, d_mlogits, m_rois, m_cls, m_poly, d_poly_xy, d_poly_off, gt->inst_poly_off ? d_inst_poly_off : nullptr,
+                                         n_runs ? d_rle_off : nullptr, m_targets, m_partial, m_targets));
         AMP_HIP_CHECK(hipMemcpyAsync(h_mpart.data(), m_partial, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (n_runs) AMP_HIP_CHECK(hipMemcpyAsync(&bm_overflow, m->bm_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         tap(m, "train_mask_targets", m_targets, 4, {N, 28, 28});
         tap(m, "train_mask_logits", mlogits, 0, {N, 28, 28, Kp});
     }
@@ -937,6 +978,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_HIP_CHECK(hipMemcpyAsync(h_rpn.data(), rpn_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(h_box.data(), box_partial, (size_t)2 * B * 4, hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        AMP_REQUIRE(!bm_overflow, "amp_model_forward_losses: a bitmask window did not fit its scratch slot (internal sizing error)");
         float s_bce = 0.f, s_loc = 0.f, s_ce = 0.f, s_l1 = 0.f, s_mask = 0.f;
         for (int b = 0; b < B; ++b) { s_bce += h_rpn[2 * b]; s_loc += h_rpn[2 * b + 1]; s_ce += h_box[2 * b]; s_l1 += h_box[2 * b + 1]; }
         for (int i = 0; i < N; ++i) s_mask += h_mpart[i];
@@ -1412,6 +1454,8 @@ void amp_model_destroy(amp_model* m) {
     (void)hipFree(m->dgrad_arena);
     (void)hipFree(m->split_arena);
     (void)hipFree(m->img_stage);
+    if (m->bm_scratch) (void)hipFree(m->bm_scratch);
+    if (m->bm_flag) (void)hipFree(m->bm_flag);
     (void)hipFree(m->ws.base);
     (void)hipFree(m->d_batch_iota);
     (void)hipFree(m->d_flags);

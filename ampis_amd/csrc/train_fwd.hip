@@ -413,9 +413,12 @@ struct MaskLossArgs {
     float* dlogits;               // same shape (may be null)
     const float* rois;            // [N][4]
     const int* cls;               // [N]
-    const int* poly_id;           // [N] global instance index (polygon of the matched GT)
+    const int* poly_id;           // [N] global instance index (the matched GT)
     const double* poly_xy;        // flat vertex list
-    const int* poly_off;          // [instances+1] offsets into poly_xy (in doubles)
+    const int* poly_off;          // [polygons+1] offsets into poly_xy (in doubles)
+    const int* inst_poly_off;     // [instances+1] polygons of an instance (null: exactly one polygon per instance, polygon index = instance index)
+    const unsigned long long* rle_off;   // [instances+1] (null: no bitmask ground truth): an instance with runs takes its target from target_in
+    const unsigned char* target_in;      // [N][784] row-major targets of the bitmask instances (mask_target_bitmask_kernel)
     int N, K;
     float inv_count;              // 1 / (N * 784)
     float* partial;               // [N] per-RoI BCE sums
@@ -431,16 +434,27 @@ __global__ __launch_bounds__(64) void mask_target_loss_kernel(const MaskLossArgs
     __shared__ unsigned char bits[MS * MS];   // column-major: bits[x*28 + y]
     __shared__ float s_red[64];
     const int n = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < NWORDS; i += 64) tog[i] = 0u;
-    __syncthreads();
     const float* r = a.rois + (size_t)n * 4;
+    const int pid = a.poly_id[n];
+    const bool from_bitmask = a.rle_off && a.rle_off[pid + 1] > a.rle_off[pid];
+    if (from_bitmask) {      // BitMasks.crop_and_resize ran in mask_target_bitmask_kernel: row-major bytes -> this kernel's column-major bits
+        for (int i = lane; i < MS * MS; i += 64) { const int y = i / MS, x = i - y * MS; bits[x * MS + y] = a.target_in[(size_t)n * MS * MS + i]; }
+    } else {
+        for (int i = lane; i < MS * MS; i += 64) bits[i] = 0;
+    }
     // detectron2 rasterize_polygons_within_box: box arithmetic in fp32, polygon in fp64
     const float w32 = __fsub_rn(r[2], r[0]), h32 = __fsub_rn(r[3], r[1]);
     const double rw = (double)__fdiv_rn((float)MS, fmaxf(w32, 0.1f)), rh = (double)__fdiv_rn((float)MS, fmaxf(h32, 0.1f));
     const double bx = (double)r[0], by = (double)r[1];
-    const int pid = a.poly_id[n];
-    const double* xy = a.poly_xy + a.poly_off[pid];
-    const int k = (a.poly_off[pid + 1] - a.poly_off[pid]) / 2;
+    // polygons_to_bitmask: frPyObjects of every polygon of the instance, merged (union), decoded
+    const int q0 = from_bitmask ? 0 : (a.inst_poly_off ? a.inst_poly_off[pid] : pid);
+    const int q1 = from_bitmask ? 0 : (a.inst_poly_off ? a.inst_poly_off[pid + 1] : pid + 1);
+    for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    for (int i = lane; i < NWORDS; i += 64) tog[i] = 0u;
+    __syncthreads();
+    const double* xy = a.poly_xy + a.poly_off[q];
+    const int k = (a.poly_off[q + 1] - a.poly_off[q]) / 2;
     const double scale = 5.0;
     for (int j = lane; j < k; j += 64) {
         const int j2 = (j + 1 == k) ? 0 : j + 1;
@@ -483,7 +497,8 @@ __global__ __launch_bounds__(64) void mask_target_loss_kernel(const MaskLossArgs
         }
     }
     __syncthreads();
-    for (int i = lane; i < MS * MS; i += 64) bits[i] = (tog[i >> 5] >> (i & 31)) & 1u;
+    for (int i = lane; i < MS * MS; i += 64) bits[i] |= (unsigned char)((tog[i >> 5] >> (i & 31)) & 1u);
+    }
     __syncthreads();
     const int c = a.cls[n];
     float acc = 0.f;
@@ -506,6 +521,118 @@ __global__ __launch_bounds__(64) void mask_target_loss_kernel(const MaskLossArgs
         __syncthreads();
     }
     if (lane == 0) a.partial[n] = s_red[0];
+}
+
+// ---- mask targets from BITMASK ground truth: detectron2 BitMasks.crop_and_resize = torchvision roi_align(mask as a 1-channel fp32 map,
+// spatial_scale 1, sampling_ratio 0, aligned) >= 0.5 -------------------------------------------------------------------------------
+// The instance's full-image mask never exists densely: it arrives as COCO run lengths (column-major).  One workgroup per RoI
+//   1. finds the window of pixels the RoI's samples can touch,
+//   2. decodes the runs that cross it into a bit map of the window (column-major like the runs: a run is a few word-wide ORs) in a
+//      scratch slot of its own,
+//   3. evaluates the 28 x 28 bins with roi_align's arithmetic, operation for operation (roi_align_lanes_kernel above; taps are 0 / 1).
+struct BitmaskTargetArgs {
+    const float* rois;                    // [N][4]
+    const int* inst;                      // [N] instance of each RoI
+    const unsigned long long* rle_off;    // [instances+1] into rle_counts
+    const unsigned int* rle_counts;       // run lengths, the first run counts zeros
+    const int* rle_hw;                    // [instances][2] height, width of the instance's mask
+    unsigned int* scratch;                // [gridDim.x][slot_words]
+    size_t slot_words;
+    int N;
+    unsigned char* target;                // [N][784] row-major
+    int* overflow;                        // set when a window does not fit its slot (host sizes slots for the whole frame: never)
+};
+
+__global__ __launch_bounds__(256) void mask_target_bitmask_kernel(const BitmaskTargetArgs a) {
+    __shared__ unsigned long long s_scan[256];
+    const int tid = threadIdx.x;
+    unsigned int* bm = a.scratch + (size_t)blockIdx.x * a.slot_words;
+    for (int n = blockIdx.x; n < a.N; n += gridDim.x) {
+        const int inst = a.inst[n];
+        const unsigned long long r0 = a.rle_off[inst], r1 = a.rle_off[inst + 1];
+        if (r1 <= r0) continue;                                  // polygon instance: mask_target_loss_kernel rasterises it (block-uniform)
+        const int nr = (int)(r1 - r0);
+        const unsigned int* cnt = a.rle_counts + r0;
+        const int H = a.rle_hw[2 * inst], W = a.rle_hw[2 * inst + 1];
+        const float x1 = a.rois[4 * n + 0], y1 = a.rois[4 * n + 1], x2 = a.rois[4 * n + 2], y2 = a.rois[4 * n + 3];
+        const float sw = __fsub_rn(x1, 0.5f), sh = __fsub_rn(y1, 0.5f), ew = __fsub_rn(x2, 0.5f), eh = __fsub_rn(y2, 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)MS), bw = __fdiv_rn(rw, (float)MS);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)MS)), gw = (int)ceilf(__fdiv_rn(rw, (float)MS));
+        const float count = (float)max(gh * gw, 1);
+        // pixels a sample can read: columns floor(max(x, 0)) and +1 for x in [sw, ew] (a little slack for fp32 rounding of the positions)
+        const int wx0 = max(0, (int)floorf(fmaxf(sw, 0.f)) - 1), wx1 = min(W - 1, (int)floorf(fmaxf(ew, 0.f)) + 2);
+        const int wy0 = max(0, (int)floorf(fmaxf(sh, 0.f)) - 1), wy1 = min(H - 1, (int)floorf(fmaxf(eh, 0.f)) + 2);
+        const int ncols = max(wx1 - wx0 + 1, 0), nrows = max(wy1 - wy0 + 1, 0);
+        const int pitch = (nrows + 31) >> 5;                     // words per column
+        const size_t nwords = (size_t)ncols * pitch;
+        if (nwords > a.slot_words) { if (tid == 0) *a.overflow = 1; continue; }
+        __syncthreads();                                         // the previous RoI of this block has finished reading the slot
+        for (size_t i = tid; i < nwords; i += 256) bm[i] = 0u;
+        // start position of every run: each thread owns a contiguous chunk of runs; block-wide exclusive scan of the chunk sums
+        const int per = (nr + 255) / 256;
+        const int j0 = min(tid * per, nr), j1 = min(j0 + per, nr);
+        unsigned long long sum = 0;
+        for (int j = j0; j < j1; ++j) sum += cnt[j];
+        s_scan[tid] = sum;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const unsigned long long v = tid >= o ? s_scan[tid - o] : 0ull;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        unsigned long long pos = s_scan[tid] - sum;              // exclusive
+        for (int j = j0; j < j1; ++j) {
+            const unsigned long long s0 = pos, e0 = pos + cnt[j];
+            pos = e0;
+            if (!(j & 1) || e0 == s0) continue;                  // even runs are zeros
+            const int c_first = (int)(s0 / (unsigned)H), c_last = (int)((e0 - 1) / (unsigned)H);
+            for (int c = max(c_first, wx0); c <= min(c_last, wx1); ++c) {
+                const unsigned long long cb = (unsigned long long)c * H;
+                int ya = (int)((s0 > cb ? s0 : cb) - cb), yb = (int)((e0 < cb + H ? e0 : cb + H) - cb);     // [ya, yb) inside column c
+                ya = max(ya, wy0) - wy0; yb = min(yb, wy1 + 1) - wy0;
+                if (yb <= ya) continue;
+                unsigned int* col = bm + (size_t)(c - wx0) * pitch;
+                for (int wv = ya >> 5; wv <= (yb - 1) >> 5; ++wv) {
+                    const int lo = max(ya - (wv << 5), 0), hi = min(yb - (wv << 5), 32);                     // bits [lo, hi) of word wv
+                    const unsigned int mask = (hi == 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+                    atomicOr(&col[wv], mask);
+                }
+            }
+        }
+        __syncthreads();
+        auto tap = [&](int y, int x) -> float {                  // mask value of pixel (y, x); outside the window the mask is not sampled
+            const int yy = y - wy0, xx = x - wx0;
+            if (yy < 0 || yy >= nrows || xx < 0 || xx >= ncols) return 0.f;
+            return (float)((bm[(size_t)xx * pitch + (yy >> 5)] >> (yy & 31)) & 1u);
+        };
+        for (int i = tid; i < MS * MS; i += 256) {
+            const int ph = i / MS, pw = i - ph * MS;
+            float acc = 0.f;
+            for (int iy = 0; iy < gh; ++iy) {
+                float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(__fadd_rn((float)iy, 0.5f), bh), (float)gh));
+                if (y < -1.0f || y > (float)H) continue;
+                if (y <= 0.f) y = 0.f;
+                int ylo = (int)y, yhi;
+                if (ylo >= H - 1) { ylo = yhi = H - 1; y = (float)ylo; } else { yhi = ylo + 1; }
+                const float ly = __fsub_rn(y, (float)ylo), hy = __fsub_rn(1.0f, ly);
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(__fadd_rn((float)ix, 0.5f), bw), (float)gw));
+                    if (x < -1.0f || x > (float)W) continue;
+                    if (x <= 0.f) x = 0.f;
+                    int xlo = (int)x, xhi;
+                    if (xlo >= W - 1) { xlo = xhi = W - 1; x = (float)xlo; } else { xhi = xlo + 1; }
+                    const float lx = __fsub_rn(x, (float)xlo), hx = __fsub_rn(1.0f, lx);
+                    const float w1 = __fmul_rn(hy, hx), w2 = __fmul_rn(hy, lx), w3 = __fmul_rn(ly, hx), w4 = __fmul_rn(ly, lx);
+                    const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(w1, tap(ylo, xlo)), __fmul_rn(w2, tap(ylo, xhi))), __fmul_rn(w3, tap(yhi, xlo))),
+                                              __fmul_rn(w4, tap(yhi, xhi)));
+                    acc = __fadd_rn(acc, t);
+                }
+            }
+            a.target[(size_t)n * MS * MS + i] = (unsigned char)(__fdiv_rn(acc, count) >= 0.5f);
+        }
+    }
 }
 
 void fill_geom(AnchorGeom& g, const amp_rpn_levels* lv) {
@@ -591,16 +718,38 @@ int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int l
     return AMP_OK;
 }
 
-int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
-                         const int* poly_id, const double* poly_xy, const int* poly_off, float* partial, unsigned char* target_out) {
-    AMP_REQUIRE(ctx && logits && rois && cls && poly_id && poly_xy && poly_off && partial, "amp_mask_target_loss: null argument");
+int amp_mask_targets_bitmask(amp_ctx* ctx, int N, const float* rois, const int* inst, const unsigned long long* rle_off,
+                             const uint32_t* rle_counts, const int* rle_hw, unsigned int* scratch, size_t slot_words, int nslots,
+                             unsigned char* target, int* overflow_flag) {
+    AMP_REQUIRE(ctx && rois && inst && rle_off && rle_counts && rle_hw && scratch && target && overflow_flag && slot_words > 0 && nslots > 0,
+                "amp_mask_targets_bitmask: bad argument");
+    if (N == 0) return AMP_OK;
+    BitmaskTargetArgs a;
+    a.rois = rois; a.inst = inst; a.rle_off = rle_off; a.rle_counts = rle_counts; a.rle_hw = rle_hw; a.scratch = scratch;
+    a.slot_words = slot_words; a.N = N; a.target = target; a.overflow = overflow_flag;
+    hipLaunchKernelGGL(mask_target_bitmask_kernel, dim3(std::min(N, nslots)), dim3(256), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_mask_target_loss_fmt(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
+                             const int* inst, const double* poly_xy, const int* poly_off, const int* inst_poly_off,
+                             const unsigned long long* rle_off, const unsigned char* target_in, float* partial, unsigned char* target_out) {
+    AMP_REQUIRE(ctx && logits && rois && cls && inst && poly_xy && poly_off && partial, "amp_mask_target_loss: null argument");
+    AMP_REQUIRE(!rle_off || target_in, "amp_mask_target_loss: bitmask instances need the targets of amp_mask_targets_bitmask");
     if (N == 0) return AMP_OK;
     MaskLossArgs a;
-    a.logits = logits; a.dlogits = dlogits; a.rois = rois; a.cls = cls; a.poly_id = poly_id; a.poly_xy = poly_xy; a.poly_off = poly_off;
+    a.logits = logits; a.dlogits = dlogits; a.rois = rois; a.cls = cls; a.poly_id = inst; a.poly_xy = poly_xy; a.poly_off = poly_off;
+    a.inst_poly_off = inst_poly_off; a.rle_off = rle_off; a.target_in = target_in;
     a.N = N; a.K = K; a.inv_count = 1.0f / ((float)N * MS * MS); a.partial = partial; a.target_out = target_out;
     hipLaunchKernelGGL(mask_target_loss_kernel, dim3(N), dim3(64), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
+}
+
+int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
+                         const int* poly_id, const double* poly_xy, const int* poly_off, float* partial, unsigned char* target_out) {
+    return amp_mask_target_loss_fmt(ctx, N, K, logits, dlogits, rois, cls, poly_id, poly_xy, poly_off, nullptr, nullptr, nullptr, partial, target_out);
 }
 
 }  // extern "C"

@@ -3,7 +3,9 @@ DatasetMapper and the loaders AmpisTrainer names (ampis/data_utils.py:24,171-175
 
 A mapped sample is a dict: image_bgr uint8 [h,w,3] (after ResizeShortestEdge / RandomFlip), height / width of the ORIGINAL image,
 and in training mode gt = dict(boxes f32 [G,4] XYXY, classes i64 [G], polygons list[G] of flat xy float64) in resized coordinates.
-Only polygon ground truth (INPUT.MASK_FORMAT='polygon', what the tutorial uses, notebook cell 20) is supported for training."""
+Ground truth: INPUT.MASK_FORMAT='polygon' (what the tutorial uses, notebook cell 20; one or several polygons per instance) and
+'bitmask' (RLE / polygon segmentations turned into per-instance bitmasks at network-input resolution, kept as COCO run lengths:
+what get_ddicts('binary' | 'label' | 'rle') emits, ampis/data_utils.py:394-433,482-525)."""
 import types
 
 import numpy as np
@@ -72,27 +74,84 @@ def _transform_annotations_loop(annos, scale_x, scale_y, flip, new_w, new_h):
     for a in annos:
         if a.get("iscrowd", 0):
             continue
-        seg = a.get("segmentation")
-        if not isinstance(seg, (list, tuple)) or len(seg) == 0:
-            raise NotImplementedError("ampis_amd training supports polygon ground truth only (INPUT.MASK_FORMAT='polygon')")
-        if len(seg) != 1:
-            raise NotImplementedError("ampis_amd training expects one polygon per instance (as ampis.data_utils.get_ddicts emits)")
+        seg = _polygon_segmentation(a)
         b = np.asarray(a["bbox"], dtype=np.float64).copy()
         if int(a.get("bbox_mode", 0)) == 1:   # XYWH_ABS -> XYXY_ABS
             b[2:] += b[:2]
-        p = np.asarray(seg[0], dtype=np.float64).reshape(-1).copy()
+        ps = [np.asarray(q, dtype=np.float64).reshape(-1).copy() for q in seg]
         b[0::2] *= scale_x; b[1::2] *= scale_y
-        p[0::2] *= scale_x; p[1::2] *= scale_y
+        for p in ps:
+            p[0::2] *= scale_x; p[1::2] *= scale_y
         if flip:
             b[0], b[2] = new_w - b[2], new_w - b[0]
-            p[0::2] = new_w - p[0::2]
+            for p in ps:
+                p[0::2] = new_w - p[0::2]
         b = np.clip(b, 0, [new_w, new_h, new_w, new_h])
         if b[2] - b[0] <= 1e-5 or b[3] - b[1] <= 1e-5:
             continue
         boxes.append(b.astype(np.float32))
         classes.append(int(a["category_id"]))
-        polys.append(p)
+        polys.append(ps[0] if len(ps) == 1 else ps)       # several polygons: their union is the instance (polygons_to_bitmask)
     return dict(boxes=np.asarray(boxes, np.float32).reshape(-1, 4), classes=np.asarray(classes, np.int64), polygons=polys)
+
+
+def _polygon_segmentation(a):
+    """The polygon list of one annotation under INPUT.MASK_FORMAT='polygon'; detectron2's message when it is something else."""
+    seg = a.get("segmentation")
+    if isinstance(seg, dict):
+        raise ValueError("Cannot convert segmentation of type 'dict' (RLE) to PolygonMasks: the dataset was registered with "
+                         "mask_format='bitmask' annotations -- set cfg.INPUT.MASK_FORMAT = 'bitmask'")
+    if not isinstance(seg, (list, tuple)) or len(seg) == 0:
+        raise ValueError(f"Cannot convert segmentation of type '{type(seg).__name__}' to PolygonMasks: expected a list of polygons")
+    return seg
+
+
+def transform_annotations_bitmask(annos, old_h, old_w, new_h, new_w, flip):
+    """INPUT.MASK_FORMAT='bitmask' (detectron2 detection_utils: transform_instance_annotations + annotations_to_instances(mask_format=
+    'bitmask') + filter_empty_instances): every instance ends as ONE full-image mask at network-input resolution --
+      * an RLE segmentation is decoded, resized like the image's geometry with NEAREST interpolation (ResizeTransform.apply_segmentation:
+        PIL) and mirrored with it;
+      * a polygon segmentation has its vertices scaled / mirrored and is rasterised at the new size (polygons_to_bitmask);
+    instances whose box or mask is empty are dropped.  The mask is handed on as COCO run lengths (`masks_rle`), never as a dense
+    N x H x W tensor: the device builds the 28 x 28 targets from the runs (amp_mask_targets_bitmask)."""
+    from PIL import Image
+    from . import rle
+    boxes, classes, masks = [], [], []
+    sx, sy = new_w / old_w, new_h / old_h
+    for a in annos:
+        if a.get("iscrowd", 0):
+            continue
+        b = np.asarray(a["bbox"], dtype=np.float64).copy()
+        if int(a.get("bbox_mode", 0)) == 1:
+            b[2:] += b[:2]
+        b[0::2] *= sx; b[1::2] *= sy
+        if flip:
+            b[0], b[2] = new_w - b[2], new_w - b[0]
+        b = np.clip(b, 0, [new_w, new_h, new_w, new_h])
+        seg = a.get("segmentation")
+        if isinstance(seg, dict):
+            m = rle.decode(seg)
+            assert m.shape == (old_h, old_w), f"segmentation of size {m.shape} on an image of {(old_h, old_w)}"
+            if (new_h, new_w) != (old_h, old_w):
+                m = np.asarray(Image.fromarray(np.ascontiguousarray(m)).resize((new_w, new_h), Image.NEAREST))
+            if flip:
+                m = m[:, ::-1]
+            r = rle.encode(np.asfortranarray(m))
+        elif isinstance(seg, (list, tuple)) and len(seg):
+            ps = []
+            for q in seg:
+                p = np.asarray(q, dtype=np.float64).reshape(-1).copy()
+                p[0::2] *= sx; p[1::2] *= sy
+                if flip:
+                    p[0::2] = new_w - p[0::2]
+                ps.append(p.tolist())
+            r = rle.merge(rle.frPyObjects(ps, new_h, new_w))
+        else:
+            raise ValueError(f"Cannot convert segmentation of type '{type(seg).__name__}' to BitMasks: expected polygons or an RLE dict")
+        if b[2] - b[0] <= 1e-5 or b[3] - b[1] <= 1e-5 or rle.area(r) == 0:
+            continue
+        boxes.append(b.astype(np.float32)); classes.append(int(a["category_id"])); masks.append(r)
+    return dict(boxes=np.asarray(boxes, np.float32).reshape(-1, 4), classes=np.asarray(classes, np.int64), polygons=[None] * len(masks), masks_rle=masks)
 
 
 def parse_annotations(annos):
@@ -103,11 +162,9 @@ def parse_annotations(annos):
     n = len(annos)
     segs = []
     for a in annos:
-        seg = a.get("segmentation")
-        if not isinstance(seg, (list, tuple)) or len(seg) == 0:
-            raise NotImplementedError("ampis_amd training supports polygon ground truth only (INPUT.MASK_FORMAT='polygon')")
+        seg = _polygon_segmentation(a)
         if len(seg) != 1:
-            raise NotImplementedError("ampis_amd training expects one polygon per instance (as ampis.data_utils.get_ddicts emits)")
+            return None            # an instance made of several polygons: the per-instance form handles it
         segs.append(seg[0])
     if n == 0:
         return dict(n=0)
@@ -192,6 +249,10 @@ class DatasetMapper:
             if flip:
                 out = out[:, ::-1]
             annos = dataset_dict.get("annotations", [])
+            if str(c.INPUT.get("MASK_FORMAT", "polygon")) == "bitmask":
+                d["gt"] = transform_annotations_bitmask(annos, h, w, nh, nw, flip)
+                d["image_bgr"] = np.ascontiguousarray(out)
+                return d
             ent = self._parsed.get(id(annos))
             if ent is None or ent[0] is not annos:
                 ent = (annos, parse_annotations(annos))

@@ -15,7 +15,11 @@ _TAP_DTYPES = {0: np.float32, 1: np.int32, 2: np.uint64, 3: np.int8, 4: np.uint8
 
 
 class PackedGt:
-    """The amp_gt struct of a batch: per image dict(boxes [G,4], classes [G], polygons list[G] of flat xy arrays) flattened once.
+    """The amp_gt struct of a batch, flattened once.  Per image: dict(boxes [G,4], classes [G]) plus the instances' masks as
+      * polygons: list[G]; an entry is one flat xy array (one polygon) or a list of flat xy arrays (several polygons: their union,
+        detectron2 polygons_to_bitmask), or `poly_flat` / `poly_len` (the mapper's pre-flattened single polygons); and / or
+      * masks_rle: list[G] of COCO RLE dicts of the instance's full-image mask at network-input resolution (None for an instance that
+        has polygons): detectron2's INPUT.MASK_FORMAT = 'bitmask' (BitMasks.crop_and_resize).
     Keeps the arrays alive; reusable across steps (a data loader packs in its worker, not in the training loop)."""
 
     def __init__(self, gt):
@@ -26,23 +30,67 @@ class PackedGt:
         total = int(off[B])
         boxes = np.ascontiguousarray(np.concatenate([np.asarray(g["boxes"], np.float32).reshape(-1, 4) for g in gt]) if total else np.zeros((0, 4), np.float32))
         classes = np.ascontiguousarray(np.concatenate([np.asarray(g["classes"], np.int32).reshape(-1) for g in gt]) if total else np.zeros(0, np.int32), dtype=np.int32)
-        poff = np.zeros(total + 1, dtype=np.int32)
+        ipoff = None
         if total and all("poly_flat" in g and len(g["poly_len"]) == len(g["boxes"]) for g in gt):
             # the mapper's transform left every image's polygons as one flat array already (data.transform_parsed)
+            poff = np.zeros(total + 1, dtype=np.int32)
             poff[1:] = np.cumsum(np.concatenate([np.asarray(g["poly_len"], np.int64) for g in gt]))
             pxy = np.ascontiguousarray(np.concatenate([np.asarray(g["poly_flat"], np.float64).reshape(-1) for g in gt]))
             assert int(poff[-1]) == len(pxy), "poly_len does not add up to poly_flat"
         else:
-            polys = [np.asarray(p, np.float64).reshape(-1) for g in gt for p in g["polygons"]]
-            assert len(polys) == total, "one polygon per instance"
-            if total:
-                poff[1:] = np.cumsum([len(p) for p in polys])
-            pxy = np.ascontiguousarray(np.concatenate(polys) if total else np.zeros(1, np.float64))
+            per_inst = []          # per instance: list of flat polygons (possibly empty when the instance has a bitmask)
+            for g in gt:
+                ps = g.get("polygons")
+                n = len(g["boxes"])
+                if ps is None:
+                    ps = [[] for _ in range(n)]
+                assert len(ps) == n, "one polygons entry per instance"
+                for p in ps:
+                    if p is None:
+                        per_inst.append([])
+                    elif isinstance(p, (list, tuple)) and (len(p) == 0 or not np.isscalar(p[0])):
+                        per_inst.append([np.asarray(q, np.float64).reshape(-1) for q in p])
+                    else:
+                        per_inst.append([np.asarray(p, np.float64).reshape(-1)])
+            flat = [q for inst in per_inst for q in inst]
+            if all(len(inst) == 1 for inst in per_inst):
+                pass                                                      # polygon index == instance index
+            else:
+                ipoff = np.zeros(total + 1, dtype=np.int32)
+                if total:
+                    ipoff[1:] = np.cumsum([len(inst) for inst in per_inst])
+            poff = np.zeros(max(len(flat), total) + 1, dtype=np.int32)
+            if flat:
+                poff[1:len(flat) + 1] = np.cumsum([len(q) for q in flat])
+                poff[len(flat) + 1:] = poff[len(flat)]
+            pxy = np.ascontiguousarray(np.concatenate(flat) if flat else np.zeros(1, np.float64))
+        # bitmask instances
+        roff = rcnt = rhw = None
+        if any(g.get("masks_rle") is not None for g in gt):
+            runs, roff, rhw = [], np.zeros(total + 1, dtype=np.uint64), np.zeros((max(total, 1), 2), dtype=np.int32)
+            i = 0
+            for g in gt:
+                mr = g.get("masks_rle") or [None] * len(g["boxes"])
+                assert len(mr) == len(g["boxes"]), "one masks_rle entry per instance"
+                for r in mr:
+                    n = 0
+                    if r is not None:
+                        c = _rle._counts(r)
+                        assert int(c.sum()) == int(r["size"][0]) * int(r["size"][1]), "RLE does not cover its size"
+                        runs.append(c); n = len(c)
+                        rhw[i] = (int(r["size"][0]), int(r["size"][1]))
+                    roff[i + 1] = roff[i] + n
+                    i += 1
+            rcnt = np.ascontiguousarray(np.concatenate(runs) if runs else np.zeros(1, np.uint32), dtype=np.uint32)
         self.B, self.total = B, total
-        self._keep = (off, boxes, classes, poff, pxy)
-        self.struct = Gt(B, off.ctypes.data_as(C.POINTER(C.c_int)), boxes.ctypes.data_as(C.POINTER(C.c_float)),
-                         classes.ctypes.data_as(C.POINTER(C.c_int)), poff.ctypes.data_as(C.POINTER(C.c_int)),
-                         pxy.ctypes.data_as(C.POINTER(C.c_double)))
+        self._keep = (off, boxes, classes, poff, pxy, ipoff, roff, rcnt, rhw)
+        P = C.POINTER
+        self.struct = Gt(B, off.ctypes.data_as(P(C.c_int)), boxes.ctypes.data_as(P(C.c_float)),
+                         classes.ctypes.data_as(P(C.c_int)), poff.ctypes.data_as(P(C.c_int)), pxy.ctypes.data_as(P(C.c_double)),
+                         ipoff.ctypes.data_as(P(C.c_int)) if ipoff is not None else None,
+                         roff.ctypes.data_as(P(C.c_ulonglong)) if roff is not None else None,
+                         rcnt.ctypes.data_as(P(C.c_uint32)) if rcnt is not None else None,
+                         rhw.ctypes.data_as(P(C.c_int)) if rhw is not None else None)
 
 
 RLE_COUNTS, RLE_STRINGS, RLE_BOTH = 0, 1, 2

@@ -296,8 +296,21 @@ int amp_roi_sample(amp_ctx* ctx, int B, const float* prop_boxes, const int* prop
                    int* counts, const int* prop_anchor /* [B,Pcap] stable ids for the sampling hash */, int num_anchors);
 int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int ld, float* dpred, const float* rois, const int* roi_cls,
                  const int* roi_gti, const float* gt_boxes, const int* gt_off, const float reg_weights[4], int total_rois, float* partial);
+/* Mask targets + mask BCE loss.  Polygon ground truth: detectron2 PolygonMasks.crop_and_resize = rasterize_polygons_within_box (every
+ * polygon of the instance by pycocotools' rleFrPoly at 28 x 28, merged).  Bitmask ground truth (what `get_ddicts('binary'|'label'|'rle')`
+ * emits, ampis/data_utils.py:394-433,482-525): BitMasks.crop_and_resize = roi_align(mask, scale 1, sampling_ratio 0, aligned) >= 0.5,
+ * evaluated straight from the instance's COCO run lengths (amp_mask_targets_bitmask; scratch = nslots x slot_words words, a slot must
+ * hold width x ceil(height / 32) words of the largest mask).  amp_mask_target_loss = one polygon per instance, no bitmasks. */
 int amp_mask_target_loss(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
                          const int* poly_id, const double* poly_xy, const int* poly_off, float* partial, unsigned char* target_out);
+int amp_mask_targets_bitmask(amp_ctx* ctx, int N, const float* rois, const int* inst, const unsigned long long* rle_off,
+                             const uint32_t* rle_counts, const int* rle_hw, unsigned int* scratch, size_t slot_words, int nslots,
+                             unsigned char* target /* [N,28,28] */, int* overflow_flag);
+int amp_mask_target_loss_fmt(amp_ctx* ctx, int N, int K, const float* logits, float* dlogits, const float* rois, const int* cls,
+                             const int* inst, const double* poly_xy, const int* poly_off /* per polygon */,
+                             const int* inst_poly_off /* [instances+1] or NULL: one polygon per instance */,
+                             const unsigned long long* rle_off /* [instances+1] or NULL */, const unsigned char* target_in,
+                             float* partial, unsigned char* target_out);
 
 /* Host-side COCO RLE codec (all pointers HOST) --------------------------------------------------- */
 int amp_rle_to_string(const uint32_t* cnts, int m, char* out, size_t cap, size_t* len);
@@ -355,15 +368,23 @@ typedef struct amp_model_cfg {
      * STRIDE_IN_1X1}.  R50-FPN = 50/1/64/1 (default, also when resnet_depth == 0); X101-32x8d-FPN = 101/32/8/0. */
     int resnet_depth, num_groups, width_per_group, stride_in_1x1;
 } amp_model_cfg;
-/* Ground truth of one batch (all pointers HOST): instances of image b are [gt_off[b], gt_off[b+1]); one polygon per instance
- * (flat x0,y0,x1,y1,... in input-image pixels), polygon of instance i = poly_xy[poly_off[i] .. poly_off[i+1]). */
+/* Ground truth of one batch (all pointers HOST): instances of image b are [gt_off[b], gt_off[b+1]).  The mask of an instance is
+ * EITHER polygons (flat x0,y0,x1,y1,... in input-image pixels; polygon q = poly_xy[poly_off[q] .. poly_off[q+1]); the polygons of
+ * instance i are [inst_poly_off[i], inst_poly_off[i+1]), or polygon i alone when inst_poly_off is NULL) -- detectron2's
+ * INPUT.MASK_FORMAT = 'polygon' -- OR a bitmask given as COCO run lengths of the instance's full-image mask at network-input
+ * resolution (column-major, first run counts zeros; runs of instance i = rle_counts[rle_off[i] .. rle_off[i+1]), size rle_hw[i]) --
+ * MASK_FORMAT = 'bitmask'.  An instance with runs uses them; rle_off == NULL: polygons only. */
 typedef struct amp_gt {
     int B;
     const int* gt_off;
     const float* boxes;              /* [total,4] XYXY */
     const int* classes;              /* [total] in [0, num_classes) */
-    const int* poly_off;             /* [total+1], in doubles */
+    const int* poly_off;             /* [polygons+1], in doubles */
     const double* poly_xy;
+    const int* inst_poly_off;        /* [total+1] or NULL */
+    const unsigned long long* rle_off; /* [total+1] or NULL */
+    const uint32_t* rle_counts;
+    const int* rle_hw;               /* [total,2] */
 } amp_gt;
 /* Host view of the detections of the last amp_model_infer call; pointers stay valid until the next call. */
 typedef struct amp_dets {

@@ -37,7 +37,7 @@ PROB_NOISE = 2e-5     # fp32 noise of a mask probability (measured 1e-6 .. 7e-6 
 TIE_CAP = 1e-3        # no differing pixel may be further from the threshold than this, whatever the box difference
 
 
-def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_tol=SCORE_TOL):
+def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_tol=SCORE_TOL, box_rel=BOX_REL):
     """hip: dict(boxes, scores, classes, masks=[rle dict]) of the product path; ref: one entry of oracle.maskrcnn.infer (torch).
     decode(rle_dict) -> bool [h, w].  Raises AssertionError listing every violation; returns statistics."""
     rb, rs, rc = ref["boxes"].numpy(), ref["scores"].numpy(), ref["classes"].numpy()
@@ -55,8 +55,9 @@ def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_to
         st["worst_box"] = max(st["worst_box"], float(d[j]))
         if max(bw, bh) <= 333.0:
             st["worst_box_le333"] = max(st["worst_box_le333"], float(d[j]))
-        st["box_rel_used"] += int(box_tol <= d[j] < BOX_REL * max(bw, bh))
-        if not d[j] < max(box_tol, BOX_REL * max(bw, bh)):
+        st["box_rel_used"] += int(box_tol <= d[j] < box_rel * max(bw, bh))
+        st["worst_box_rel"] = max(st["worst_box_rel"], float(d[j]) / max(bw, bh, 1.0))
+        if not d[j] < max(box_tol, box_rel * max(bw, bh)):
             bad.append(f"instance {i} ({bw:.0f}x{bh:.0f} px): nearest HIP box is {d[j]:.3e} px away")
             continue
         if j in used:
@@ -113,7 +114,7 @@ def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_to
 
 
 _SUM = ("instances", "identical", "tie_masks", "tie_pixels", "tie_pixels_beyond_noise", "iou_below", "box_rel_used")
-_MAX = ("worst_margin", "worst_box", "worst_box_le333", "worst_score", "max_tie_pixels", "iou_below_area_max")
+_MAX = ("worst_margin", "worst_box", "worst_box_le333", "worst_box_rel", "worst_score", "max_tie_pixels", "iou_below_area_max")
 
 
 def new_stats():
@@ -139,7 +140,7 @@ def summary(st):
     """One line with everything the gate measured, relaxations included (printed by every end-to-end test and by smoke())."""
     n = max(st["instances"], 1)
     return (f"gate: {st['instances']} instances | boxes worst {st['worst_box']:.2e} px (<= 333 px: {st['worst_box_le333']:.2e}), "
-            f"{st['box_rel_used']} passed only through the {BOX_REL:.0e} x side term | scores worst {st['worst_score']:.1e} | masks "
+            f"{st['box_rel_used']} passed only through the relative term (worst {1e6 * st['worst_box_rel']:.2f} ppm of the side) | scores worst {st['worst_score']:.1e} | masks "
             f"{st['identical']} bit-identical, {st['tie_masks']} with threshold ties ({st['tie_pixels']} px, at most {st['max_tie_pixels']} in one mask, "
             f"{st['tie_pixels_beyond_noise']} beyond the fixed {PROB_NOISE:.0e} noise margin, worst |p-0.5| {st['worst_margin']:.1e}) | IoU < 0.999: "
             f"{st['iou_below']} masks = {100.0 * st['iou_below'] / n:.2f} % (largest such mask {st['iou_below_area_max']} px, lowest IoU {st['iou_min']:.4f})")

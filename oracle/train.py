@@ -149,19 +149,43 @@ def fr_poly(xy, h, w):
 
 
 def rasterize_polygon_within_box(poly, box, size):
-    """detectron2 structures/masks.py rasterize_polygons_within_box for ONE polygon: -> bool [size,size]."""
+    """detectron2 structures/masks.py rasterize_polygons_within_box: the polygons of ONE instance (a flat xy array, or a list of
+    them) are moved into the box frame, scaled to size x size and turned into a bitmask by polygons_to_bitmask = frPyObjects of each
+    polygon, merge (union), decode.  -> bool [size,size]."""
     from . import rle as R
+    polys = poly if isinstance(poly, (list, tuple)) and len(poly) and not np.isscalar(poly[0]) else [poly]
     w, h = float(box[2] - box[0]), float(box[3] - box[1])
-    p = np.asarray(poly, dtype=np.float64).copy()
-    p[0::2] -= float(box[0])
-    p[1::2] -= float(box[1])
     rh, rw = size / max(h, 0.1), size / max(w, 0.1)
-    if rh == rw:
-        p *= rh
-    else:
-        p[0::2] *= rw
-        p[1::2] *= rh
-    return R.decode_counts(fr_poly(p, size, size), size, size)
+    out = np.zeros((size, size), dtype=bool)
+    for q in polys:
+        p = np.asarray(q, dtype=np.float64).copy()
+        p[0::2] -= float(box[0])
+        p[1::2] -= float(box[1])
+        if rh == rw:
+            p *= rh
+        else:
+            p[0::2] *= rw
+            p[1::2] *= rh
+        out |= R.decode_counts(fr_poly(p, size, size), size, size).astype(bool)
+    return out
+
+
+def bitmask_crop_and_resize(mask, box, size):
+    """detectron2 structures/masks.py BitMasks.crop_and_resize for ONE instance: ROIAlign((size, size), 1.0, 0, aligned=True) of the
+    0/1 mask as a one-channel fp32 map, then >= 0.5.  mask: bool [H,W] at network-input resolution.  -> bool [size,size]."""
+    m = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float32))[None]
+    out = M.roi_align(m, torch.as_tensor(np.asarray(box, dtype=np.float32).reshape(1, 4)), size, 1.0)
+    return (out[0, 0].numpy() >= 0.5)
+
+
+def instance_mask_target(g, gi, box, size=28):
+    """Mask target of instance gi of image-gt dict g for proposal `box`: from its bitmask when g['masks_rle'][gi] is given
+    (INPUT.MASK_FORMAT = 'bitmask'), else from its polygon(s)."""
+    from . import rle as R
+    mr = g.get("masks_rle")
+    if mr is not None and mr[gi] is not None:
+        return bitmask_crop_and_resize(R.decode(mr[gi]).astype(bool), box, size)
+    return rasterize_polygon_within_box(g["polygons"][gi], box, size)
 
 
 # ------------------------------------------------------------------------------------------------ differentiable RoIAlign
@@ -360,7 +384,7 @@ def forward_losses(images_u8, gt, params, cfg, stages=None, image_sizes=None):
     for b in range(B):
         keep = (roi_cls[b] != K).numpy()
         for r, gi in zip(rois[b][keep], roi_gtidx[b][keep]):
-            targets.append(torch.from_numpy(rasterize_polygon_within_box(gt[b]["polygons"][int(gi)], r.numpy(), 28)))
+            targets.append(torch.from_numpy(instance_mask_target(gt[b], int(gi), r.numpy(), 28)))
     fgc = torch.cat([c[c != K] for c in roi_cls])
     if len(targets):
         tg = torch.stack(targets).to(torch.float32)

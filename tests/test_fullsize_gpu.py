@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-FULLSIZE_IOU_BELOW_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.10, 16, 0.90      # tightened to the measured level below
+FULLSIZE_IOU_BELOW_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.03, 6, 0.99      # about twice the measured level (see the test)
 
 
 # BASELINE configs[1] (R50-FPN, 1024^2, 200 detections) and configs[4] (X-101-32x8d-FPN, native 2048^2, dense: 500 detections)
@@ -116,12 +116,15 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx, mode):
     for b in (0, 5):
         ref = O.infer(imgs[b:b + 1], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]
         assert len(ref["boxes"]) == D
-        stats.append(gate.check_image(out[b], ref, S, S, lambda mk: _decode(mk["counts"], S, S)))
+        # fp32 MFMA sums two products per instruction, the split arithmetic 16: its re-association noise is the LARGER one (DESIGN §4.1,
+        # tests/test_conv_modes_gpu.py), measured 3.3 ppm of a 393-px side against 1.9 ppm -> its relative term is 4e-6, not 3e-6
+        stats.append(gate.check_image(out[b], ref, S, S, lambda mk: _decode(mk["counts"], S, S), box_rel=4e-6 if mode == "f32" else gate.BOX_REL))
     st = gate.merge(stats)
     print(f"full-size gate [{mode}]:", gate.summary(st))
     assert st["instances"] == 2 * D and st["identical"] + st["tie_masks"] == st["instances"]
-    # caps at the measured level (round 3, both modes: <= 12 of 400 masks below IoU 0.999, all of them satellites of a few hundred px;
-    # <= 4 boxes of ~740 px inside the relative term): a regression shows here even while the per-instance rule holds
+    # caps at about twice the measured level (round 3: f16x3 6 of 400 masks below IoU 0.999 -- the largest 1158 px, lowest IoU 0.9969 --
+    # and 2 boxes of ~740 px inside the relative term; f32 5 of 200 in one image): a regression shows here even while the per-instance
+    # rule holds
     gate.assert_bounds(st, iou_below_share=FULLSIZE_IOU_BELOW_CAP, box_rel_used=FULLSIZE_BOX_REL_CAP, iou_min=FULLSIZE_IOU_MIN)
     if mode == "f32":
         return
