@@ -179,7 +179,7 @@ def test_losses_and_gradients_with_bitmask_ground_truth_match_the_oracle(gpu_ctx
     m.load_params(npp)
     got = m.forward_losses(imgs, bgt, seed=5)
     st = {}
-    cfg = T.TrainCfg(num_classes=K)
+    cfg = T.TrainCfg(num_classes=K, seed=5)
     ref = T.forward_losses(imgs, bgt, M.to_torch_params(npp), cfg, stages=st)
     for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
         assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
