@@ -635,6 +635,64 @@ __global__ __launch_bounds__(256) void mask_target_bitmask_kernel(const BitmaskT
     }
 }
 
+// ---- sigmoid focal loss (fvcore sigmoid_focal_loss as detectron2's dense heads use it), forward + gradient in one pass -----------------
+// Not on the Mask R-CNN path of the reference; built because the north star lists it among the loss kernels.
+//   p = sigmoid(x); ce = max(x, 0) - x t + log1p(exp(-|x|)); p_t = p t + (1 - p)(1 - t); loss = alpha_t ce (1 - p_t)^gamma
+//   alpha_t = alpha t + (1 - alpha)(1 - t) for alpha >= 0, else 1;  t = one_hot(label)[:K] (label K = background, < 0 = ignored row)
+//   d loss / d x = alpha_t [ (p - t)(1 - p_t)^gamma - ce gamma (1 - p_t)^(gamma-1) p (1 - p)(2t - 1) ]
+// Sums: each workgroup adds its 256 lanes in a fixed tree, amp_sigmoid_focal_loss adds the workgroups' partials in index order on the
+// host side of the same call (a second tiny kernel): the loss is bitwise reproducible.
+struct FocalArgs {
+    const float* logits;          // [N][K]
+    const int* labels;            // [N]
+    float* dlogits;               // [N][K] or null
+    float* partial;               // [gridDim.x]
+    long long total;              // N * K
+    int K;
+    float alpha, gamma, scale;    // scale multiplies loss and gradient (1 / normaliser)
+};
+
+__global__ __launch_bounds__(256) void sigmoid_focal_loss_kernel(const FocalArgs a) {
+    __shared__ float s_red[256];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long long)gridDim.x * 256) {
+        const long long n = i / a.K;
+        const int k = (int)(i - n * a.K);
+        const int lab = a.labels[n];
+        float g = 0.f;
+        if (lab >= 0) {
+            const float x = a.logits[i];
+            const float t = (lab == k) ? 1.f : 0.f;
+            const float p = __fdiv_rn(1.f, __fadd_rn(1.f, expf(-x)));
+            const float ce = __fadd_rn(__fsub_rn(fmaxf(x, 0.f), __fmul_rn(x, t)), log1pf(expf(-fabsf(x))));
+            const float pt = __fadd_rn(__fmul_rn(p, t), __fmul_rn(__fsub_rn(1.f, p), __fsub_rn(1.f, t)));
+            const float q = __fsub_rn(1.f, pt);                                   // 1 - p_t
+            const float mod = a.gamma == 0.f ? 1.f : powf(q, a.gamma);
+            const float at = a.alpha >= 0.f ? __fadd_rn(__fmul_rn(a.alpha, t), __fmul_rn(__fsub_rn(1.f, a.alpha), __fsub_rn(1.f, t))) : 1.f;
+            acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(at, ce), mod));
+            if (a.dlogits) {
+                const float dpt = __fmul_rn(__fmul_rn(p, __fsub_rn(1.f, p)), __fsub_rn(__fmul_rn(2.f, t), 1.f));
+                const float dmod = a.gamma == 0.f ? 0.f : __fmul_rn(__fmul_rn(-a.gamma, powf(q, a.gamma - 1.f)), dpt);
+                g = __fmul_rn(__fmul_rn(at, __fadd_rn(__fmul_rn(__fsub_rn(p, t), mod), __fmul_rn(ce, dmod))), a.scale);
+            }
+        }
+        if (a.dlogits) a.dlogits[i] = g;
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] = __fadd_rn(s_red[threadIdx.x], s_red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = s_red[0];
+}
+
+__global__ void focal_finish_kernel(const float* partial, int n, float scale, float* loss) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s = __fadd_rn(s, partial[i]);
+    *loss = __fmul_rn(s, scale);
+}
+
 void fill_geom(AnchorGeom& g, const amp_rpn_levels* lv) {
     g.off[0] = 0;
     for (int l = 0; l < NL; ++l) {
@@ -714,6 +772,18 @@ int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int l
     a.inv_total = 1.0f / (float)(total_rois > 0 ? total_rois : 1);
     a.partial = partial;
     hipLaunchKernelGGL(box_loss_kernel, dim3(B), dim3(512), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_sigmoid_focal_loss(amp_ctx* ctx, long long N, int K, const float* logits, const int* labels, float alpha, float gamma, float scale,
+                           float* dlogits, float* partial, int partial_cap, float* loss) {
+    AMP_REQUIRE(ctx && logits && labels && partial && loss && N >= 0 && K >= 1 && partial_cap >= 1 && gamma >= 0.f, "amp_sigmoid_focal_loss: bad argument");
+    FocalArgs a;
+    a.logits = logits; a.labels = labels; a.dlogits = dlogits; a.partial = partial; a.total = N * K; a.K = K; a.alpha = alpha; a.gamma = gamma; a.scale = scale;
+    const int grid = (int)std::max<long long>(1, std::min<long long>({(long long)partial_cap, 2048ll, (a.total + 255) / 256}));
+    hipLaunchKernelGGL(sigmoid_focal_loss_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(focal_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, partial, grid, scale, loss);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

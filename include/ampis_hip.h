@@ -296,6 +296,12 @@ int amp_roi_sample(amp_ctx* ctx, int B, const float* prop_boxes, const int* prop
                    int* counts, const int* prop_anchor /* [B,Pcap] stable ids for the sampling hash */, int num_anchors);
 int amp_box_loss(amp_ctx* ctx, int B, int batch, int K, const float* pred, int ld, float* dpred, const float* rois, const int* roi_cls,
                  const int* roi_gti, const float* gt_boxes, const int* gt_off, const float reg_weights[4], int total_rois, float* partial);
+/* Sigmoid focal loss (fvcore sigmoid_focal_loss, reduction 'sum', times `scale`) over logits [N,K] with integer labels (label K =
+ * background, negative = the row is ignored), forward and gradient in one pass: *loss_d = scale * sum, dlogits (optional) = scale *
+ * d sum / d logits.  alpha < 0 switches the class weighting off.  partial: device scratch of partial_cap floats (<= 2048 used); sums run in a
+ * fixed order (bitwise reproducible).  Not on the reference's Mask R-CNN path; the north star names it. */
+int amp_sigmoid_focal_loss(amp_ctx* ctx, long long N, int K, const float* logits, const int* labels, float alpha, float gamma, float scale,
+                           float* dlogits, float* partial, int partial_cap, float* loss_d);
 /* Mask targets + mask BCE loss.  Polygon ground truth: detectron2 PolygonMasks.crop_and_resize = rasterize_polygons_within_box (every
  * polygon of the instance by pycocotools' rleFrPoly at 28 x 28, merged).  Bitmask ground truth (what `get_ddicts('binary'|'label'|'rle')`
  * emits, ampis/data_utils.py:394-433,482-525): BitMasks.crop_and_resize = roi_align(mask, scale 1, sampling_ratio 0, aligned) >= 0.5,

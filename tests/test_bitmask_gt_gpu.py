@@ -237,14 +237,17 @@ def test_default_trainer_on_get_ddicts_binary(tmp_path):
     assert all(isinstance(a["segmentation"], dict) and "counts" in a["segmentation"] for d in dd for a in d["annotations"])
     DatasetCatalog.register("sph_Train", lambda: dd)
     MetadataCatalog.get("sph_Train").set(thing_classes=["spheroidite"])
+    from ampis_amd import checkpoint, model_zoo, params as P
     cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
     cfg.INPUT.MASK_FORMAT = "bitmask"
     cfg.INPUT.MIN_SIZE_TRAIN = (160, 192); cfg.INPUT.MAX_SIZE_TRAIN = 256
     cfg.DATASETS.TRAIN = ("sph_Train",); cfg.DATASETS.TEST = ()
     cfg.DATALOADER.NUM_WORKERS = 2
     cfg.SOLVER.IMS_PER_BATCH = 2; cfg.SOLVER.BASE_LR = 0.002; cfg.SOLVER.MAX_ITER = 4; cfg.SOLVER.WARMUP_ITERS = 0; cfg.SOLVER.CHECKPOINT_PERIOD = 100
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
-    cfg.MODEL.WEIGHTS = ""
+    checkpoint.save_checkpoint(tmp_path / "init.pth", P.init_params(1, seed=4, style="spread"))      # a well-conditioned start, as the tutorial starts from a checkpoint
+    cfg.MODEL.WEIGHTS = str(tmp_path / "init.pth")
     cfg.OUTPUT_DIR = str(tmp_path / "out")
     cfg.SEED = 3
     tr = DefaultTrainer(cfg)
