@@ -56,7 +56,8 @@ def check_image(hip, ref, h, w, decode, threshold=0.5, box_tol=BOX_TOL, score_to
         if max(bw, bh) <= 333.0:
             st["worst_box_le333"] = max(st["worst_box_le333"], float(d[j]))
         st["box_rel_used"] += int(box_tol <= d[j] < box_rel * max(bw, bh))
-        st["worst_box_rel"] = max(st["worst_box_rel"], float(d[j]) / max(bw, bh, 1.0))
+        if max(bw, bh) > 333.0:
+            st["worst_box_rel"] = max(st["worst_box_rel"], float(d[j]) / max(bw, bh))
         if not d[j] < max(box_tol, box_rel * max(bw, bh)):
             bad.append(f"instance {i} ({bw:.0f}x{bh:.0f} px): nearest HIP box is {d[j]:.3e} px away")
             continue
@@ -140,7 +141,7 @@ def summary(st):
     """One line with everything the gate measured, relaxations included (printed by every end-to-end test and by smoke())."""
     n = max(st["instances"], 1)
     return (f"gate: {st['instances']} instances | boxes worst {st['worst_box']:.2e} px (<= 333 px: {st['worst_box_le333']:.2e}), "
-            f"{st['box_rel_used']} passed only through the relative term (worst {1e6 * st['worst_box_rel']:.2f} ppm of the side) | scores worst {st['worst_score']:.1e} | masks "
+            f"{st['box_rel_used']} passed only through the relative term (boxes > 333 px: worst {1e6 * st['worst_box_rel']:.2f} ppm of the side) | scores worst {st['worst_score']:.1e} | masks "
             f"{st['identical']} bit-identical, {st['tie_masks']} with threshold ties ({st['tie_pixels']} px, at most {st['max_tie_pixels']} in one mask, "
             f"{st['tie_pixels_beyond_noise']} beyond the fixed {PROB_NOISE:.0e} noise margin, worst |p-0.5| {st['worst_margin']:.1e}) | IoU < 0.999: "
             f"{st['iou_below']} masks = {100.0 * st['iou_below'] / n:.2f} % (largest such mask {st['iou_below_area_max']} px, lowest IoU {st['iou_min']:.4f})")
