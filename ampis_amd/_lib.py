@@ -179,6 +179,10 @@ def _declare(L):
         "amp_small_k_dgrad": ([vp, vp, i, i, vp, i, vp, vp, C.c_size_t], i),
         "amp_deconv_grad_transpose": ([vp, vp, vp, i, i, i, i], i),
         "amp_sgd_update": ([vp, vp, vp, vp, C.c_size_t, f, f, f, f], i),
+        "amp_pipeline_create": ([vp, i, C.POINTER(vp)], i),
+        "amp_pipeline_submit": ([vp, vp, i, i, i, i, vp, vp, C.POINTER(C.c_longlong)], i),
+        "amp_pipeline_wait": ([vp, C.c_longlong, C.POINTER(Dets)], i),
+        "amp_pipeline_destroy": ([vp], i),
         "amp_comm_unique_id": ([vp], i),
         "amp_comm_init": ([vp, i, i, vp], i),
         "amp_comm_destroy": ([vp], i),

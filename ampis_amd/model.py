@@ -96,6 +96,95 @@ class PackedGt:
 RLE_COUNTS, RLE_STRINGS, RLE_BOTH = 0, 1, 2
 
 
+class InferPipeline:
+    """`depth` batches in flight on one GPU from one calling thread (include/ampis_hip.h amp_pipeline): `depth` models with the same
+    weights on contexts of their own, driven by worker threads inside the library.
+
+        pipe = InferPipeline(0, num_classes, depth=2, max_batch=8, max_h=1024, max_w=1024, detections_per_image=200)
+        pipe.load_params(params)
+        tickets = [pipe.submit(batch) for batch in first_two]
+        for batch in rest: out = pipe.wait(tickets.pop(0)); tickets.append(pipe.submit(batch))      # results in submission order
+
+    or simply `for out in pipe.map(batches)`.  Every batch's result is bit-identical to MaskRCNN.infer of that batch."""
+
+    def __init__(self, device, num_classes, depth=2, rle="bytes", **model_kwargs):
+        self.rle = rle
+        self.ctxs = [_lib.Context(device) for _ in range(depth)]
+        self.models = [MaskRCNN(c, num_classes, **model_kwargs) for c in self.ctxs]
+        self._h = C.c_void_p()
+        self._keep = {}                 # ticket -> host arrays that must outlive the batch
+        self._open = False
+
+    def load_params(self, params):
+        for m in self.models:
+            m.load_params(params)
+            m.set_rle_output(RLE_COUNTS if self.rle == "counts" else RLE_STRINGS)
+        handles = (C.c_void_p * len(self.models))(*[m._h for m in self.models])
+        check(lib().amp_pipeline_create(handles, len(self.models), C.byref(self._h)), "amp_pipeline_create")
+        self._open = True
+
+    @property
+    def depth(self):
+        return len(self.models)
+
+    def submit(self, images=None, out_sizes=None, device_ptr=None, shape=None):
+        """Hand the next batch over and return its ticket at once.  images: uint8 [B,H,W,3] on the host (kept alive here until wait),
+        or device_ptr + shape=(B,H,W) of a frame already in HBM (complete before this call; not overwritten before wait)."""
+        if device_ptr is not None:
+            B, H, W = shape
+            p, on_host, keep = C.c_void_p(int(device_ptr)), 0, None
+        else:
+            keep = np.ascontiguousarray(images, dtype=np.uint8)
+            assert keep.ndim == 4 and keep.shape[3] == 3, "images must be [B,H,W,3] uint8 BGR"
+            B, H, W, _ = keep.shape
+            p, on_host = keep.ctypes.data_as(C.c_void_p), 1
+        oh = ow = None
+        if out_sizes is not None:
+            oh = (C.c_int * B)(*[int(s[0]) for s in out_sizes])
+            ow = (C.c_int * B)(*[int(s[1]) for s in out_sizes])
+        t = C.c_longlong()
+        check(lib().amp_pipeline_submit(self._h, p, on_host, B, H, W, oh, ow, C.byref(t)), "amp_pipeline_submit")
+        self._keep[t.value] = keep
+        return t.value
+
+    def wait_raw(self, ticket):
+        d = Dets()
+        try:
+            check(lib().amp_pipeline_wait(self._h, int(ticket), C.byref(d)), "amp_pipeline_wait")
+        finally:
+            self._keep.pop(int(ticket), None)
+        return d
+
+    def wait(self, ticket):
+        return MaskRCNN.unpack(self.wait_raw(ticket), self.rle)
+
+    def map(self, batches):
+        """Results of an iterable of host batches, in order, with `depth` of them in flight."""
+        pending = []
+        for b in batches:
+            if len(pending) == self.depth:
+                yield self.wait(pending.pop(0))
+            pending.append(self.submit(b))
+        while pending:
+            yield self.wait(pending.pop(0))
+
+    def close(self):
+        if self._open:
+            check(lib().amp_pipeline_destroy(self._h), "amp_pipeline_destroy")
+            self._open = False
+        for m in self.models:
+            m.close()
+        for c in self.ctxs:
+            c.close()
+        self.models, self.ctxs = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MaskRCNN:
     def __init__(self, ctx, num_classes, max_batch=1, max_h=1344, max_w=1344, max_out_hw=4096,
                  detections_per_image=100, pre_nms_topk=1000, post_nms_topk=1000, rpn_nms_thresh=0.7,
@@ -177,7 +266,11 @@ class MaskRCNN:
         masks = list of COCO RLE dicts {'size':[h,w], 'counts': bytes}) -- the content compress_pred produces
         (ampis/data_utils.py:275-278). rle='counts' keeps the uncompressed uint32 run lengths instead."""
         self.set_rle_output(RLE_COUNTS if rle == "counts" else RLE_STRINGS)
-        d = self.infer_raw(images, out_sizes, device_ptr, shape)
+        return self.unpack(self.infer_raw(images, out_sizes, device_ptr, shape), rle)
+
+    @staticmethod
+    def unpack(d, rle="bytes"):
+        """amp_dets (ctypes view into the model's result buffers) -> the per-image dicts of infer(); copies everything it returns."""
         B, D = d.B, d.D
         n = np.ctypeslib.as_array(d.n, (B,)).copy()
         boxes = np.ctypeslib.as_array(d.boxes, (B, D, 4))

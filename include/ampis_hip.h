@@ -451,6 +451,21 @@ int  amp_model_set_image_sizes(amp_model* m, const int* hw_h, int B);
 /* Device buffer of an intermediate stage of the last infer call (parity tests): dtype 0 f32, 1 i32, 2 u64. */
 int  amp_model_get_tap(amp_model* m, const char* name, void** ptr, int* dtype, int* ndim, long long shape[5]);
 
+/* Several batches in flight on one GPU (serving throughput) -------------------------------------------------------------
+ * An amp_pipeline runs `depth` lanes -- models the caller created on contexts of their own (own stream, workspace and result buffers),
+ * normally loaded with the same weights -- from one worker thread each, so that ONE calling thread keeps `depth` batches in flight:
+ * the next batch's convolutions fill the chip while the previous batch sits in its latency-bound selection / NMS / paste kernels and
+ * host read-backs (+9 % images/s at depth 2 on BASELINE configs[1]; splitting one call into micro-batches does not).
+ * submit() returns at once with a ticket (lanes round-robin; at most `depth` uncollected tickets), wait(ticket) blocks until that
+ * batch is done and hands out its amp_dets, valid until the lane's next submit.  Host images must stay alive until wait() returns.
+ * Every batch runs the same kernels in the same order as amp_model_infer: results are bit-identical to the plain call. */
+typedef struct amp_pipeline amp_pipeline;
+int amp_pipeline_create(amp_model* const* models, int depth, amp_pipeline** out);
+int amp_pipeline_submit(amp_pipeline* p, const uint8_t* imgs_bgr, int imgs_on_host, int B, int H, int W, const int* out_h_h,
+                        const int* out_w_h, long long* ticket);
+int amp_pipeline_wait(amp_pipeline* p, long long ticket, amp_dets* out);
+int amp_pipeline_destroy(amp_pipeline* p);       /* waits for batches in flight; the models stay the caller's */
+
 /* Multi-GPU exchange: RCCL over xGMI, one process and one communicator per GPU ---------------------------------------
  * Replaces what the reference gets from detectron2's launch()/DDP + NCCL: the gradient all-reduce under
  * `DefaultTrainer(cfg).train()` (ampis/data_utils.py:135, notebook cell 22) and `comm.synchronize()`

@@ -58,3 +58,32 @@ def run_joined(parts, steps, stagger_us=0):
 for parts, stag in ((1, 0), (2, 0), (2, 1500), (2, 3000), (4, 0), (4, 1000), (1, 0)):
     ms, nd = run_joined(parts, STEPS, stag)
     print(f"parts {parts} stagger {stag:5d} us: {ms:7.3f} ms per batch of {BATCH} = {BATCH / ms * 1e3:6.1f} images/s   ({nd} detections)", flush=True)
+
+
+def run_pipeline(depth, steps):
+    """amp_pipeline: `depth` full batches in flight from this one thread (consecutive batches overlap, nothing is joined per step)."""
+    from ampis_amd.model import InferPipeline
+    pipe = InferPipeline(0, K, depth=depth, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
+    pipe.load_params(params)
+    c = _lib.Context(0)
+    d = c.malloc(imgs.nbytes); c.h2d(d, imgs); c.sync()
+    def loop(n):
+        pend, nd = [], 0
+        for _ in range(n):
+            if len(pend) == depth:
+                r = pipe.wait_raw(pend.pop(0)); nd += sum(r.n[b] for b in range(BATCH))
+            pend.append(pipe.submit(device_ptr=d, shape=(BATCH, SIZE, SIZE)))
+        while pend:
+            r = pipe.wait_raw(pend.pop(0)); nd += sum(r.n[b] for b in range(BATCH))
+        return nd
+    loop(4)
+    t0 = time.perf_counter()
+    nd = loop(steps)
+    el = time.perf_counter() - t0
+    pipe.close(); c.free(d); c.close()
+    return el / steps * 1e3, nd
+
+
+for depth in (1, 2, 3, 2, 1):
+    ms, nd = run_pipeline(depth, STEPS)
+    print(f"amp_pipeline depth {depth}: {ms:7.3f} ms per batch of {BATCH} = {BATCH / ms * 1e3:6.1f} images/s   ({nd} detections over {STEPS} batches)", flush=True)
