@@ -230,6 +230,8 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
         except Exception as e:   # noqa: BLE001
             log(f"rank {rank}: RCCL communicator of size 1 not available ({e}); training step timed without the exchange machinery")
     has_comm = ctx.comm_info()[1] > 0
+    if has_comm:
+        model.broadcast_params(0)             # rank 0's parameters and momentum to every rank (DDP's constructor broadcast; a no-op exchange at 1 rank)
 
     def step(i):
         losses = model.forward_losses(None, packed, seed=i, backward=True, device_ptr=d_imgs, shape=(TRAIN_BATCH, SIZE, SIZE))
@@ -242,6 +244,7 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
     ranks.barrier()
     ctx.prof_begin(max_launches=(steps // PROF_EVERY + 1) * 512)
     exposed, span, nstat = 0.0, 0.0, 0
+    bucket_us = None
     t0 = time.perf_counter()
     prof_steps = 0
     for i in range(steps):
@@ -252,6 +255,8 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
         if has_comm and sampled:      # event times of this step's exchange (waits for the step: only on the sampled steps)
             st = ctx.comm_stats()
             exposed += st["exposed_ms"]; span += st["span_ms"]; nstat += 1
+            bu = ctx.comm_bucket_stats()
+            bucket_us = bu if bucket_us is None else [a + b for a, b in zip(bucket_us, bu)]
     ctx.sync()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
@@ -290,60 +295,61 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
                              "buckets": len({b for b, _, _ in buckets}), "ranges": len(buckets),
                              "MB_per_step": round(sum(n for _, _, n in buckets) * 4 / 1e6, 1),
                              "exposed_comm_ms": round(exposed / nstat, 3) if nstat else None,
-                             "comm_span_ms": round(span / nstat, 3) if nstat else None},
+                             "comm_span_ms": round(span / nstat, 3) if nstat else None,
+                             # mean microseconds of each bucket's grouped all-reduce on the communication stream, in issue order
+                             # (mask head, box head, RPN, FPN, res5, res4, res3): with N > 1 ranks this is the per-bucket xGMI time
+                             "bucket_us": [round(v / nstat, 1) for v in bucket_us] if (nstat and bucket_us) else None},
            "last_losses": {k: round(v, 4) for k, v in losses.items()}}
     return out
 
 
 def two_pipelines_leg(local_rank, dev, rank, world, steps, ranks, params, imgs):
-    """The headline workload with TWO batches in flight per GPU: two contexts (own HIP stream, own model workspace), one host thread
-    each.  A single pipeline leaves the chip idle while the host waits for the detection counts and the results, in the ramp and tail
-    of every launch and in the under-filled grids of the small layers; a second pipeline fills those.  Same kernels, same batch of 8
-    per step -- only the scheduling differs, which is how a serving process would run it."""
-    ctxs, models, bufs = [], [], []
-    for i in range(2):
-        c = _lib.Context(local_rank)
-        m = MaskRCNN(c, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
-        m.load_params(params)
-        m.set_rle_output(RLE_STRINGS)
-        d = c.malloc(imgs.nbytes)
-        c.h2d(d, imgs)
-        ctxs.append(c); models.append(m); bufs.append(d)
-    counts = [0, 0]
-    errors = []
+    """The headline workload with TWO batches in flight per GPU through the library's own pipeline object (include/ampis_hip.h
+    amp_pipeline: one handle, ONE calling thread, a worker thread and a context per lane inside the library).  A single synchronous
+    call leaves the chip idle while the host reads the detection counts and the results, in the latency-bound selection / NMS / paste
+    kernels and in the ramp and tail of every launch; the next batch's convolutions fill those.  Same kernels, same batch of 8 per
+    step, bit-identical results (tests/test_pipeline_gpu.py) -- only consecutive batches overlap, which is how a serving process runs.
+    (Splitting ONE call into micro-batches on several streams does not help: tools/exp_halfbatch.py)"""
+    from ampis_amd.model import InferPipeline
+    depth = 2
+    pipe = InferPipeline(local_rank, K, depth=depth, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
+    pipe.load_params(params)
+    c = _lib.Context(local_rank)
+    d = c.malloc(imgs.nbytes)
+    c.h2d(d, imgs)
+    c.sync()
 
-    def worker(i, n):
-        try:
-            for _ in range(n):
-                r = models[i].infer_raw(None, device_ptr=bufs[i], shape=(BATCH, SIZE, SIZE))
-                counts[i] += sum(r.n[b] for b in range(BATCH))
-        except Exception as e:   # noqa: BLE001
-            errors.append(f"{type(e).__name__}: {e}"[:200])
+    def run(n):
+        pend, nd = [], 0
+        for _ in range(n):
+            if len(pend) == depth:
+                r = pipe.wait_raw(pend.pop(0))
+                nd += sum(r.n[b] for b in range(BATCH))
+            pend.append(pipe.submit(device_ptr=d, shape=(BATCH, SIZE, SIZE)))
+        while pend:
+            r = pipe.wait_raw(pend.pop(0))
+            nd += sum(r.n[b] for b in range(BATCH))
+        return nd
 
-    def run(n_each):
-        th = [threading.Thread(target=worker, args=(i, n_each)) for i in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+    try:
+        run(4)
+        n = max(2, steps)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        nd = run(n)
         torch.cuda.synchronize(dev)
-
-    run(2)
-    counts[0] = counts[1] = 0
-    n_each = max(1, steps // 2)
-    ranks.barrier()
-    t0 = time.perf_counter()
-    run(n_each)
-    el = time.perf_counter() - t0
-    ranks.barrier()
-    el = ranks.max(el)
-    for m in models:
-        m.close()
-    if errors:
-        return {"error": errors[0]}
-    return {"what": "same workload, two batches of 8 in flight per GPU (two contexts / streams / host threads)",
-            "value": round(world * BATCH * 2 * n_each / el, 3), "unit": "images/s", "steps": 2 * n_each,
-            "ms_per_step": round(el / (2 * n_each) * 1e3, 3), "detections_per_image_mean": round(sum(counts) / (2 * n_each * BATCH), 2)}
+        el = time.perf_counter() - t0
+        ranks.barrier()
+        el = ranks.max(el)
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        pipe.close()
+        c.free(d)
+        c.close()
+    return {"what": "same workload, two batches of 8 in flight per GPU: amp_pipeline depth 2 (one handle, one calling thread; every batch's results on the host inside the timed region)",
+            "value": round(world * BATCH * n / el, 3), "unit": "images/s", "steps": n, "pipeline_depth": depth,
+            "ms_per_step": round(el / n * 1e3, 3), "detections_per_image_mean": round(nd / (n * BATCH), 2)}
 
 
 def host_inclusive_leg(model, imgs, dev, world, steps, ranks):
