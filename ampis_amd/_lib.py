@@ -162,6 +162,9 @@ def _declare(L):
         "amp_roi_sample": ([vp, i, vp, vp, i, vp, vp, vp, i, i, f, f, C.c_uint, vp, vp, vp, i, vp, vp, vp, vp, vp, i], i),
         "amp_box_loss": ([vp, i, i, i, vp, i, vp, vp, vp, vp, vp, vp, C.POINTER(f), i, vp], i),
         "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_grouped_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
+        "amp_conv2d_grouped_wgrad": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp], i),
+        "amp_group_dgrad_weights": ([vp, vp, vp, i, i, i, vp], i),
         "amp_sigmoid_focal_loss": ([vp, C.c_longlong, i, vp, vp, f, f, f, vp, vp, i, vp], i),
         "amp_mask_targets_bitmask": ([vp, i, vp, vp, vp, vp, vp, vp, C.c_size_t, i, vp, vp], i),
         "amp_mask_target_loss_fmt": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),

@@ -1,0 +1,146 @@
+// Backward of the grouped 3x3 convolution of a ResNeXt bottleneck (detectron2 `conv2` with RESNETS.NUM_GROUPS > 1; BASELINE configs[4]):
+// weights live in the window layout of the forward kernel, [Cout][KH][KW][64] -- output channel o sees the 64 input channels of its own
+// 64-wide tile, with zeros outside its group -- and so do their gradients (the arenas share offsets).
+//   * data gradient: the SAME grouped forward kernel on transposed / flipped / FrozenBN-scaled windows (amp_group_dgrad_weights); a
+//     stride-2 layer first spreads dy over the even positions of a zeroed map (amp_subsample2_bwd), then convolves with stride 1;
+//   * weight gradient (this file): per 64-channel tile and tap a 64 x 64 product dY^T X over the pixels on the fp32 MFMA, operands
+//     straight from global memory (a lane's A / B value is one float of a 128-byte channel run: coalesced), split over row slices whose
+//     partial sums are added in slice order (bitwise reproducible); entries outside a channel's group are zeroed by the reduce pass, which
+//     also applies the FrozenBN scale of the output channel.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GWArgs {
+    const float* x;       // [B][H][W][C]
+    const float* dy;      // [B][Ho][Wo][C]
+    float* partial;       // [nslices][C/64][KH*KW][64 co][64 ci]
+    int B, H, W, C, Ho, Wo, KH, KW, stride, pad;
+    int rows_per_slice;   // output rows (b, oy) per slice
+    int nslices;
+};
+
+// grid: (C/64) * KH*KW * nslices workgroups of 256 threads; wave w computes the 32 x 32 quadrant (co half w & 1, ci half w >> 1)
+__global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntaps = a.KH * a.KW, ntiles = a.C >> 6;
+    int id = blockIdx.x;
+    const int slice = id % a.nslices; id /= a.nslices;
+    const int tap = id % ntaps;
+    const int tile = id / ntaps;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int i = lane & 31, k = lane >> 5;                        // MFMA 32x32x2: a lane holds A[i][k] and B[k][i]
+    const int co = (tile << 6) + ((wave & 1) << 5) + i;
+    const int ci = (tile << 6) + ((wave >> 1) << 5) + i;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row0 = slice * a.rows_per_slice, row1 = min(row0 + a.rows_per_slice, a.B * a.Ho);
+    for (int row = row0; row < row1; ++row) {
+        const int b = row / a.Ho, oy = row - b * a.Ho;
+        const int iy = oy * a.stride + ky - a.pad;
+        if (iy < 0 || iy >= a.H) continue;                         // the whole row of taps is padding (wave-uniform)
+        const float* dyr = a.dy + ((size_t)row * a.Wo) * a.C + co;
+        const float* xr = a.x + (((size_t)b * a.H + iy) * a.W) * a.C + ci;
+        for (int ox0 = 0; ox0 < a.Wo; ox0 += 8) {                  // four MFMAs (8 pixels) per trip, loads first
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ox = ox0 + 2 * u + k;
+                const int ix = ox * a.stride + kx - a.pad;
+                const bool ok = ox < a.Wo;
+                av[u] = ok ? dyr[(size_t)ox * a.C] : 0.f;
+                bv[u] = (ok && ix >= 0 && ix < a.W) ? xr[(size_t)ix * a.C] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+    // acc[r]: row (co) = (r / 4) * 8 + (lane / 32) * 4 + r % 4, column (ci) = lane % 32
+    float* out = a.partial + ((((size_t)slice * ntiles + tile) * ntaps + tap) << 12);
+    const int cob = (wave & 1) << 5, cib = (wave >> 1) << 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rco = cob + (r >> 2) * 8 + k * 4 + (r & 3);
+        out[(rco << 6) + cib + i] = acc[r];
+    }
+}
+
+// grad[co][ky][kx][slot] = scale[co] * sum over slices (in slice order) of the partials, zero outside the group of co
+__global__ void grouped_wgrad_reduce_kernel(const float* partial, const float* scale, float* grad, int C, int ntaps, int nslices, int cpg) {
+    const size_t total = (size_t)C * ntaps * 64;
+    const int ntiles = C >> 6;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(idx & 63);
+        const int tap = (int)((idx >> 6) % ntaps);
+        const int co = (int)(idx / ((size_t)ntaps * 64));
+        const int tile = co >> 6, cl = co & 63;
+        float s = 0.f;
+        if (cl / cpg == slot / cpg) {
+            for (int sl = 0; sl < nslices; ++sl) s = __fadd_rn(s, partial[((((size_t)sl * ntiles + tile) * ntaps + tap) << 12) + (cl << 6) + slot]);
+            if (scale) s = __fmul_rn(s, scale[co]);
+        }
+        grad[idx] = s;
+    }
+}
+
+// wt[ci][ky][kx][b] = w[tile*64 + b][KH-1-ky][KW-1-kx][ci & 63] * scale[tile*64 + b]   (ci and tile*64 + b share the 64-wide tile)
+__global__ void group_dgrad_weights_kernel(const float* w, const float* scale, float* wt, int C, int KH, int KW) {
+    const size_t total = (size_t)C * KH * KW * 64;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx & 63);
+        size_t t = idx >> 6;
+        const int kx = (int)(t % KW); t /= KW;
+        const int ky = (int)(t % KH);
+        const int ci = (int)(t / KH);
+        const int co = (ci & ~63) + b;
+        float v = w[(((size_t)co * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * 64 + (ci & 63)];
+        if (scale) v = __fmul_rn(v, scale[co]);
+        wt[idx] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d) {
+    if (!d || d->Cin <= 0) return 0;
+    return (size_t)16 * d->Cin * d->KH * d->KW * 64;          // at most 16 slices
+}
+
+int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
+                             float* scratch, float* grad_win) {
+    AMP_REQUIRE(ctx && d && x && dy && scratch && grad_win && groups > 1, "amp_conv2d_grouped_wgrad: bad argument");
+    AMP_REQUIRE(d->Cin == d->Cout && d->Cin % 64 == 0 && d->Cin % groups == 0, "amp_conv2d_grouped_wgrad: needs Cin == Cout, a multiple of 64 and of groups");
+    const int cpg = d->Cin / groups;
+    AMP_REQUIRE(cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64, "amp_conv2d_grouped_wgrad: %d channels per group (8/16/32/64 supported)", cpg);
+    GWArgs a;
+    a.x = x; a.dy = dy; a.partial = scratch;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->Cin; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    AMP_REQUIRE(a.Ho > 0 && a.Wo > 0, "amp_conv2d_grouped_wgrad: empty output");
+    const int rows = a.B * a.Ho, pairs = (a.C >> 6) * a.KH * a.KW;
+    int nslices = std::max(1, std::min({16, rows, (1024 + pairs - 1) / pairs}));      // ~1024 workgroups: four per CU
+    a.rows_per_slice = (rows + nslices - 1) / nslices;
+    nslices = (rows + a.rows_per_slice - 1) / a.rows_per_slice;
+    a.nslices = nslices;
+    hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(256), 0, ctx->stream, a);
+    const size_t total = (size_t)a.C * a.KH * a.KW * 64;
+    hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
+                       scratch, scale, grad_win, a.C, a.KH * a.KW, nslices, cpg);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_group_dgrad_weights(amp_ctx* ctx, const float* w_win, const float* scale, int C, int KH, int KW, float* wt_win) {
+    AMP_REQUIRE(ctx && w_win && wt_win && C > 0 && C % 64 == 0 && KH > 0 && KW > 0, "amp_group_dgrad_weights: bad argument");
+    const size_t total = (size_t)C * KH * KW * 64;
+    hipLaunchKernelGGL(group_dgrad_weights_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream, w_win, scale, wt_win, C, KH, KW);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+}  // extern "C"

@@ -307,6 +307,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             const bool trunk = k.rfind("backbone.", 0) == 0 || k.rfind("proposal_generator.", 0) == 0;
             if (trunk && k != "backbone.bottom_up.stem.conv1" && (kv.second.groups != 1 ? m->saving : !reads_split(k))) native_all = false;
         }
+    if (m->saving && !c.stride_in_1x1) native_all = false;   // the split-gradient chain of the backward pass assumes the stride in conv1
     if (m->saving && !native_all) native = false;     // (reads_split follows: everything fp32)
     m->acts_split = m->saving && native_all;
     const int SPL = 5;                 // tap dtype of a split tensor
@@ -1243,8 +1244,37 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const ConvW& c3 = CONV((ba.key + ".conv3").c_str());
         const ConvW& c2 = CONV((ba.key + ".conv2").c_str());
         const ConvW& c1 = CONV((ba.key + ".conv1").c_str());
+        // RESNETS.STRIDE_IN_1X1: the block's stride sits in conv1 (MSRA R50 / R101) or in the 3x3 conv2 (ResNeXt); t1 is conv1's output
+        const int st1 = c.stride_in_1x1 ? ba.stride : 1, st2 = c.stride_in_1x1 ? 1 : ba.stride;
+        const int h1 = (ba.in_h - 1) / st1 + 1, w1 = (ba.in_w - 1) / st1 + 1;
         AMP_ALLOC(d_t2, float, (size_t)B * ba.oh * ba.ow * ba.mid);
-        AMP_ALLOC(d_t1, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+        AMP_ALLOC(d_t1, float, (size_t)B * h1 * w1 * ba.mid);
+        float* d_t2_up = nullptr;            // stride-2 conv2: dy spread over the even positions of a zeroed map, then a stride-1 data gradient
+        if (st2 == 2) { AMP_ALLOC(up, float, (size_t)B * h1 * w1 * ba.mid); d_t2_up = up; }
+        // conv2's two gradients: dense, or grouped (ResNeXt: window layout, grouped_bwd.hip)
+        auto c2_backward = [&]() -> int {
+            const float* dy2 = d_t2;
+            if (st2 == 2) {
+                AMP_HIP_CHECK(hipMemsetAsync(d_t2_up, 0, (size_t)B * h1 * w1 * ba.mid * 4, ctx->stream));
+                AMP_TRY(amp_subsample2_bwd(ctx, d_t2, d_t2_up, B, h1, w1, ba.mid));
+                dy2 = d_t2_up;
+            } else {
+                AMP_REQUIRE(st2 == 1, "backward: conv2 with stride %d", st2);
+            }
+            if (c2.groups > 1) {
+                amp_conv_desc dw;
+                dw.B = B; dw.H = h1; dw.W = w1; dw.Cin = ba.mid; dw.Cout = ba.mid; dw.KH = 3; dw.KW = 3; dw.stride = st2; dw.pad = 1; dw.relu = 0; dw.res_mode = 0; dw.out_mode = 0;
+                AMP_REQUIRE(amp_grouped_wgrad_scratch_floats(&dw) <= WG_SCRATCH && (size_t)ba.mid * 9 * 64 <= WT_SCRATCH, "backward: grouped scratch too small");
+                AMP_TRY(amp_conv2d_grouped_wgrad(ctx, &dw, c2.groups, ba.t1, d_t2, c2.scale, wg_scratch, GW(c2)));
+                AMP_TRY(amp_group_dgrad_weights(ctx, c2.w, c2.scale, ba.mid, 3, 3, wt_scratch));
+                amp_conv_desc dd = dw;
+                dd.stride = 1;
+                dys_of = nullptr;
+                return amp::conv_run(ctx, &dd, c2.groups, dy2, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, ba.t1, d_t1, 16, 0);
+            }
+            AMP_TRY(wgrad(c2, ba.t1, B, h1, w1, st2, 1, d_t2, false, false, AS));
+            return dgrad(c2, dy2, B, h1, w1, 1, nullptr, ba.t1, d_t1, AS);
+        };
         const bool need_dx = !(ba.stage == 1 && ba.has_sc);   // the input of res3.0 is the frozen res2 output
         if (GS) {
             // every gradient of the chain below is a scaled split tensor (see dgrad_s)
@@ -1287,20 +1317,26 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         dcur_masked = false;
         AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false, false, AS));
         AMP_TRY(dgrad(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2, AS));
-        AMP_TRY(wgrad(c2, ba.t1, B, ba.oh, ba.ow, 1, 1, d_t2, false, false, AS));
-        AMP_TRY(dgrad(c2, d_t2, B, ba.oh, ba.ow, 1, nullptr, ba.t1, d_t1, AS));
-        AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, d_t1, false, false, AS));
+        AMP_TRY(c2_backward());
+        AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, st1, 0, d_t1, false, false, AS));
         if (ba.has_sc) {
             const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
             AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false, false, AS));
             if (need_dx) {
-                AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
-                AMP_ALLOC(tmp_in, float, (size_t)B * ba.oh * ba.ow * ba.cin);
-                AMP_TRY(dgrad(cs, dcur, B, ba.oh, ba.ow, 0, nullptr, nullptr, tmp_sc));
-                AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, tmp_sc, nullptr, tmp_in));
                 float* dprev = d_res[ba.stage - 1];             // already holds the FPN lateral's share
-                if (ba.stride == 2) AMP_TRY(amp_subsample2_bwd(ctx, tmp_in, dprev, B, ba.in_h, ba.in_w, ba.cin));
-                else { amp::set_error("backward: stride-1 projection block is not expected here"); return AMP_ERR_STATE; }
+                AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                AMP_TRY(dgrad(cs, dcur, B, ba.oh, ba.ow, 0, nullptr, nullptr, tmp_sc));
+                if (ba.stride != 2) { amp::set_error("backward: stride-1 projection block is not expected here"); return AMP_ERR_STATE; }
+                if (st1 == 2) {     // both branches at the block's output resolution: add, then spread over the input map
+                    AMP_ALLOC(tmp_in, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                    AMP_TRY(dgrad(c1, d_t1, B, ba.oh, ba.ow, 0, tmp_sc, nullptr, tmp_in));
+                    AMP_TRY(amp_subsample2_bwd(ctx, tmp_in, dprev, B, ba.in_h, ba.in_w, ba.cin));
+                } else {            // conv1 ran at the input resolution: its data gradient joins dprev there; the strided shortcut's is spread
+                    AMP_ALLOC(tmp_full, float, (size_t)B * ba.in_h * ba.in_w * ba.cin);
+                    AMP_TRY(dgrad(c1, d_t1, B, h1, w1, 0, dprev, nullptr, tmp_full));
+                    AMP_HIP_CHECK(hipMemcpyAsync(dprev, tmp_full, (size_t)B * ba.in_h * ba.in_w * ba.cin * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    AMP_TRY(amp_subsample2_bwd(ctx, tmp_sc, dprev, B, ba.in_h, ba.in_w, ba.cin));
+                }
             }
         } else {
             AMP_ALLOC(d_in, float, out_elems);
@@ -1363,10 +1399,8 @@ int amp_model_create(amp_ctx* ctx, const amp_model_cfg* cfg, amp_model** out) {
         const bool ok_depth = c.resnet_depth == 50 || c.resnet_depth == 101;
         const int width = c.num_groups * c.width_per_group;
         if (!ok_depth || c.num_groups < 1 || width < 64 || width % 64 != 0 ||
-            (c.num_groups > 1 && !(c.width_per_group == 8 || c.width_per_group == 16 || c.width_per_group == 32 || c.width_per_group == 64)) ||
-            (c.num_groups > 1 && c.train_enable)) {
-            amp::set_error("amp_model_create: unsupported backbone (depth %d, groups %d x width %d%s)", c.resnet_depth, c.num_groups,
-                           c.width_per_group, (c.num_groups > 1 && c.train_enable) ? ", training a grouped backbone is not built" : "");
+            (c.num_groups > 1 && !(c.width_per_group == 8 || c.width_per_group == 16 || c.width_per_group == 32 || c.width_per_group == 64))) {
+            amp::set_error("amp_model_create: unsupported backbone (depth %d, groups %d x width %d)", c.resnet_depth, c.num_groups, c.width_per_group);
             delete m;
             return AMP_ERR_ARG;
         }

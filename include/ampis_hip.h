@@ -122,6 +122,15 @@ int amp_conv2d_grouped_nhwc(amp_ctx* ctx, const amp_conv_desc* d, int groups, co
  * is 256 B of a split row as it is of an fp32 row, so a ResNeXt trunk stays in the format through its grouped layers */
 int amp_conv2d_grouped_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w_win,
                                 const float* scale, const float* shift, const float* res, float* y, int fmt);
+/* Backward of the grouped convolution (training a ResNeXt backbone).  Weight gradient in the window layout (zero outside a channel's
+ * group), times scale[co] when given (FrozenBN); fp32 MFMA, partial sums over row slices added in slice order.  scratch:
+ * amp_grouped_wgrad_scratch_floats(d) floats.  Data gradient: the grouped forward convolution of dy with amp_group_dgrad_weights'
+ * windows (transposed inside each 64-channel tile, taps flipped, times scale[co]); stride 1 (a stride-2 layer spreads dy over the even
+ * positions of a zeroed map first). */
+size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d);
+int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
+                             float* scratch, float* grad_win);
+int amp_group_dgrad_weights(amp_ctx* ctx, const float* w_win, const float* scale, int C, int KH, int KW, float* wt_win);
 /* same, with an optional mask tensor indexed like y: y = mask > 0 ? y : 0 (applied last; the ReLU backward of a data gradient) */
 int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                        const float* res, const float* mask, float* y);
