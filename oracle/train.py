@@ -286,7 +286,7 @@ def forward_losses(images_u8, gt, params, cfg, stages=None, image_sizes=None):
         for b, (h_b, w_b) in enumerate(image_sizes):
             x[b, :, h_b:, :] = 0.0
             x[b, :, :, w_b:] = 0.0
-    res = M.resnet50(x, params)
+    res = M.resnet50(x, params, cfg)
     feats = M.fpn(res, params)
     rpn_outs = M.rpn_head(feats, params)
     shapes = [(f.shape[2], f.shape[3]) for f in feats]

@@ -217,6 +217,48 @@ def test_fullsize_step_f16x3_storage_paths_agree_with_fp32_mode():
     ctx.close()
 
 
+def test_configs2_real_size_step_b16_1024_all_ground_truth():
+    """BASELINE configs[2] at its REAL size -- local batch 16, 1024 x 1024, every ground-truth instance of the synthetic micrographs
+    (particles + satellites, several hundred per image) -- not only inside bench.py: the five losses against the training oracle
+    (forward only: a minute of host time), the step bitwise repeatable (losses and every value of the gradient arena), and the fp32-MFMA
+    mode agreeing on the losses."""
+    import hashlib
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    ctx = _lib.Context(0)
+    K, B, S = 2, 16, 1024
+    imgs, gts = synth.batch(B, S, S, first_index=1000)
+    ngt = [len(g["boxes"]) for g in gts]
+    assert min(ngt) >= 150 and sum(ngt) / B >= 250, ngt
+    npp = P.init_params(K, seed=0, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 800, max_poly_doubles=B * 800 * 64)
+    m.load_params(npp)
+    runs = []
+    for rep in range(2):
+        L = m.forward_losses(imgs, gts, seed=21, backward=True)
+        ptr, n = m.grad_arena()
+        arena = np.empty(n, dtype=np.float32)
+        ctx.sync(); ctx.d2h(arena, ptr)
+        runs.append((L, hashlib.sha256(arena.tobytes()).hexdigest(), float(np.abs(arena).max())))
+    assert runs[0][0] == runs[1][0] and runs[0][1] == runs[1][1] and runs[0][2] > 0 and np.isfinite(runs[0][2])
+    assert not ctx.conv_range_flag()
+    ctx.conv_mode = "f32"
+    try:
+        L32 = m.forward_losses(imgs, gts, seed=21)
+    finally:
+        ctx.conv_mode = "f16x3"
+    m.close(); ctx.close()
+    for k, v in L32.items():
+        assert runs[0][0][k] == pytest.approx(v, rel=3e-4, abs=1e-6), k
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = T.forward_losses(imgs, gts, M.to_torch_params(npp), T.TrainCfg(num_classes=K, seed=21))
+    print("configs[2] losses:", runs[0][0], "oracle:", {k: round(float(v), 6) for k, v in ref.items()}, "GT per image:", ngt)
+    for k, v in ref.items():
+        assert runs[0][0][k] == pytest.approx(float(v), rel=5e-4, abs=1e-6), (k, runs[0][0][k], float(v))
+
+
 @pytest.mark.parametrize("shape,scaled", [((256, 3, 3, 128), True), ((1024, 1, 1, 256), False), ((96, 3, 3, 36), True), ((64, 1, 1, 12544), True)])
 def test_dgrad_weights_split_is_transpose_then_split(gpu_ctx, shape, scaled):
     """One pass (LDS-tiled where both channel counts are multiples of 64, pairwise otherwise) against the two passes it replaces in a
