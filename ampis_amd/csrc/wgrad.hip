@@ -9,6 +9,8 @@
 // range is cut into S slices (split-K) so that the grid fills the chip; every slice writes its partial tile to a scratch slab
 // [S][N][K'] and wgrad_reduce_kernel adds the slabs in fixed order (bitwise reproducible, no float atomics), applies the
 // FrozenBN scale of the output channel and stores or accumulates into the gradient.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -921,7 +923,31 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
     a.rowtab = rowtab;
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     a.bias_partial = bias_grad ? reinterpret_cast<float*>(rowtab + tab_n) : nullptr;
-    hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
+    // The table is a function of the geometry alone: a context keeps the tables of the shapes it has seen (a training loop asks for the same
+    // ~30 every step: 69 launches and 0.4 ms per step otherwise) up to 512 MiB / 128 shapes; beyond that, and on a miss, it is made in the
+    // call's scratch as before.
+    {
+        const int key[9] = {a.B, a.H, a.W, a.Cin, a.KH, a.KW, a.stride, a.pad, a.Mpad};
+        static const bool no_cache = getenv("AMP_NO_ROWTAB_CACHE") != nullptr;      // EXPERIMENT switch
+        unsigned int* cached = nullptr;
+        for (auto& t : ctx->rowtabs) if (memcmp(t.key, key, sizeof(key)) == 0) { cached = t.tab; break; }
+        if (!cached && !no_cache && ctx->rowtabs.size() < 128 && ctx->rowtab_bytes + tab_n * 4 <= ((size_t)512 << 20)) {
+            unsigned int* t = nullptr;
+            if (hipMalloc(&t, tab_n * 4) == hipSuccess) {
+                WgradArgs ta = a;
+                hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, ta, t);
+                amp_ctx::RowTab e;
+                memcpy(e.key, key, sizeof(key)); e.tab = t; e.n = tab_n;
+                ctx->rowtabs.push_back(e);
+                ctx->rowtab_bytes += tab_n * 4;
+                cached = t;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (cached) a.rowtab = cached;
+        else hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, a, rowtab);
+    }
     amp_prof_rec* rec = nullptr;      // live profile (amp_prof_begin): slot 2 = the weight-gradient MFMA kernel alone
     if (ctx->prof_on) {
         if (ctx->prof_used < ctx->prof_pool.size()) {

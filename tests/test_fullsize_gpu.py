@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-FULLSIZE_IOU_BELOW_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.03, 6, 0.99      # about twice the measured level (see the test)
+FULLSIZE_TIE_SHARE_CAP, FULLSIZE_TIE_PIXELS_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.40, 20, 6, 0.99      # a little above the measured level (see the test)
 
 
 # BASELINE configs[1] (R50-FPN, 1024^2, 200 detections) and configs[4] (X-101-32x8d-FPN, native 2048^2, dense: 500 detections)
@@ -122,10 +122,10 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx, mode):
     st = gate.merge(stats)
     print(f"full-size gate [{mode}]:", gate.summary(st))
     assert st["instances"] == 2 * D and st["identical"] + st["tie_masks"] == st["instances"]
-    # caps at about twice the measured level (round 3: f16x3 6 of 400 masks below IoU 0.999 -- the largest 1158 px, lowest IoU 0.9969 --
-    # and 2 boxes of ~740 px inside the relative term; f32 5 of 200 in one image): a regression shows here even while the per-instance
-    # rule holds
-    gate.assert_bounds(st, iou_below_share=FULLSIZE_IOU_BELOW_CAP, box_rel_used=FULLSIZE_BOX_REL_CAP, iou_min=FULLSIZE_IOU_MIN)
+    # caps a little above the measured level (round 3: f16x3 115 of 400 masks with ties, at most 8 pixels in one, 6 masks below IoU 0.999
+    # -- the largest 1158 px, lowest IoU 0.9969 -- and 2 boxes of ~740 px inside the relative term; f32 124 / 12 / 6 / 0.9974 / 5):
+    # a regression shows here even while the per-instance rule holds
+    gate.assert_bounds(st, tie_mask_share=FULLSIZE_TIE_SHARE_CAP, max_tie_pixels=FULLSIZE_TIE_PIXELS_CAP, iou_min=FULLSIZE_IOU_MIN, box_rel_used=FULLSIZE_BOX_REL_CAP)
     if mode == "f32":
         return
     # where 1e-3 px is below the reference's own fp32 noise (boxes of several hundred px): against an exact-convolution evaluation
