@@ -147,15 +147,16 @@ def summary(st):
             f"{st['iou_below']} masks = {100.0 * st['iou_below'] / n:.2f} % (largest such mask {st['iou_below_area_max']} px, lowest IoU {st['iou_min']:.4f})")
 
 
-def assert_bounds(st, tie_mask_share, max_tie_pixels, iou_min, box_rel_used=0):
+def assert_bounds(st, tie_mask_share, max_tie_pixels, iou_min=None, box_rel_used=0):
     """The measured level of each relaxation, as a cap: a regression (more masks with flipped pixels, more flipped pixels per mask, boxes
     drifting into the relative term) fails here even though the per-instance rule still holds.  A mask falls below IoU 0.999 exactly when
-    its tied pixels exceed a thousandth of its area (one pixel does that to a mask of fewer than 1000 px): bounded through the share of
-    masks that have ties at all, the most tied pixels in one mask and the lowest IoU, and cross-checked below."""
+    its tied pixels exceed a thousandth of its area (one pixel does that to a mask of fewer than 1000 px -- a 64-px satellite with one
+    tied pixel has IoU 0.984): bounded through the share of masks that have ties at all and the most tied pixels in one mask, cross-checked
+    against the area of the largest mask below 0.999; iou_min only where the masks are large enough for it to mean something."""
     n = max(st["instances"], 1)
     assert st["tie_masks"] <= tie_mask_share * n + 1e-9, f"{st['tie_masks']} of {n} masks have threshold ties (cap {tie_mask_share:.2f}): {summary(st)}"
     assert st["max_tie_pixels"] <= max_tie_pixels, f"{st['max_tie_pixels']} tied pixels in one mask (cap {max_tie_pixels}): {summary(st)}"
-    assert st["iou_min"] >= iou_min, summary(st)
+    assert iou_min is None or st["iou_min"] >= iou_min, summary(st)
     assert st["iou_below"] <= st["tie_masks"] and st["iou_below_area_max"] < 1000 * max(st["max_tie_pixels"], 1), summary(st)
     assert st["box_rel_used"] <= box_rel_used, f"{st['box_rel_used']} boxes needed the relative term (cap {box_rel_used}): {summary(st)}"
     assert st["worst_box_le333"] < BOX_TOL, f"a box of at most 333 px is {st['worst_box_le333']:.2e} px off: the bare 1e-3 px must hold there"
