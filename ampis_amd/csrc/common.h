@@ -91,6 +91,8 @@ struct amp_ctx {
     size_t topk_bytes = 0;
     size_t split_bytes = 0;
     amp_comm* comm = nullptr;              // amp_comm_init: RCCL communicator of this context (one rank per context)
+    int* roi_order = nullptr;              // roi_align.hip: XCD-major processing order of the RoIs of a call (8 x (R/8 + 64) + 8 ints)
+    size_t roi_order_ints = 0;
     // wgrad row tables (wgrad.hip): they depend on the layer geometry only, so a training loop computes each once, not once per step
     struct RowTab { int key[9]; unsigned int* tab; size_t n; };
     std::vector<RowTab> rowtabs;

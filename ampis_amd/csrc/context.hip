@@ -145,6 +145,7 @@ void amp_destroy(amp_ctx* ctx) {
     (void)hipFree(ctx->split_scratch);
     (void)hipFree(ctx->topk_scratch);
     for (auto& t : ctx->rowtabs) (void)hipFree(t.tab);
+    (void)hipFree(ctx->roi_order);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

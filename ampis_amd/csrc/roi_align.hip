@@ -27,6 +27,12 @@ struct RoiArgs {
     int out_split;          // 1: write the AMP_CONV_F16X3 operand format (per 32 channels 64 B of f16 hi halves + 64 B of lo' halves)
     int in_split;           // 1: the feature maps are in that format (the trunk's native activation format in AMP_CONV_F16X3 inference)
     int share_taps;         // roi_align_split_kernel: keep a sample row's taps in registers (EXPERIMENT switch AMP_ROI_SHARE)
+    // XCD-major order (roi_order_kernel): workgroup b runs on XCD b % 8 and takes its RoIs from order[(b % 8) * xstride + ...], xlen[b % 8]
+    // of them -- per image the x-th eighth of the RoIs sorted by (level, Morton tile of the centre), so that the RoIs an L2 sees one after
+    // the other overlap, while all eight XCDs still work on the same image (its maps stay in the Infinity Cache).  null: index order.
+    const int* order;
+    const int* xlen;
+    int xstride;
 };
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -442,6 +448,76 @@ __device__ __forceinline__ void load_tap8(const float* row, int c8, f32x2r (&v)[
     }
 }
 
+// XCD-major processing order (RoiArgs::order).  One workgroup: keys (image | level | Morton tile of the box centre at that level, 8 x 8
+// cells | index) sorted bitonically in LDS (R <= 8192), then every image's sorted RoIs dealt out to the 8 XCDs in contiguous eighths.
+constexpr int ORDER_MAX = 8192;
+__device__ __forceinline__ unsigned int morton6(unsigned int y, unsigned int x) {
+    unsigned int m = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) m |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+    return m;
+}
+__global__ __launch_bounds__(1024) void roi_order_kernel(const RoiArgs a, int* __restrict__ order, int* __restrict__ xlen, int xstride) {
+    __shared__ unsigned int keys[ORDER_MAX];
+    __shared__ int cnt[32], start[33], off[8][33];
+    const int tid = threadIdx.x;
+    int n2 = 1;
+    while (n2 < a.R) n2 <<= 1;
+    if (tid < 32) cnt[tid] = 0;
+    __syncthreads();
+    for (int r = tid; r < n2; r += 1024) {
+        unsigned int k = 0xffffffffu;
+        if (r < a.R) {
+            const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+            const int lv = assign_level(x1, y1, x2, y2);
+            const int b = min(a.batch_idx ? a.batch_idx[r] : 0, 31);
+            // tile of the box centre in IMAGE pixels (32 x 32 px = 8 x 8 cells of p2), levels mixed: a chunk of the sorted list then holds the
+            // same mix of cheap (p2, 1-4 samples per bin axis) and expensive (p3..p5, 4-8) RoIs as every other chunk -- sorting by level
+            // first left whole XCDs with the expensive ones
+            const int cx = min(max((int)((x1 + x2) * 0.5f), 0) >> 5, 63), cy = min(max((int)((y1 + y2) * 0.5f), 0) >> 5, 63);
+            k = ((unsigned)b << 27) | (morton6((unsigned)cy, (unsigned)cx) << 15) | ((unsigned)lv << 13) | (unsigned)r;
+            atomicAdd(&cnt[b], 1);
+        }
+        keys[r] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (n2 >> 1); i += 1024) {
+                const int lo = ((i / stride) * stride << 1) + (i % stride), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned int ka = keys[lo], kb = keys[hi];
+                if ((ka > kb) == up) { keys[lo] = kb; keys[hi] = ka; }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        start[0] = 0;
+        for (int i = 0; i < 32; ++i) start[i + 1] = start[i] + cnt[i];
+    }
+    __syncthreads();
+    if (tid < 8) {       // chunk x of image i = sorted ranks [ceil(x n / 8), ceil((x + 1) n / 8))
+        int o = 0;
+        for (int i = 0; i < 32; ++i) {
+            off[tid][i] = o;
+            const int n = cnt[i];
+            o += (((tid + 1) * n + 7) >> 3) - ((tid * n + 7) >> 3);
+        }
+        off[tid][32] = o;
+        xlen[tid] = o;
+    }
+    __syncthreads();
+    for (int q = tid; q < a.R; q += 1024) {
+        const unsigned int k = keys[q];
+        const int i = (int)(k >> 27), r = (int)(k & 8191u);
+        const int n = cnt[i], s = q - start[i];
+        int x = min((s * 8) / max(n, 1), 7);
+        while (x < 7 && s >= (((x + 1) * n + 7) >> 3)) ++x;
+        while (x > 0 && s < ((x * n + 7) >> 3)) --x;
+        order[x * xstride + off[x][i] + (s - ((x * n + 7) >> 3))] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
     const bool g_share = a.share_taps != 0;
     const int lane = threadIdx.x & 63;
@@ -449,8 +525,18 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
     const int half = lane >> 5, c8 = lane & 31;                 // C == 256: 32 lanes x 8 channels
     const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
     const long long nbins = (long long)nvalid * a.P * a.P;
-    for (long long pair = (long long)blockIdx.x * 4 + wave; pair * 2 < nbins; pair += (long long)gridDim.x * 4) {
-        const long long bin = pair * 2 + half;
+    const int PP = a.P * a.P;
+    const long long npairs_x = a.order ? ((long long)a.xlen[blockIdx.x & 7] * PP + 1) / 2 : 0;     // XCD-major: this XCD's own bin pairs
+    const long long pair0 = a.order ? (long long)(blockIdx.x >> 3) * 4 + wave : (long long)blockIdx.x * 4 + wave;
+    const long long pstep = a.order ? (long long)(gridDim.x >> 3) * 4 : (long long)gridDim.x * 4;
+    for (long long pair = pair0; a.order ? pair < npairs_x : pair * 2 < nbins; pair += pstep) {
+        long long bin = pair * 2 + half;
+        if (a.order) {
+            const long long u = bin;                                   // bin unit inside the XCD's sequence
+            const int slot = (int)(u / PP);
+            if (slot >= a.xlen[blockIdx.x & 7]) continue;
+            bin = (long long)a.order[(blockIdx.x & 7) * a.xstride + slot] * PP + (u - (long long)slot * PP);
+        }
         if (bin >= nbins) continue;
         const int pw = (int)(bin % a.P);
         const int ph = (int)((bin / a.P) % a.P);
@@ -543,6 +629,8 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
 }  // namespace
 
 static int g_roi_share = getenv("AMP_ROI_SHARE") ? atoi(getenv("AMP_ROI_SHARE")) : 1;
+static int g_roi_xcd = getenv("AMP_ROI_XCD") ? atoi(getenv("AMP_ROI_XCD")) : 0;      // EXPERIMENT: XCD-major RoI order (roi_order_kernel)
+extern "C" void amp_debug_set_roi_xcd(int v) { g_roi_xcd = v; }
 static int g_roi_lanes = getenv("AMP_ROI_LANES") ? atoi(getenv("AMP_ROI_LANES")) : 1;   // 1: lane-parallel sample parameters (default); 0: the reference kernel (every lane computes every sample's parameters); 3: one workgroup per bin row, cells staged in LDS (slower, see roi_align_rows_kernel)
 extern "C" void amp_debug_set_roi_lanes(int v) { g_roi_lanes = v; }
 
@@ -577,6 +665,7 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
     }
     a.rois = rois; a.batch_idx = batch_idx; a.roi_count = roi_count; a.out = out; a.level_out = level_out;
     a.R = R; a.P = P; a.C = f->C; a.out_split = out_split; a.in_split = in_split; a.share_taps = g_roi_share;
+    a.order = nullptr; a.xlen = nullptr; a.xstride = 0;
     const long long nbins = (long long)R * P * P;
     long long g = (nbins + 3) / 4;
     if (g > 65536) g = 65536;
@@ -588,6 +677,24 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
     } else if (in_split && f->C == 256) {
         long long g2 = (nbins + 7) / 8;              // two bins per wave
         if (g2 > 65536) g2 = 65536;
+        if (g_roi_xcd && !roi_count && R <= ORDER_MAX && R >= 64) {
+            const int xstride = R / 8 + 64;
+            const size_t need = (size_t)8 * xstride + 8;
+            if (ctx->roi_order_ints < need) {
+                AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (ctx->roi_order) AMP_HIP_CHECK(hipFree(ctx->roi_order));
+                ctx->roi_order = nullptr; ctx->roi_order_ints = 0;
+                AMP_HIP_CHECK(hipMalloc(&ctx->roi_order, need * sizeof(int)));
+                ctx->roi_order_ints = need;
+            }
+            int* xlen = ctx->roi_order + (size_t)8 * xstride;
+            hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, ctx->roi_order, xlen, xstride);
+            a.order = ctx->roi_order; a.xlen = xlen; a.xstride = xstride;
+            // every XCD gets the same number of workgroups: enough for the longest chunk (R / 8 + one RoI of rounding per image, <= 32 images)
+            long long per_x = ((long long)(R / 8 + 33) * P * P + 7) / 8;
+            if (per_x > 8192) per_x = 8192;
+            g2 = per_x * 8;
+        }
         hipLaunchKernelGGL(roi_align_split_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
     } else if (in_split) hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     else if (g_roi_lanes) hipLaunchKernelGGL(roi_align_lanes_kernel<0>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);

@@ -41,3 +41,25 @@ for P, n in ((7, 1000), (14, 200)):
     for nm, F, fmt in (("fp32 maps", feats, 0), ("split maps -> split out", fs, 3)):
         run(f"{nm}, proposal-like boxes", rois, bidx, P, fmt, F)
         run(f"{nm}, every box the same 74 px box", same, bidx * 0, P, fmt, F)
+
+# XCD-major RoI order (AMP_ROI_XCD / amp_debug_set_roi_xcd): same outputs, fewer L2 misses?
+from ampis_amd import _lib
+L = _lib.lib()
+for P, n in ((7, 1000), (14, 200)):
+    rois, bidx = rois_like_proposals(n)
+    # proposals of a real image cluster on its particles: half of the boxes are jittered copies of 150 "objects" per image
+    obj = rois.view(B, n, 4)[:, :150]
+    pick = torch.randint(0, 150, (B, n // 2), generator=g).to(d)
+    jit = (torch.randn(B, n // 2, 4, generator=g) * 4.0).to(d)
+    clustered = rois.view(B, n, 4).clone()
+    clustered[:, : n // 2] = (torch.gather(obj, 1, pick[..., None].expand(-1, -1, 4)) + jit).clamp(0, S)
+    clustered = clustered.view(-1, 4).contiguous()
+    for nm, R_ in (("uniform centres", rois), ("clustered on 150 objects / image", clustered)):
+        outs = []
+        for mode in (0, 1, 0, 1):
+            L.amp_debug_set_roi_xcd(mode)
+            run(f"split maps, {nm}, XCD-major order = {mode}", R_, bidx, P, 3, fs)
+            outs.append(ops.roi_align(ctx, fs, R_, bidx, P, fmt=3)[0].clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), "XCD-major order changed the result"
+L.amp_debug_set_roi_xcd(0)
