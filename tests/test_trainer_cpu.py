@@ -39,7 +39,7 @@ def test_transform_annotations_scale_and_flip():
     f = transform_annotations(annos[:1], 0.5, 0.5, True, 100, 100)
     assert f["boxes"].tolist() == [[75, 10, 95, 30]]
     assert f["polygons"][0][0] == pytest.approx(100 - 5.25)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="bitmask"):      # an RLE segmentation under MASK_FORMAT='polygon': detectron2's kind of refusal (the bitmask format takes it)
         transform_annotations([{"bbox": [0, 0, 5, 5], "segmentation": {"size": [5, 5], "counts": b"0"}, "category_id": 0}], 1, 1, False, 5, 5)
 
 
