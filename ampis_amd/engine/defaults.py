@@ -141,6 +141,57 @@ class DefaultPredictor:
         return {"instances": inst}
 
 
+    def _model_kwargs(self):
+        c = self.cfg
+        return dict(detections_per_image=int(c.TEST.DETECTIONS_PER_IMAGE), pre_nms_topk=int(c.MODEL.RPN.PRE_NMS_TOPK_TEST),
+                    post_nms_topk=int(c.MODEL.RPN.POST_NMS_TOPK_TEST), rpn_nms_thresh=float(c.MODEL.RPN.NMS_THRESH),
+                    score_thresh=float(c.MODEL.ROI_HEADS.SCORE_THRESH_TEST), nms_thresh=float(c.MODEL.ROI_HEADS.NMS_THRESH_TEST),
+                    pixel_mean=tuple(c.MODEL.PIXEL_MEAN), pixel_std=tuple(c.MODEL.PIXEL_STD), arch=self.arch)
+
+    def stream(self, images, depth=2):
+        """`predictor(img)` for every image of an iterable, with `depth` images in flight on the GPU (amp_pipeline: the next image's
+        convolutions run while the previous one is in its selection / NMS / paste tail and its results travel to the host).  Yields
+        the same dicts `__call__` returns, in order, bit for bit (ResizeShortestEdge here is the PIL resize the device kernel reproduces
+        exactly).  The lanes are sized for the largest frame cfg.INPUT.{MIN,MAX}_SIZE_TEST allows and kept for later calls."""
+        from ..model import InferPipeline
+        c = self.cfg
+        mx = (int(c.INPUT.MAX_SIZE_TEST) + 31) // 32 * 32
+        key = (int(depth), mx)
+        if getattr(self, "_pipe_key", None) != key:
+            if getattr(self, "_pipe", None) is not None:
+                self._pipe.close()
+            self._pipe = InferPipeline(self.ctx.device if hasattr(self.ctx, "device") else _device_index(c.MODEL.DEVICE), self.num_classes, depth=int(depth),
+                                       max_batch=1, max_h=mx, max_w=mx, max_out_hw=4096, **self._model_kwargs())
+            self._pipe.load_params(self.params)
+            self._pipe_key = key
+        pipe = self._pipe
+        pending = []
+
+        def finish(entry):
+            ticket, (height, width) = entry
+            r = pipe.wait(ticket)[0]
+            inst = Instances((height, width))
+            inst.pred_boxes = Boxes(torch.from_numpy(r["boxes"]))
+            inst.scores = torch.from_numpy(r["scores"])
+            inst.pred_classes = torch.from_numpy(r["classes"])
+            inst.pred_masks = RLEBitMasks(r["masks"], (height, width))
+            return {"instances": inst}
+
+        for original_image in images:
+            original_image = np.asarray(original_image)
+            assert original_image.ndim == 3 and original_image.shape[2] == 3 and original_image.dtype == np.uint8, \
+                "DefaultPredictor expects HxWx3 uint8 images"
+            if self.input_format == "RGB":
+                original_image = original_image[:, :, ::-1]
+            height, width = original_image.shape[:2]
+            small = resize_shortest_edge(np.ascontiguousarray(original_image), int(c.INPUT.MIN_SIZE_TEST), int(c.INPUT.MAX_SIZE_TEST))
+            if len(pending) == pipe.depth:
+                yield finish(pending.pop(0))
+            pending.append((pipe.submit(small[None], out_sizes=[(height, width)]), (height, width)))
+        while pending:
+            yield finish(pending.pop(0))
+
+
 class TrainModel:
     """What `trainer.model` is: callable on a batch (list of mapped dicts).  In training mode (the default, and what
     LossEvalHook relies on: ampis/data_utils.py:116) it returns the dict of the five losses as floats."""

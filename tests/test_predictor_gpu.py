@@ -56,3 +56,35 @@ def test_predictor_refuses_cpu_device():
     cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
     with pytest.raises(_lib.AmpError):
         DefaultPredictor(cfg)
+
+
+def test_predictor_stream_equals_single_calls(tmp_path):
+    """DefaultPredictor.stream (amp_pipeline, two images in flight) against predictor(img) image by image: differently sized
+    micrographs, same boxes / scores / classes / RLE bytes, in order."""
+    from ampis_amd import checkpoint, model_zoo, params as P, synth
+    from ampis_amd.config import get_cfg
+    from ampis_amd.engine import DefaultPredictor
+    K, D = 1, 25
+    wpath = tmp_path / "model_final.pth"
+    checkpoint.save_checkpoint(wpath, P.init_params(K, seed=21, style="spread"))
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = K
+    cfg.TEST.DETECTIONS_PER_IMAGE = D
+    cfg.DATASETS.TEST = ("particle_Train",)
+    cfg.MODEL.WEIGHTS = str(wpath)
+    cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 160, 256
+    imgs = [synth.micrograph(i, h, w)[0] for i, (h, w) in enumerate(((240, 300), (200, 200), (180, 320), (256, 256), (150, 290)))]
+    predictor = DefaultPredictor(cfg)
+
+    def sig(o):
+        i = o["instances"]
+        return (i.image_size, i.pred_boxes.tensor.numpy().tobytes(), i.scores.numpy().tobytes(), i.pred_classes.numpy().tobytes(),
+                tuple(m["counts"] for m in i.pred_masks.rle))
+
+    want = [sig(predictor(im)) for im in imgs]
+    assert sum(len(w[4]) for w in want) > 20
+    for depth in (2, 3):
+        got = [sig(o) for o in predictor.stream(iter(imgs), depth=depth)]
+        assert got == want, depth
+    assert [sig(o) for o in predictor.stream(imgs[:1])] == want[:1]
