@@ -69,6 +69,19 @@ __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(
 
 }  // namespace amp
 
+// AMP_NO_PK: compile a kernel without packed-FP32 instructions (v_pk_mul / add / fma_f32).
+// Found in round 3 (tools/_probe_conc.py): with SEVERAL contexts running kernels on the card at once, box_candidates_kernel
+// occasionally wrote a box whose x1 (or y1) was the box CENTRE -- for 16 consecutive lanes, i.e. exp(dw) * w had come out as 0 there.  The
+// compiler keeps two wait states between a VALU instruction that writes VCC / an SGPR pair (v_cmp) and the VALU instruction that reads it as a
+// mask (v_cndmask: the range checks inside expf), and it had filled them with v_pk_* instructions; without packed instructions, or with
+// explicit s_nops, the same source never fails.  Single-context runs were never affected (every bitwise test of rounds 1-2 holds).
+// tools/scan_vcc_hazard.py finds these windows in a `hipcc -S` listing; tests/test_isa_hazard.py keeps every kernel file free of them.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AMP_NO_PK __attribute__((target("no-packed-fp32-ops")))
+#else
+#define AMP_NO_PK
+#endif
+
 #include <vector>
 struct amp_comm;   // comm.hip: RCCL communicator + its stream and events
 struct amp_prof_rec { hipEvent_t e0, e1; double flops; int variant; };

@@ -558,6 +558,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         AMP_TRY(detect(nullptr));
         tap(m, "box_pooled", pooled, bchain ? 5 : 0, {R, 7, 7, 256});
         tap(m, "box_pred", box_pred, 0, {R, ld_box});
+        tap(m, "box_dense", dense_boxes, 0, {B, Rcap * K, 4});
+        tap(m, "box_sorted", bs_boxes, 0, {B, ccap, 4});
         tap(m, "det_boxes", det_boxes, 0, {B, D, 4});
         tap(m, "det_scores", det_scores, 0, {B, D});
         tap(m, "det_classes", det_classes, 1, {B, D});
