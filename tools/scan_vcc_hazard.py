@@ -42,7 +42,8 @@ def scan(path):
             if op.startswith("s_nop"):
                 real += int(rest) + 1
                 continue
-            if op.startswith(("v_cndmask", "v_div_fmas", "v_addc", "v_subb")) and dst in rest:
+            reads_mask = op.startswith("v_") and dst in rest and not (re.match(r"(v_cmp|v_div_scale|v_add_co|v_sub_co)", op) and rest.split(",")[0].strip() == dst and rest.count(dst) == 1)
+            if reads_mask:
                 if real < 2 and pk > 0:
                     out.append((k[:60], l, " | ".join(x[1] for x in ins[i + 1:j + 1])))
                 break
