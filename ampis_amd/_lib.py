@@ -145,6 +145,7 @@ def _declare(L):
         "amp_rle_iou": ([vp, i, vp, i, i, C.POINTER(C.c_double)], i),
         "amp_rle_iou_matrix": ([vp, vp, vp, i, vp, vp, vp, i, vp, i, vp], i),
         "amp_rle_merge2": ([vp, i, vp, i, i, vp, i, C.POINTER(i)], i),
+        "amp_rle_resize_nearest": ([vp, i, i, i, i, i, i, vp, i, C.POINTER(i)], i),
         "amp_rle_pair_overlap": ([vp, vp, vp, vp, vp, vp, vp, vp, i, vp, vp, vp], i),
         "amp_rle_from_polygon": ([vp, i, i, i, vp, i, C.POINTER(i)], i),
         "amp_model_cfg_default": ([C.POINTER(ModelCfg)], i),

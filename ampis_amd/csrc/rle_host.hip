@@ -326,3 +326,84 @@ int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, 
 }
 
 }  // extern "C"
+
+// ---- nearest-neighbour resize (+ horizontal mirror) of a mask IN THE RUN-LENGTH DOMAIN -----------------------------------------------
+// What detectron2 does to a bitmask annotation when the image is resized: ResizeTransform.apply_segmentation = PIL Image.resize(NEAREST)
+// of the decoded mask (then HFlipTransform).  Decoding, resizing and re-encoding every instance of a micrograph costs seconds per image on
+// the host (476 instances at 1024 x 1536: 2.1 s); the same result from the runs costs microseconds.  The pixel correspondence is Pillow's
+// ImagingScaleAffine, restated with its double-precision ACCUMULATION (xo += a0 per step, COORD() = truncation): output column x reads source
+// column xin[x], output row y reads source row yin[y]; both tables are non-decreasing, so a run boundary of a source column maps to the
+// first output row whose source row reaches it.
+extern "C" int amp_rle_resize_nearest(const uint32_t* cnts, int m, int h, int w, int nh, int nw, int flip, uint32_t* out, int cap, int* m_out) {
+    AMP_REQUIRE(cnts && out && m_out && m > 0 && h > 0 && w > 0 && nh > 0 && nw > 0 && cap > 0, "amp_rle_resize_nearest: bad argument");
+    auto table = [](int n_in, int n_out, std::vector<int>& tab) {
+        tab.resize((size_t)n_out);
+        const double a = (double)n_in / (double)n_out;
+        double o = a * 0.5;
+        for (int i = 0; i < n_out; ++i) {
+            int v = o < 0.0 ? -1 : (int)o;
+            tab[(size_t)i] = v < n_in ? v : n_in - 1;          // (Pillow skips coordinates beyond the image; they cannot occur for a pure scale)
+            o += a;
+        }
+    };
+    std::vector<int> xin, yin;
+    table(w, nw, xin);
+    table(h, nh, yin);
+    // first output row that reads source row >= r, for r in [0, h]
+    std::vector<int> first((size_t)h + 1);
+    {
+        int y = 0;
+        for (int r = 0; r <= h; ++r) {
+            while (y < nh && yin[(size_t)y] < r) ++y;
+            first[(size_t)r] = y;
+        }
+    }
+    // per source column: value at row 0 and the rows where the value changes (a zero-length run gives two changes at one row: they cancel)
+    std::vector<int> col_start((size_t)w + 1, 0);
+    std::vector<int> trans;          // transition rows, column after column
+    std::vector<unsigned char> col_v0((size_t)w, 0);
+    {
+        unsigned long long total = 0;
+        for (int j = 0; j < m; ++j) total += cnts[j];
+        AMP_REQUIRE(total == (unsigned long long)h * w, "amp_rle_resize_nearest: the runs cover %llu pixels, the mask has %d x %d", total, h, w);
+        int j = 0;
+        unsigned long long run_end = cnts[0];
+        unsigned char v = 0;
+        for (int c = 0; c < w; ++c) {
+            const unsigned long long top = (unsigned long long)c * h, bot = top + h;
+            while (run_end <= top) { ++j; run_end += cnts[j]; v ^= 1; }
+            col_v0[(size_t)c] = v;
+            col_start[(size_t)c] = (int)trans.size();
+            while (run_end < bot) { trans.push_back((int)(run_end - top)); ++j; run_end += cnts[j]; v ^= 1; }
+        }
+        col_start[(size_t)w] = (int)trans.size();
+    }
+    // emit the output runs column by column
+    int mo = 0;
+    unsigned long long run = 0;
+    unsigned char cur = 0;           // COCO RLE starts with a run of zeros
+    auto put = [&](unsigned char v, unsigned long long n) -> bool {
+        if (n == 0) return true;
+        if (v == cur) { run += n; return true; }
+        if (mo >= cap) return false;
+        out[mo++] = (uint32_t)run;
+        cur = v; run = n;
+        return true;
+    };
+    for (int ox = 0; ox < nw; ++ox) {
+        const int sx = xin[(size_t)(flip ? nw - 1 - ox : ox)];
+        unsigned char v = col_v0[(size_t)sx];
+        int y0 = 0;
+        for (int t = col_start[(size_t)sx]; t < col_start[(size_t)sx + 1]; ++t) {
+            const int y1 = first[(size_t)trans[(size_t)t]];
+            if (!put(v, (unsigned long long)(y1 - y0))) { amp::set_error("amp_rle_resize_nearest: output capacity %d too small", cap); return AMP_ERR_NOMEM; }
+            y0 = y1;
+            v ^= 1;
+        }
+        if (!put(v, (unsigned long long)(nh - y0))) { amp::set_error("amp_rle_resize_nearest: output capacity %d too small", cap); return AMP_ERR_NOMEM; }
+    }
+    if (mo >= cap) { amp::set_error("amp_rle_resize_nearest: output capacity %d too small", cap); return AMP_ERR_NOMEM; }
+    out[mo++] = (uint32_t)run;
+    *m_out = mo;
+    return AMP_OK;
+}

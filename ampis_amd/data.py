@@ -114,7 +114,6 @@ def transform_annotations_bitmask(annos, old_h, old_w, new_h, new_w, flip):
       * a polygon segmentation has its vertices scaled / mirrored and is rasterised at the new size (polygons_to_bitmask);
     instances whose box or mask is empty are dropped.  The mask is handed on as COCO run lengths (`masks_rle`), never as a dense
     N x H x W tensor: the device builds the 28 x 28 targets from the runs (amp_mask_targets_bitmask)."""
-    from PIL import Image
     from . import rle
     boxes, classes, masks = [], [], []
     sx, sy = new_w / old_w, new_h / old_h
@@ -130,13 +129,10 @@ def transform_annotations_bitmask(annos, old_h, old_w, new_h, new_w, flip):
         b = np.clip(b, 0, [new_w, new_h, new_w, new_h])
         seg = a.get("segmentation")
         if isinstance(seg, dict):
-            m = rle.decode(seg)
-            assert m.shape == (old_h, old_w), f"segmentation of size {m.shape} on an image of {(old_h, old_w)}"
-            if (new_h, new_w) != (old_h, old_w):
-                m = np.asarray(Image.fromarray(np.ascontiguousarray(m)).resize((new_w, new_h), Image.NEAREST))
-            if flip:
-                m = m[:, ::-1]
-            r = rle.encode(np.asfortranarray(m))
+            assert tuple(int(v) for v in seg["size"]) == (old_h, old_w), f"segmentation of size {seg['size']} on an image of {(old_h, old_w)}"
+            # PIL NEAREST resize + mirror on the run lengths themselves (amp_rle_resize_nearest: the same pixels as decode -> Image.resize ->
+            # [:, ::-1] -> encode, 0.2 ms instead of 4 ms per instance of a 1024 x 1536 micrograph)
+            r = rle.resize_nearest(seg, new_h, new_w, flip) if ((new_h, new_w) != (old_h, old_w) or flip) else {"size": [old_h, old_w], "counts": rle.counts_to_string(rle._counts(seg))}
         elif isinstance(seg, (list, tuple)) and len(seg):
             ps = []
             for q in seg:

@@ -109,6 +109,24 @@ def iou(dt, gt, iscrowd):
     return out
 
 
+def resize_nearest(r, new_h, new_w, flip=False):
+    """RLE of flip(PIL.Image.resize(decode(r), (new_w, new_h), NEAREST)) computed on the runs (amp_rle_resize_nearest): what detectron2 does to a
+    bitmask annotation under ResizeShortestEdge + RandomFlip, without decoding."""
+    h, w = int(r["size"][0]), int(r["size"][1])
+    c = _counts(r)
+    cap = 2 * int(new_w) + 2 * len(c) * max(1, -(-int(new_w) // max(w, 1))) + 8      # every source transition repeats for each output column that reads its column
+    while True:
+        out = np.empty(cap, dtype=np.uint32)
+        m = C.c_int()
+        st = lib().amp_rle_resize_nearest(c.ctypes.data_as(C.c_void_p), len(c), h, w, int(new_h), int(new_w), int(bool(flip)),
+                                          out.ctypes.data_as(C.c_void_p), cap, C.byref(m))
+        if st == 0:
+            return {"size": [int(new_h), int(new_w)], "counts": counts_to_string(out[: m.value])}
+        if cap >= int(new_h) * int(new_w) + 2:
+            check(st, "amp_rle_resize_nearest")
+        cap = min(cap * 4, int(new_h) * int(new_w) + 2)
+
+
 def pair_overlap(a, b, pairs):
     """For index pairs (i, j): |a[i] AND b[j]|, |a[i] minus b[j]|, |b[j] minus a[i]| as three int64 arrays, one C call
     (amp_rle_pair_overlap)."""

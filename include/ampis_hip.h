@@ -350,6 +350,10 @@ int amp_rle_iou_matrix(const uint32_t* dpool, const unsigned long long* doff, co
 int amp_rle_pair_overlap(const uint32_t* apool, const unsigned long long* aoff, const int* alen, const uint32_t* bpool,
                          const unsigned long long* boff, const int* blen, const int* pair_a, const int* pair_b, int npairs,
                          unsigned long long* inter, unsigned long long* only_a, unsigned long long* only_b);
+/* Nearest-neighbour resize (+ horizontal mirror when flip) of a mask in the run-length domain: the runs of
+ * flip(PIL.Image.resize(decode(cnts), (nw, nh), NEAREST)) -- what detectron2's ResizeTransform.apply_segmentation + HFlipTransform do to a bitmask
+ * annotation -- without decoding (Pillow's ImagingScaleAffine pixel correspondence, restated).  cap >= nh * nw + 1 is always enough. */
+int amp_rle_resize_nearest(const uint32_t* cnts, int m, int h, int w, int nh, int nw, int flip, uint32_t* out, int cap, int* m_out);
 int amp_rle_merge2(const uint32_t* A, int ka, const uint32_t* B, int kb, int intersect, uint32_t* out, int cap, int* m_out);
 /* polygon (k vertices, flat xy) -> runs of an h x w mask (pycocotools rleFrPoly / frPyObjects) */
 int amp_rle_from_polygon(const double* xy, int k, int h, int w, uint32_t* cnts, int cap, int* m_out);

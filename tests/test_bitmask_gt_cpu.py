@@ -102,3 +102,29 @@ def test_oracle_target_builders_on_closed_form_cases():
     a = np.array([2, 2, 12, 2, 12, 12, 2, 12], float); b = np.array([15, 15, 25, 15, 25, 25, 15, 25], float)
     box = [0, 0, 28, 28]
     assert np.array_equal(T.rasterize_polygon_within_box([a, b], box, 28), T.rasterize_polygon_within_box(a, box, 28) | T.rasterize_polygon_within_box(b, box, 28))
+
+
+def test_rle_domain_resize_is_pil_nearest_resize_and_flip():
+    """amp_rle_resize_nearest against PIL itself (the call detectron2's ResizeTransform.apply_segmentation makes) on random, empty, full,
+    blocky and sparse masks, up- and down-scaling with awkward ratios, 1-pixel sizes, with and without the mirror: same pixels, same
+    counts string as encode(resize(decode))."""
+    from PIL import Image
+    from ampis_amd import rle
+    rng = np.random.default_rng(0)
+    for trial in range(150):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 90))
+        nh, nw = int(rng.integers(1, 140)), int(rng.integers(1, 160))
+        kind = trial % 5
+        m = (rng.random((h, w)) > (0.5, 2.0, -1.0, 0.5, 0.9)[kind])
+        if kind == 3:
+            m = np.zeros((h, w), bool); m[h // 4:max(h // 4 + 1, 3 * h // 4), w // 3:max(w // 3 + 1, 2 * w // 3)] = True
+        r = rle.encode(np.asfortranarray(m))
+        for flip in (False, True):
+            ref = np.asarray(Image.fromarray(m.astype(np.uint8)).resize((nw, nh), Image.NEAREST)).astype(bool)
+            ref = ref[:, ::-1] if flip else ref
+            got = rle.resize_nearest(r, nh, nw, flip)
+            assert got["size"] == [nh, nw] and got["counts"] == rle.encode(np.asfortranarray(ref))["counts"], (h, w, nh, nw, flip, kind)
+    m = np.zeros((1024, 1536), bool); m[300:700, 200:900] = True; m[::97, ::89] = True
+    got = rle.resize_nearest(rle.encode(np.asfortranarray(m)), 800, 1200, True)
+    ref = np.asarray(Image.fromarray(m.astype(np.uint8)).resize((1200, 800), Image.NEAREST)).astype(bool)[:, ::-1]
+    assert np.array_equal(rle.decode(got).astype(bool), ref)
