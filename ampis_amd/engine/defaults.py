@@ -141,6 +141,19 @@ class DefaultPredictor:
         return {"instances": inst}
 
 
+    def close(self):
+        """Free the device side of the predictor (model, the stream() lanes, context)."""
+        if getattr(self, "_pipe", None) is not None:
+            self._pipe.close()
+            self._pipe = None
+            self._pipe_key = None
+        if self._model is not None:
+            self._model.close()
+            self._model = None
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
     def _model_kwargs(self):
         c = self.cfg
         return dict(detections_per_image=int(c.TEST.DETECTIONS_PER_IMAGE), pre_nms_topk=int(c.MODEL.RPN.PRE_NMS_TOPK_TEST),

@@ -88,3 +88,4 @@ def test_predictor_stream_equals_single_calls(tmp_path):
         got = [sig(o) for o in predictor.stream(iter(imgs), depth=depth)]
         assert got == want, depth
     assert [sig(o) for o in predictor.stream(imgs[:1])] == want[:1]
+    predictor.close()
