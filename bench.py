@@ -432,6 +432,11 @@ def main(args):
     if staged:
         local_rank = 0
         os.environ["AMP_COMM_BACKEND"] = "staged"
+    elif os.environ.get("AMP_BENCH_ONE_CARD"):
+        # second rehearsal mode: every rank on device 0 with the library's OWN exchange path (amp_comm_*: barrier, max of the elapsed times,
+        # parameter broadcast, the seven overlapped gradient buckets) -- possible with AMP_RCCL_LIB pointing at the shared-memory stand-in
+        # for librccl (tests/fake_rccl: RCCL itself refuses two ranks on one device).  Timings of such a run mean nothing; that it runs does.
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
