@@ -263,3 +263,36 @@ def test_default_trainer_on_get_ddicts_binary(tmp_path):
         tr2.run_step()
     tr.close(); tr2.close()
     DatasetCatalog.clear()
+
+
+def test_ragged_batch_with_bitmask_and_mixed_ground_truth(gpu_ctx):
+    """Two images of different size in one frame, ground truth MIXED: the first image's instances are bitmasks at that image's own size
+    (rle_hw per instance), the second image's are polygons, one of them made of two polygons -- one amp_gt, one call; losses against the oracle."""
+    from ampis_amd import params as P, rle, synth
+    from ampis_amd.model import MaskRCNN
+    from oracle import maskrcnn as M, train as T
+    K, B, H, W = 2, 2, 256, 320
+    sizes = [(200, 250), (256, 320)]
+    imgs, gts = synth.batch(B, H, W, seed=9)
+    def inside(g, h, w, n):
+        keep = [i for i in range(len(g["boxes"])) if g["boxes"][i][2] <= w - 1 and g["boxes"][i][3] <= h - 1][:n]
+        return dict(boxes=np.asarray(g["boxes"])[keep], classes=np.asarray(g["classes"])[keep], polygons=[g["polygons"][i] for i in keep])
+    g0, g1 = inside(gts[0], 200, 250, 30), inside(gts[1], 256, 320, 30)
+    g0 = dict(boxes=g0["boxes"], classes=g0["classes"], polygons=[None] * len(g0["boxes"]),
+              masks_rle=[rle.merge(rle.frPyObjects([np.asarray(p, float).tolist()], 200, 250)) for p in g0["polygons"]])
+    p0 = np.asarray(g1["polygons"][0], float)
+    extra = p0.copy(); extra[0::2] += 6.0; extra[1::2] += 4.0                      # a second, shifted polygon of the same instance
+    g1["polygons"] = [[p0, extra]] + list(g1["polygons"][1:])
+    gts = [g0, g1]
+    npp = P.init_params(K, seed=1, style="spread")
+    ref = T.forward_losses(imgs, gts, M.to_torch_params(npp), T.TrainCfg(num_classes=K, seed=3), image_sizes=sizes)
+    model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=4096, max_poly_doubles=4096 * 64)
+    model.load_params(npp)
+    model.set_image_sizes(sizes)
+    got = model.forward_losses(imgs, gts, seed=3)
+    back = model.forward_losses(imgs, gts, seed=3, backward=True)
+    model.set_image_sizes(None)
+    model.close()
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg", "loss_mask"):
+        assert got[k] == pytest.approx(float(ref[k]), rel=2e-4, abs=1e-6), (k, got[k], float(ref[k]))
+    assert back == got
