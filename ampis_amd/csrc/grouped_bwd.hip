@@ -20,9 +20,11 @@ struct GWArgs {
     int B, H, W, C, Ho, Wo, KH, KW, stride, pad;
     int rows_per_slice;   // output rows (b, oy) per slice
     int nslices;
+    int diag_only;        // <= 32 channels per group: the two off-diagonal 32 x 32 quadrants of a tile hold no in-group pair -- two waves, not four
 };
 
-// grid: (C/64) * KH*KW * nslices workgroups of 256 threads; wave w computes the 32 x 32 quadrant (co half w & 1, ci half w >> 1)
+// grid: (C/64) * KH*KW * nslices workgroups of 256 (128 with diag_only) threads; wave w computes the 32 x 32 quadrant (co half w & 1, ci half
+// w >> 1), or the diagonal quadrant w when the groups are at most 32 channels wide (the reduce pass never reads the other two)
 __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ntaps = a.KH * a.KW, ntiles = a.C >> 6;
@@ -32,8 +34,9 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
     const int tile = id / ntaps;
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
     const int i = lane & 31, k = lane >> 5;                        // MFMA 32x32x2: a lane holds A[i][k] and B[k][i]
-    const int co = (tile << 6) + ((wave & 1) << 5) + i;
-    const int ci = (tile << 6) + ((wave >> 1) << 5) + i;
+    const int cob = a.diag_only ? (wave << 5) : ((wave & 1) << 5), cib = a.diag_only ? (wave << 5) : ((wave >> 1) << 5);
+    const int co = (tile << 6) + cob + i;
+    const int ci = (tile << 6) + cib + i;
     f32x16 acc;
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int row0 = slice * a.rows_per_slice, row1 = min(row0 + a.rows_per_slice, a.B * a.Ho);
@@ -59,7 +62,6 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
     }
     // acc[r]: row (co) = (r / 4) * 8 + (lane / 32) * 4 + r % 4, column (ci) = lane % 32
     float* out = a.partial + ((((size_t)slice * ntiles + tile) * ntaps + tap) << 12);
-    const int cob = (wave & 1) << 5, cib = (wave >> 1) << 5;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int rco = cob + (r >> 2) * 8 + k * 4 + (r & 3);
@@ -123,11 +125,13 @@ int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, c
     a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     AMP_REQUIRE(a.Ho > 0 && a.Wo > 0, "amp_conv2d_grouped_wgrad: empty output");
     const int rows = a.B * a.Ho, pairs = (a.C >> 6) * a.KH * a.KW;
-    int nslices = std::max(1, std::min({16, rows, (1024 + pairs - 1) / pairs}));      // ~1024 workgroups: four per CU
+    const int target = (cpg <= 32) ? 3072 : 1024;                                        // ~four (two-wave: twelve) workgroups per CU
+    int nslices = std::max(1, std::min({16, rows, (target + pairs - 1) / pairs}));
     a.rows_per_slice = (rows + nslices - 1) / nslices;
     nslices = (rows + a.rows_per_slice - 1) / a.rows_per_slice;
     a.nslices = nslices;
-    hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(256), 0, ctx->stream, a);
+    a.diag_only = cpg <= 32 ? 1 : 0;
+    hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(a.diag_only ? 128 : 256), 0, ctx->stream, a);
     const size_t total = (size_t)a.C * a.KH * a.KW * 64;
     hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
                        scratch, scale, grad_win, a.C, a.KH * a.KW, nslices, cpg);
