@@ -98,7 +98,7 @@ __device__ __forceinline__ int paste_bit(const float* sp, Axis ax, Axis ay, floa
     return v >= thr ? 1 : 0;
 }
 
-__global__ __launch_bounds__(PT) AMP_NO_PK void paste_rle_kernel(const PasteArgs a) {
+__global__ __launch_bounds__(PT) void paste_rle_kernel(const PasteArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sp = reinterpret_cast<float*>(smem);                          // [784]
     int* s_scan = reinterpret_cast<int*>(sp + MS * MS);                  // [PT]
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(PT) AMP_NO_PK void paste_rle_kernel(const PasteArgs
         for (int iy = 0; iy < ny; ++iy) {
             Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
             const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
-            cnt += (bit != prev);
+            cnt += bit ^ prev;          // (both are 0 / 1)
             prev = bit;
         }
         // closing transition back to 0 when the next pixel in linear order lies outside the region

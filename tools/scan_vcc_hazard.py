@@ -33,7 +33,7 @@ def scan(path):
         if not dst:
             continue
         real, pk = 0, 0
-        for j in range(i + 1, min(i + 7, len(ins))):
+        for j in range(i + 1, min(i + 9, len(ins))):
             k2, l2 = ins[j]
             if k2 != k:
                 break
@@ -42,9 +42,14 @@ def scan(path):
             if op.startswith("s_nop"):
                 real += int(rest) + 1
                 continue
-            reads_mask = op.startswith("v_") and dst in rest and not (re.match(r"(v_cmp|v_div_scale|v_add_co|v_sub_co)", op) and rest.split(",")[0].strip() == dst and rest.count(dst) == 1)
+            parts = [x.strip() for x in rest.split(",")]
+            dst_slots = [0] if re.match(r"v_cmpx?_", op) and (parts[0] == "vcc" or parts[0].startswith("s[")) else ([1] if re.match(r"(v_div_scale|v_add_co|v_sub_co|v_subrev_co|v_addc_co|v_subb_co)", op) else [])
+            src_hits = [i for i, x in enumerate(parts) if dst in x and i not in dst_slots]
+            reads_mask = op.startswith("v_") and bool(src_hits)
+            if op.startswith("v_") and not src_hits and any(dst in parts[i] for i in dst_slots if i < len(parts)):
+                break                      # the mask is redefined before anybody read it
             if reads_mask:
-                if real < 2 and pk > 0:
+                if real < (4 if op.startswith("v_div_fmas") else 2) and pk > 0:      # v_div_scale -> v_div_fmas wants four wait states
                     out.append((k[:60], l, " | ".join(x[1] for x in ins[i + 1:j + 1])))
                 break
             if re.match(r"(v_cmp|v_div_scale|s_)", op) and dst in rest.split(",")[0]:
