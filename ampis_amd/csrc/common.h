@@ -75,6 +75,7 @@ __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(
 // compiler keeps two wait states between a VALU instruction that writes VCC / an SGPR pair (v_cmp) and the VALU instruction that reads it as a
 // mask (v_cndmask: the range checks inside expf), and it had filled them with v_pk_* instructions; without packed instructions, or with
 // explicit s_nops, the same source never fails.  Single-context runs were never affected (every bitwise test of rounds 1-2 holds).
+// (paste_rle_kernel had one such window too: its compare / select became an xor.)
 // tools/scan_vcc_hazard.py finds these windows in a `hipcc -S` listing; tests/test_isa_hazard.py keeps every kernel file free of them.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define AMP_NO_PK __attribute__((target("no-packed-fp32-ops")))
