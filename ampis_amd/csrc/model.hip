@@ -469,31 +469,43 @@ int run_proposals(amp_model* m, const Trunk& T, int B, int H, int W, int k, int 
     AMP_ALLOC(sel_count, int, (size_t)B * 5);
     AMP_ALLOC(cand_boxes, float, (size_t)B * cap * 4);
     AMP_ALLOC(cand_keys, unsigned long long, (size_t)B * cap);
-    AMP_ALLOC(s_boxes, float, (size_t)B * cap * 4);
-    AMP_ALLOC(s_scores, float, (size_t)B * cap);
-    AMP_ALLOC(s_cats, int, (size_t)B * cap);
-    AMP_ALLOC(s_count, int, (size_t)B);
-    AMP_ALLOC(nms_mask, unsigned long long, (size_t)B * cap * ((cap + 63) / 64));
-    AMP_ALLOC(keep_idx, int, (size_t)B * Rcap);
     AMP_ALLOC(prop_count, int, (size_t)B);
     AMP_ALLOC(prop_boxes, float, (size_t)B * Rcap * 4);
     AMP_ALLOC(prop_logits, float, (size_t)B * Rcap);
     AMP_ALLOC(prop_lvl, int, (size_t)B * Rcap);
     AMP_ALLOC(cand_anchor, int, (size_t)B * cap);
-    AMP_ALLOC(s_anchor, int, (size_t)B * cap);
     AMP_ALLOC(prop_anchor, int, (size_t)B * Rcap);
+    // AMP_RPN_NMS=flat: the one-list path of rounds 1-3 (sort all levels' candidates, one NMS per image) for A/B runs; same proposals
+    static const bool flat = [] { const char* e = getenv("AMP_RPN_NMS"); return e && !strcmp(e, "flat"); }();
+    if (flat) {
+        AMP_ALLOC(s_boxes, float, (size_t)B * cap * 4);
+        AMP_ALLOC(s_scores, float, (size_t)B * cap);
+        AMP_ALLOC(s_cats, int, (size_t)B * cap);
+        AMP_ALLOC(s_count, int, (size_t)B);
+        AMP_ALLOC(nms_mask, unsigned long long, (size_t)B * cap * ((cap + 63) / 64));
+        AMP_ALLOC(keep_idx, int, (size_t)B * Rcap);
+        AMP_ALLOC(s_anchor, int, (size_t)B * cap);
+        if (!dry) {
+            AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
+            AMP_TRY(amp_rpn_decode_sized(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, T.img_hw, cap, cand_boxes, cand_keys, cand_anchor));
+            AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr, cand_anchor, s_anchor));
+            AMP_TRY(amp_nms(ctx, B, cap, s_boxes, s_cats, s_count, c.rpn_nms_thresh, Rcap, nms_mask, keep_idx, prop_count));
+            AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl, s_anchor, prop_anchor));
+        }
+    } else {
+        // each level's top-k list is its own NMS problem (the level is batched_nms's category); the survivors' lists are merged (nms.hip)
+        AMP_ALLOC(lvl_scratch, unsigned long long, amp_rpn_nms_scratch_words(B, 5, k));
+        if (!dry) {
+            AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
+            AMP_TRY(amp_rpn_decode_sized(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, T.img_hw, cap, cand_boxes, cand_keys, cand_anchor));
+            AMP_TRY(amp_rpn_nms_levels(ctx, B, 5, k, cap, cand_boxes, cand_keys, sel_count, c.rpn_nms_thresh, Rcap, lvl_scratch, prop_boxes,
+                                       prop_logits, prop_lvl, prop_count, cand_anchor, prop_anchor));
+        }
+    }
     if (!dry) {
-        AMP_TRY(amp_rpn_topk(ctx, &lv, B, k, keys_scratch, max_n, sel_idx, sel_logit, sel_count));
-        AMP_TRY(amp_rpn_decode_sized(ctx, &lv, B, k, sel_idx, sel_logit, sel_count, H, W, T.img_hw, cap, cand_boxes, cand_keys, cand_anchor));
-        AMP_TRY(amp_sort_gather(ctx, B, cap, cap, cand_keys, cand_boxes, s_boxes, s_scores, s_cats, s_count, nullptr, cand_anchor, s_anchor));
-        AMP_TRY(amp_nms(ctx, B, cap, s_boxes, s_cats, s_count, c.rpn_nms_thresh, Rcap, nms_mask, keep_idx, prop_count));
-        AMP_TRY(amp_gather_dets(ctx, B, cap, Rcap, s_boxes, s_scores, s_cats, keep_idx, prop_count, prop_boxes, prop_logits, prop_lvl, s_anchor, prop_anchor));
         tap(m, "rpn_sel_idx", sel_idx, 1, {B, 5, k});
         tap(m, "rpn_sel_logit", sel_logit, 0, {B, 5, k});
-        tap(m, "rpn_cand_sorted_boxes", s_boxes, 0, {B, cap, 4});
-        tap(m, "rpn_cand_sorted_scores", s_scores, 0, {B, cap});
-        tap(m, "rpn_cand_sorted_lvl", s_cats, 1, {B, cap});
-        tap(m, "rpn_cand_count", s_count, 1, {B});
+        tap(m, "rpn_cand_boxes", cand_boxes, 0, {B, cap, 4});
         tap(m, "prop_boxes", prop_boxes, 0, {B, Rcap, 4});
         tap(m, "prop_logits", prop_logits, 0, {B, Rcap});
         tap(m, "prop_count", prop_count, 1, {B});

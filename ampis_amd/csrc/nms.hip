@@ -141,6 +141,208 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
     if (lane == 0) keep_count[b] = min(nkept, max_keep);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// RPN proposals: NMS per (image, level) segment + merge.  batched_nms uses the level as category, so boxes of different levels never
+// meet: instead of ONE score-ordered list of 5 k candidates per image (79 chunks walked by one wave, a 79 x 79-tile matrix, a
+// 8192-word sort in front) each level's top-k list -- already in (logit desc, anchor asc) order -- is its own problem of <= 16 (32)
+// chunks, and the first post_nms_topk of the image are a merge of L sorted lists of survivors.  Same decisions as the one-list path
+// (greedy NMS restricted to a category IS the category's greedy NMS), same order (the sort word's position breaks ties between levels).
+struct LvlArgs {
+    const float* boxes;                 // [B][cap][4] decoded candidates: level l of image b at [off, off + sel_count[b][l]), off = counts before
+    const unsigned long long* keys;     // [B][cap] sort words of those candidates, 0 = invalid (non-finite / empty box)
+    const int* sel_count;               // [B][L]
+    int L, cap, k, nchk;                // nchk = ceil(k / 64): chunks per segment at most
+    float thresh;
+    unsigned long long* mt;             // [B*L][nchk][nchk*64] suppression words, see lvl_mask_kernel
+    unsigned long long* kept;           // [B*L][k] sort words of the survivors, in order
+    int* kept_count;                    // [B*L]
+    int max_keep;
+};
+
+__device__ __forceinline__ int lvl_offset(const LvlArgs& a, int b, int lvl) {
+    int off = 0;
+    for (int l = 0; l < lvl; ++l) off += a.sel_count[b * a.L + l];
+    return off;
+}
+
+// One wave per 64 x 64 tile (rb <= cb) of a segment.  Lane = box cb*64 + lane; it meets the 64 boxes of chunk rb (LDS).
+//   rb <  cb: word [rb][cb*64 + lane], bit ii = "box rb*64+ii (higher score) suppresses this box"     (column-oriented)
+//   rb == cb: word [cb][cb*64 + lane], bit jj = "this box suppresses box cb*64+jj", jj > lane         (row-oriented: the scan's scalar loop)
+// IoU in torchvision's op order, fp32, no contraction; max / min / the sum of the two areas are commutative, so the value does not depend
+// on which of the two boxes the lane holds.  A trip whose 64 pairs are all disjoint skips the division (inter == 0 -> iou 0 or NaN, never
+// above a threshold >= 0).
+__global__ __launch_bounds__(64) void lvl_mask_kernel(const LvlArgs a) {
+    const int seg = blockIdx.z;
+    const int n = min(a.sel_count[seg], a.k);
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb || cb * 64 >= n) return;
+    const int b = seg / a.L, lvl = seg - b * a.L;
+    const float4* boxes = reinterpret_cast<const float4*>(a.boxes) + (size_t)b * a.cap + lvl_offset(a, b, lvl);
+    const int lane = threadIdx.x;
+    __shared__ float4 sb[64];
+    {
+        const int i = rb * 64 + lane;
+        sb[lane] = (i < n) ? boxes[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    const int j = cb * 64 + lane;
+    const float4 me = (j < n) ? boxes[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float area_me = __fmul_rn(__fsub_rn(me.z, me.x), __fsub_rn(me.w, me.y));
+    const bool diag = rb == cb;
+    const int in = min(64, n - rb * 64);
+    unsigned long long bits = 0ull;
+    for (int ii = 0; ii < in; ++ii) {
+        const float4 o = sb[ii];
+        const float xx1 = fmaxf(me.x, o.x), yy1 = fmaxf(me.y, o.y);
+        const float xx2 = fminf(me.z, o.z), yy2 = fminf(me.w, o.w);
+        const float w = fmaxf(__fsub_rn(xx2, xx1), 0.f), h = fmaxf(__fsub_rn(yy2, yy1), 0.f);
+        const float inter = __fmul_rn(w, h);
+        const bool pair = (j < n) && (!diag || ii > lane);
+        if (__ballot(pair && inter > 0.f) == 0ull) continue;
+        const float area_o = __fmul_rn(__fsub_rn(o.z, o.x), __fsub_rn(o.w, o.y));
+        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_me, area_o), inter));
+        if (pair && iou > a.thresh) bits |= (1ull << ii);
+    }
+    const int rowlen = a.nchk * 64;
+    a.mt[((size_t)seg * a.nchk + rb) * rowlen + j] = bits;
+}
+
+// One 1024-thread workgroup per segment.  Super-blocks of 16 chunks (1024 boxes): every wave folds the decisions of earlier super-blocks
+// into "removed" bits of its chunk (coalesced reads of the words, ANDed with the kept words) and copies the super-block's own triangle of
+// words into LDS; then wave 0 walks the 16 chunks out of LDS: removed = OR of (word & kept word of the earlier chunk), the chunk's own
+// order by the scalar loop over its row-oriented diagonal words.
+constexpr int LVL_SB = 16;
+__global__ __launch_bounds__(1024) void lvl_scan_kernel(const LvlArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smt[];     // [LVL_SB][LVL_SB * 64]
+    __shared__ unsigned long long skeep[64];                                       // kept word per chunk (nchk <= 64)
+    __shared__ unsigned long long spre[LVL_SB];                                    // removed before the super-block's own scan
+    const int seg = blockIdx.x;
+    const int b = seg / a.L, lvl = seg - b * a.L;
+    const int n = min(a.sel_count[seg], a.k);
+    const int nch = (n + 63) >> 6;
+    const int off = lvl_offset(a, b, lvl);
+    const unsigned long long* keys = a.keys + (size_t)b * a.cap + off;
+    const int rowlen = a.nchk * 64;
+    const unsigned long long* mt = a.mt + (size_t)seg * a.nchk * rowlen;
+    unsigned long long* out = a.kept + (size_t)seg * a.k;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int s_nkept;
+    if (threadIdx.x == 0) s_nkept = 0;
+    for (int sb0 = 0; sb0 < nch; sb0 += LVL_SB) {
+        __syncthreads();            // the previous super-block's kept words and count are visible, its LDS words are free
+        int nkept = s_nkept;
+        if (nkept >= a.max_keep) break;      // uniform: later boxes cannot change earlier decisions
+        {
+            const int c = sb0 + wave;
+            if (c < nch) {
+                const int j = c * 64 + lane;
+                unsigned long long acc = 0ull;
+                for (int rc = 0; rc < sb0; rc += 8) {         // sb0 is a multiple of 16
+                    unsigned long long v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = mt[(size_t)(rc + u) * rowlen + j];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc |= v[u] & skeep[rc + u];
+                }
+                const unsigned long long key = (j < n) ? keys[j] : 0ull;
+                const unsigned long long pre = __ballot(acc != 0ull || key == 0ull);
+                if (lane == 0) spre[wave] = pre;
+                for (int rc = sb0; rc <= c; ++rc) smt[(rc - sb0) * (LVL_SB * 64) + wave * 64 + lane] = mt[(size_t)rc * rowlen + j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int cend = min(LVL_SB, nch - sb0);
+            for (int cc = 0; cc < cend && nkept < a.max_keep; ++cc) {
+                const int c = sb0 + cc;
+                unsigned long long acc = 0ull;
+                for (int r2 = 0; r2 < cc; ++r2) acc |= smt[r2 * (LVL_SB * 64) + cc * 64 + lane] & skeep[sb0 + r2];
+                const unsigned long long removed = __ballot(acc != 0ull) | spre[cc];
+                const unsigned long long diag = smt[cc * (LVL_SB * 64) + cc * 64 + lane];
+                const unsigned int dlo = (unsigned int)(diag & 0xffffffffu), dhi = (unsigned int)(diag >> 32);
+                unsigned long long cur = ~removed;       // boxes beyond n and invalid ones are in spre
+                unsigned long long keep = 0ull;
+                while (cur != 0ull) {                    // wave-uniform: alive boxes of the chunk in score order
+                    const int bit = __builtin_ctzll(cur);
+                    keep |= (1ull << bit);
+                    const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
+                    const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
+                    cur &= ~(((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo);
+                    cur &= ~(1ull << bit);
+                }
+                if (lane == 0) skeep[c] = keep;
+                if ((keep >> lane) & 1ull) {
+                    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                    out[nkept + __popcll(keep & below)] = keys[c * 64 + lane];        // nkept <= n <= k
+                }
+                nkept += __popcll(keep);
+            }
+            if (lane == 0) s_nkept = nkept;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.kept_count[seg] = min(s_nkept, a.k);
+}
+
+// One workgroup per image: rank of every survivor in the merge of the L sorted lists (own index + binary searches in the others; the
+// sort words are unique), the first max_keep written in order with their boxes / logits / levels / payloads, the rest of the rows zeroed
+// as amp_gather_dets leaves them.
+struct MergeArgs {
+    const unsigned long long* kept;     // [B*L][k]
+    const int* kept_count;              // [B*L]
+    const float* boxes;                 // [B][cap][4], indexed by the sort word's position
+    const int* payload_in;              // [B][cap] or null
+    int L, cap, k, max_keep;
+    float* out_boxes; float* out_scores; int* out_cat; int* out_count; int* payload_out;
+};
+__global__ __launch_bounds__(1024) void lvl_merge_kernel(const MergeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];        // [L][k]
+    __shared__ int scnt[8];
+    const int b = blockIdx.x;
+    if (threadIdx.x < a.L) scnt[threadIdx.x] = min(a.kept_count[b * a.L + threadIdx.x], a.k);
+    __syncthreads();
+    int total = 0;
+    for (int l = 0; l < a.L; ++l) total += scnt[l];
+    for (int i = threadIdx.x; i < a.L * a.k; i += 1024) {
+        const int l = i / a.k, j = i - l * a.k;
+        sk[i] = (j < scnt[l]) ? a.kept[((size_t)b * a.L + l) * a.k + j] : 0ull;
+    }
+    __syncthreads();
+    const int count = min(total, a.max_keep);
+    for (int i = threadIdx.x; i < a.L * a.k; i += 1024) {
+        const int l = i / a.k, j = i - l * a.k;
+        if (j >= scnt[l]) continue;
+        const unsigned long long kv = sk[i];
+        int rank = j;
+        for (int l2 = 0; l2 < a.L; ++l2) {
+            if (l2 == l) continue;
+            const unsigned long long* s = sk + l2 * a.k;
+            int lo = 0, hi = scnt[l2];                  // number of words > kv in a descending list
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s[mid] > kv) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank >= a.max_keep) continue;
+        const int pos = amp::sortkey_pos(kv);
+        const size_t o = (size_t)b * a.max_keep + rank;
+        reinterpret_cast<float4*>(a.out_boxes)[o] = reinterpret_cast<const float4*>(a.boxes)[(size_t)b * a.cap + pos];
+        a.out_scores[o] = amp::ord2f((uint32_t)(kv >> 32));
+        a.out_cat[o] = amp::sortkey_cat(kv);
+        if (a.payload_out) a.payload_out[o] = a.payload_in ? a.payload_in[(size_t)b * a.cap + pos] : -1;
+    }
+    for (int r = count + threadIdx.x; r < a.max_keep; r += 1024) {
+        const size_t o = (size_t)b * a.max_keep + r;
+        reinterpret_cast<float4*>(a.out_boxes)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.out_scores[o] = 0.f;
+        a.out_cat[o] = -1;
+        if (a.payload_out) a.payload_out[o] = -1;
+    }
+    if (threadIdx.x == 0) a.out_count[b] = count;
+}
+
 }  // namespace
 
 extern "C" int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const int* cats, const int* counts, float thresh,
@@ -153,6 +355,48 @@ extern "C" int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const i
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.W, a.W, B), dim3(64), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, ctx->stream, a, max_keep, keep_idx, keep_count);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+extern "C" size_t amp_rpn_nms_scratch_words(int B, int L, int k) {
+    const size_t nchk = (size_t)amp::cdiv(k, 64);
+    return (size_t)B * L * (nchk * nchk * 64 + (size_t)k + 1);
+}
+
+extern "C" int amp_rpn_nms_levels(amp_ctx* ctx, int B, int L, int k, int cap, const float* cand_boxes, const unsigned long long* cand_keys,
+                                  const int* sel_count, float thresh, int max_keep, unsigned long long* scratch, float* prop_boxes,
+                                  float* prop_scores, int* prop_lvl, int* prop_count, const int* payload_in, int* payload_out) {
+    AMP_REQUIRE(ctx && cand_boxes && cand_keys && sel_count && scratch && prop_boxes && prop_scores && prop_lvl && prop_count,
+                "amp_rpn_nms_levels: null argument");
+    AMP_REQUIRE(B >= 1 && L >= 1 && L <= 8 && k >= 1 && k <= 4096 && cap >= L * k && max_keep >= 1,
+                "amp_rpn_nms_levels: need 1..8 levels, k=%d in [1,4096], cap >= L*k", k);
+    AMP_REQUIRE(thresh >= 0.f, "amp_rpn_nms_levels: threshold must not be negative");
+    LvlArgs a;
+    a.boxes = cand_boxes; a.keys = cand_keys; a.sel_count = sel_count;
+    a.L = L; a.cap = cap; a.k = k; a.nchk = amp::cdiv(k, 64); a.thresh = thresh; a.max_keep = max_keep;
+    const size_t mt_words = (size_t)B * L * a.nchk * a.nchk * 64;
+    a.mt = scratch;
+    a.kept = scratch + mt_words;
+    a.kept_count = reinterpret_cast<int*>(a.kept + (size_t)B * L * k);
+    hipLaunchKernelGGL(lvl_mask_kernel, dim3(a.nchk, a.nchk, B * L), dim3(64), 0, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    const size_t smem = (size_t)LVL_SB * LVL_SB * 64 * sizeof(unsigned long long);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(lvl_scan_kernel, dim3(B * L), dim3(1024), smem, ctx->stream, a);
+    AMP_HIP_CHECK(hipGetLastError());
+    MergeArgs g;
+    g.kept = a.kept; g.kept_count = a.kept_count; g.boxes = cand_boxes; g.payload_in = payload_in;
+    g.L = L; g.cap = cap; g.k = k; g.max_keep = max_keep;
+    g.out_boxes = prop_boxes; g.out_scores = prop_scores; g.out_cat = prop_lvl; g.out_count = prop_count; g.payload_out = payload_out;
+    const size_t msmem = (size_t)L * k * sizeof(unsigned long long);
+    AMP_REQUIRE(msmem <= 150 * 1024, "amp_rpn_nms_levels: L*k=%d survivors do not fit the merge's LDS", L * k);
+    AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lvl_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msmem));
+    hipLaunchKernelGGL(lvl_merge_kernel, dim3(B), dim3(1024), msmem, ctx->stream, g);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -217,6 +217,21 @@ def nms(ctx, boxes, cats, counts, thresh, max_keep):
     return keep, kc
 
 
+def rpn_nms_levels(ctx, cand_boxes, cand_keys, sel_count, k, thresh, max_keep, payload=None):
+    """Per-level NMS of amp_rpn_decode's candidates + merge: (boxes [B,max_keep,4], logits, levels, count [B], payload or None)."""
+    B, cap, _ = cand_boxes.shape
+    L = sel_count.shape[1]
+    dev = cand_boxes.device
+    scratch = _u64(lib().amp_rpn_nms_scratch_words(B, L, k), device=dev)
+    pb, ps = torch.empty((B, max_keep, 4), device=dev), torch.empty((B, max_keep), device=dev)
+    pl, pc = _i32(B, max_keep, device=dev), _i32(B, device=dev)
+    po = _i32(B, max_keep, device=dev) if payload is not None else None
+    check(lib().amp_rpn_nms_levels(ctx.handle, B, L, k, cap, ptr(cand_boxes), ptr(cand_keys), ptr(sel_count), float(thresh), max_keep,
+                                   ptr(scratch), ptr(pb), ptr(ps), ptr(pl), ptr(pc), ptr(payload) if payload is not None else None,
+                                   ptr(po) if po is not None else None), "amp_rpn_nms_levels")
+    return pb, ps, pl, pc, po
+
+
 def make_fpn_feats(feats, strides=(4, 8, 16, 32)):
     f = _lib.FpnFeats()
     for i, t in enumerate(feats):

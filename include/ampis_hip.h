@@ -239,6 +239,18 @@ int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned
 int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const int* cats, const int* counts, float thresh,
             int max_keep, unsigned long long* mask_scratch, int* keep_idx, int* keep_count);
 
+/* Stage a12, second half of find_top_rpn_proposals (detectron2 proposal_utils.py: batched_nms(boxes, scores, lvl, nms_thresh)[:post_nms_topk]):
+ * the decoded candidates of amp_rpn_decode (level l of image b at [off, off + sel_count[b][l]) of its `cap` slots, each level in
+ * descending order; sort word 0 = invalid) are suppressed PER LEVEL and the survivors of the L levels merged by sort word: the first
+ * max_keep per image with boxes / logits / levels (/ payload_in[b][slot] -> payload_out), the remaining rows zero / -1 as
+ * amp_gather_dets leaves them.  Identical to amp_sort_gather + amp_nms(cats = level) + amp_gather_dets on the same candidates.
+ * scratch: amp_rpn_nms_scratch_words(B, L, k) u64. */
+size_t amp_rpn_nms_scratch_words(int B, int L, int k);
+int amp_rpn_nms_levels(amp_ctx* ctx, int B, int L, int k, int cap, const float* cand_boxes, const unsigned long long* cand_keys,
+                       const int* sel_count, float thresh, int max_keep, unsigned long long* scratch, float* prop_boxes,
+                       float* prop_scores, int* prop_lvl, int* prop_count, const int* payload_in /* [B,cap] or NULL */,
+                       int* payload_out /* [B,max_keep] or NULL */);
+
 /* Stages a13 / a16: RoIAlign (aligned, sampling_ratio 0) with FPN level assignment ------------- */
 typedef struct amp_fpn_feats {
     const float* feat[4];      /* p2..p5, NHWC [B,h,w,C] */
