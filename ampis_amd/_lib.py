@@ -126,6 +126,7 @@ def _declare(L):
         "amp_rpn_decode": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, i, vp, vp, vp], i),
         "amp_rpn_decode_sized": ([vp, C.POINTER(RpnLevels), i, i, vp, vp, vp, i, i, vp, i, vp, vp, vp], i),
         "amp_sort_gather": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
+        "amp_sort_gather_n": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_nms": ([vp, i, i, vp, vp, vp, f, i, vp, vp, vp], i),
         "amp_rpn_nms_scratch_words": ([i, i, i], C.c_size_t),
         "amp_rpn_nms_levels": ([vp, i, i, i, i, vp, vp, vp, f, i, vp, vp, vp, vp, vp, vp, vp], i),

@@ -563,7 +563,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         auto detect = [&](const float* thresh_img) -> int {      // candidates above the score floor -> order -> per-class NMS -> first D
             AMP_TRY(amp::box_candidates_run(ctx, box_pred, ld_box, prop_boxes, prop_count, B, Rcap, K, c.bbox_reg_weights, c.score_thresh,
                                             H, W, T.img_hw, thresh_img, dense_boxes, bkeys, ccap, bcount, m->d_flags + 0));
-            AMP_TRY(amp_sort_gather(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr));
+            AMP_TRY(amp_sort_gather_n(ctx, B, ccap, Rcap * K, bkeys, dense_boxes, bs_boxes, bs_scores, bs_cats, bs_count, nullptr, nullptr, nullptr, bcount));
             AMP_TRY(amp_nms(ctx, B, ccap, bs_boxes, bs_cats, bs_count, c.nms_thresh, D, bnms_mask, bkeep_idx, det_count));
             return amp_gather_dets(ctx, B, ccap, D, bs_boxes, bs_scores, bs_cats, bkeep_idx, det_count, det_boxes, det_scores, det_classes, nullptr, nullptr);
         };

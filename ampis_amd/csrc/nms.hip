@@ -217,6 +217,7 @@ __global__ __launch_bounds__(1024) void lvl_scan_kernel(const LvlArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smt[];     // [LVL_SB][LVL_SB * 64]
     __shared__ unsigned long long skeep[64];                                       // kept word per chunk (nchk <= 64)
     __shared__ unsigned long long spre[LVL_SB];                                    // removed before the super-block's own scan
+    __shared__ unsigned long long skey[LVL_SB * 64];                               // the super-block's sort words (the scan must not wait on global loads)
     const int seg = blockIdx.x;
     const int b = seg / a.L, lvl = seg - b * a.L;
     const int n = min(a.sel_count[seg], a.k);
@@ -248,7 +249,13 @@ __global__ __launch_bounds__(1024) void lvl_scan_kernel(const LvlArgs a) {
                 const unsigned long long key = (j < n) ? keys[j] : 0ull;
                 const unsigned long long pre = __ballot(acc != 0ull || key == 0ull);
                 if (lane == 0) spre[wave] = pre;
-                for (int rc = sb0; rc <= c; ++rc) smt[(rc - sb0) * (LVL_SB * 64) + wave * 64 + lane] = mt[(size_t)rc * rowlen + j];
+                skey[wave * 64 + lane] = key;
+                unsigned long long tv[LVL_SB];              // all loads of the triangle's column in flight, then the LDS writes
+#pragma unroll
+                for (int u = 0; u < LVL_SB; ++u) tv[u] = (u <= wave) ? mt[(size_t)(sb0 + u) * rowlen + j] : 0ull;
+#pragma unroll
+                for (int u = 0; u < LVL_SB; ++u)
+                    if (u <= wave) smt[u * (LVL_SB * 64) + wave * 64 + lane] = tv[u];
             }
         }
         __syncthreads();
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(1024) void lvl_scan_kernel(const LvlArgs a) {
                 if (lane == 0) skeep[c] = keep;
                 if ((keep >> lane) & 1ull) {
                     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                    out[nkept + __popcll(keep & below)] = keys[c * 64 + lane];        // nkept <= n <= k
+                    out[nkept + __popcll(keep & below)] = skey[cc * 64 + lane];       // nkept <= n <= k
                 }
                 nkept += __popcll(keep);
             }

@@ -626,11 +626,160 @@ __global__ __launch_bounds__(256) void roi_align_split_kernel(const RoiArgs a) {
     }
 }
 
+
+// roi_align_split_kernel with the sample parameters out of the inner loops.  There every lane evaluates every sample's coordinate -- two
+// IEEE divisions, the edge rules, ~40 VALU instructions on values that are the same for the 32 lanes of a bin -- next to 32 instructions of
+// interpolation; here lane j of a half-wave evaluates sample ROW j and sample COLUMN j of its bin once (the same operations in the same
+// order: bit-identical), leaves them in a wave-private LDS table and the loops fetch a sample's {lo, hi, l, h} with one broadcast 16-B
+// read.  The split rows are decoded with one fused multiply-add per value (lo' * 2^-11 is exact, so fma(lo', 2^-11, hi) rounds once exactly
+// as the separate product and sum do; on gfx950 it is v_fma_mix_f32 straight from the f16 halves, one instruction instead of three).
+// Sampling grids beyond 32 x 32 per bin keep the in-loop evaluation.
+typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float fma_mix_lo(unsigned int l, unsigned int h) {      // fma((float)l.lo16, 2^-11, (float)h.lo16)
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(l), "v"(1.0f / 2048.0f), "v"(h));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned int l, unsigned int h) {      // ... of the high halves
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(l), "v"(1.0f / 2048.0f), "v"(h));
+    return d;
+}
+__device__ __forceinline__ void load_tap8_fma(const float* row, int c8, f32x2r (&v)[4]) {
+    const int ch = 8 * c8;
+    const char* base = reinterpret_cast<const char*>(row) + (ch >> 5) * 128 + (ch & 31) * 2;
+    const u32x4r h = *reinterpret_cast<const u32x4r*>(base);
+    const u32x4r l = *reinterpret_cast<const u32x4r*>(base + 64);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        v[p][0] = fma_mix_lo(l[p], h[p]);
+        v[p][1] = fma_mix_hi(l[p], h[p]);
+    }
+}
+
+__device__ __forceinline__ RoiTab sample_param(float start, int pidx, float binsz, int i, int g, int extent) {
+    float v = __fadd_rn(__fadd_rn(start, __fmul_rn((float)pidx, binsz)), __fdiv_rn(__fmul_rn(__fadd_rn((float)i, 0.5f), binsz), (float)g));
+    const bool bad = (v < -1.0f) || (v > (float)extent);
+    if (v <= 0.f) v = 0.f;
+    int lo = (int)v, hi;
+    if (lo >= extent - 1) { lo = hi = extent - 1; v = (float)lo; } else { hi = lo + 1; }
+    RoiTab t;
+    t.l = __fsub_rn(v, (float)lo); t.h = __fsub_rn(1.0f, t.l); t.lo = bad ? -1 : lo; t.hi = hi;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void roi_align_split_tab_kernel(const RoiArgs a) {
+    __shared__ __attribute__((aligned(16))) RoiTab tabs[4][2][64];          // [wave][rows | columns][half * 32 + sample]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int half = lane >> 5, c8 = lane & 31;                 // C == 256: 32 lanes x 8 channels
+    RoiTab* rowtab = &tabs[wave][0][half * 32];
+    RoiTab* coltab = &tabs[wave][1][half * 32];
+    const int nvalid = a.roi_count ? min(*a.roi_count, a.R) : a.R;
+    const long long nbins = (long long)nvalid * a.P * a.P;
+    const int PP = a.P * a.P;
+    const long long npairs_x = a.order ? ((long long)a.xlen[blockIdx.x & 7] * PP + 1) / 2 : 0;
+    const long long pair0 = a.order ? (long long)(blockIdx.x >> 3) * 4 + wave : (long long)blockIdx.x * 4 + wave;
+    const long long pstep = a.order ? (long long)(gridDim.x >> 3) * 4 : (long long)gridDim.x * 4;
+    for (long long pair = pair0; a.order ? pair < npairs_x : pair * 2 < nbins; pair += pstep) {
+        long long bin = pair * 2 + half;
+        if (a.order) {
+            const long long u = bin;
+            const int slot = (int)(u / PP);
+            if (slot >= a.xlen[blockIdx.x & 7]) continue;
+            bin = (long long)a.order[(blockIdx.x & 7) * a.xstride + slot] * PP + (u - (long long)slot * PP);
+        }
+        if (bin >= nbins) continue;
+        const int pw = (int)(bin % a.P);
+        const int ph = (int)((bin / a.P) % a.P);
+        const int r = (int)(bin / (a.P * a.P));
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        if (a.level_out && ph == 0 && pw == 0 && c8 == 0) a.level_out[r] = lv;
+        const int b = a.batch_idx ? a.batch_idx[r] : 0;
+        const int H = a.fh[lv], W = a.fw[lv];
+        const float sc = a.scale[lv];
+        const float sw = __fsub_rn(__fmul_rn(x1, sc), 0.5f);
+        const float sh = __fsub_rn(__fmul_rn(y1, sc), 0.5f);
+        const float ew = __fsub_rn(__fmul_rn(x2, sc), 0.5f);
+        const float eh = __fsub_rn(__fmul_rn(y2, sc), 0.5f);
+        const float rw = __fsub_rn(ew, sw), rh = __fsub_rn(eh, sh);
+        const float bh = __fdiv_rn(rh, (float)a.P), bw = __fdiv_rn(rw, (float)a.P);
+        const int gh = (int)ceilf(__fdiv_rn(rh, (float)a.P));
+        const int gw = (int)ceilf(__fdiv_rn(rw, (float)a.P));
+        const float count = (float)max(gh * gw, 1);
+        const float* fb = a.feat[lv] + (size_t)b * H * W * a.C;
+        const bool tab = gh <= 32 && gw <= 32;
+        if (tab) {          // lane c8 of the half: sample row c8 and sample column c8 (lanes beyond the grid write entries nobody reads)
+            rowtab[c8] = sample_param(sh, ph, bh, c8, gh, H);
+            coltab[c8] = sample_param(sw, pw, bw, c8, gw, W);
+        }
+        f32x2r acc[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = f32x2r{0.f, 0.f};
+        for (int iy = 0; iy < gh; ++iy) {
+            const RoiTab ty = tab ? rowtab[iy] : sample_param(sh, ph, bh, iy, gh, H);
+            if (ty.lo < 0) continue;
+            const float* frow_lo = fb + (size_t)ty.lo * W * a.C;
+            const float* frow_hi = fb + (size_t)ty.hi * W * a.C;
+            int cxlo = -2, cxhi = -2;
+            f32x2r v1[4], v2[4], v3[4], v4[4];
+            for (int ix = 0; ix < gw; ++ix) {
+                const RoiTab tx = tab ? coltab[ix] : sample_param(sw, pw, bw, ix, gw, W);
+                if (tx.lo < 0) continue;
+                const float w1 = __fmul_rn(ty.h, tx.h), w2 = __fmul_rn(ty.h, tx.l), w3 = __fmul_rn(ty.l, tx.h), w4 = __fmul_rn(ty.l, tx.l);
+                if (tx.lo == cxhi && tx.lo != cxlo) {               // advanced by one cell: the right column becomes the left one
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { v1[p] = v2[p]; v3[p] = v4[p]; }
+                    cxlo = tx.lo;
+                }
+                if (tx.lo != cxlo) {
+                    load_tap8_fma(frow_lo + (size_t)tx.lo * a.C, c8, v1);
+                    load_tap8_fma(frow_hi + (size_t)tx.lo * a.C, c8, v3);
+                    cxlo = tx.lo;
+                }
+                if (tx.hi != cxhi) {
+                    load_tap8_fma(frow_lo + (size_t)tx.hi * a.C, c8, v2);
+                    load_tap8_fma(frow_hi + (size_t)tx.hi * a.C, c8, v4);
+                    cxhi = tx.hi;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2r s2 = ((v1[p] * w1 + v2[p] * w2) + v3[p] * w3) + v4[p] * w4;
+                    acc[p] = acc[p] + s2;
+                }
+            }
+        }
+        float accs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accs[e] = __fdiv_rn(acc[e >> 1][e & 1], count);
+        float* orow = a.out + (size_t)bin * a.C;
+        if (a.out_split) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const _Float16 h = (_Float16)accs[e];
+                hi[e] = h;
+                lo[e] = (_Float16)((accs[e] - (float)h) * 2048.0f);
+            }
+            const int ch = 8 * c8;
+            char* base = reinterpret_cast<char*>(orow) + (ch >> 5) * 128 + (ch & 31) * 2;
+            *reinterpret_cast<f16x8*>(base) = hi;
+            *reinterpret_cast<f16x8*>(base + 64) = lo;
+        } else {
+            reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{accs[0], accs[1], accs[2], accs[3]};
+            reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{accs[4], accs[5], accs[6], accs[7]};
+        }
+    }
+}
+
 }  // namespace
 
 static int g_roi_share = getenv("AMP_ROI_SHARE") ? atoi(getenv("AMP_ROI_SHARE")) : 1;
 static int g_roi_xcd = getenv("AMP_ROI_XCD") ? atoi(getenv("AMP_ROI_XCD")) : 0;      // EXPERIMENT: XCD-major RoI order (roi_order_kernel)
 extern "C" void amp_debug_set_roi_xcd(int v) { g_roi_xcd = v; }
+static int g_roi_tab = getenv("AMP_ROI_TAB") ? atoi(getenv("AMP_ROI_TAB")) : 1;      // 1: sample tables in LDS (roi_align_split_tab_kernel); 0: roi_align_split_kernel
+extern "C" void amp_debug_set_roi_tab(int v) { g_roi_tab = v; }
 static int g_roi_lanes = getenv("AMP_ROI_LANES") ? atoi(getenv("AMP_ROI_LANES")) : 1;   // 1: lane-parallel sample parameters (default); 0: the reference kernel (every lane computes every sample's parameters); 3: one workgroup per bin row, cells staged in LDS (slower, see roi_align_rows_kernel)
 extern "C" void amp_debug_set_roi_lanes(int v) { g_roi_lanes = v; }
 
@@ -695,7 +844,8 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
             if (per_x > 8192) per_x = 8192;
             g2 = per_x * 8;
         }
-        hipLaunchKernelGGL(roi_align_split_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
+        if (g_roi_tab) hipLaunchKernelGGL(roi_align_split_tab_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(roi_align_split_kernel, dim3((unsigned)g2), dim3(256), 0, ctx->stream, a);
     } else if (in_split) hipLaunchKernelGGL(roi_align_kernel<true>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     else if (g_roi_lanes) hipLaunchKernelGGL(roi_align_lanes_kernel<0>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);
     else hipLaunchKernelGGL(roi_align_kernel<false>, dim3((unsigned)g), dim3(256), 0, ctx->stream, a);

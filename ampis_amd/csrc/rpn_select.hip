@@ -179,17 +179,26 @@ __global__ AMP_NO_PK void rpn_decode_kernel(const DecodeArgs a, int B) {
 // Per image: sort cap (<= 8192) 64-bit keys descending; emit sorted boxes / scores / categories and the valid count.
 constexpr int SORT_THREADS = 1024;
 __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(const unsigned long long* sortkey, const float* boxes_in,
-                                                                  int cap, int box_stride, int N, float* boxes_out,
+                                                                  int cap, int box_stride, int Nmax, float* boxes_out,
                                                                   float* score_out, int* cat_out, int* count_out,
-                                                                  int* pos_out, const int* payload_in, int* payload_out) {
+                                                                  int* pos_out, const int* payload_in, int* payload_out, const int* n_used) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];
     const int b = blockIdx.x;
+    int N = Nmax;
+    // n_used[b]: the words of image b sit in its first n_used slots and the rest are zero (amp_box_candidates' compacted list): sort the
+    // smallest power of two that holds them instead of all `cap` slots
+    if (n_used) {
+        const int nv = min(n_used[b], cap);
+        int nn = 64;
+        while (nn < nv) nn <<= 1;
+        N = min(N, nn);
+    }
     for (int i = threadIdx.x; i < N; i += SORT_THREADS) skeys[i] = (i < cap) ? sortkey[(size_t)b * cap + i] : 0ull;
     __syncthreads();
     amp::bitonic_desc<SORT_THREADS>(skeys, N);
     int cnt = 0;
     for (int i = threadIdx.x; i < cap; i += SORT_THREADS) {
-        const unsigned long long kv = skeys[i];
+        const unsigned long long kv = (i < N) ? skeys[i] : 0ull;
         float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, sc = 0.f;
         int cat = -1, pos = -1;
         if (kv != 0ull) {
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_gather_kernel(const unsigne
         if (payload_out) payload_out[(size_t)b * cap + i] = (pos >= 0 && payload_in) ? payload_in[(size_t)b * box_stride + pos] : -1;
     }
     // block reduce of the valid count (counter lives behind the keys: keep all LDS in the one dynamic region)
-    int* s_cnt = reinterpret_cast<int*>(skeys + N);
+    int* s_cnt = reinterpret_cast<int*>(skeys + Nmax);
     __syncthreads();
     if (threadIdx.x == 0) *s_cnt = 0;
     __syncthreads();
@@ -318,6 +327,13 @@ int amp_rpn_decode_sized(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, c
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
                     float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out, const int* payload_in,
                     int* payload_out) {
+    return amp_sort_gather_n(ctx, B, cap, box_stride, sortkey, boxes_in, boxes_out, score_out, cat_out, count_out, pos_out, payload_in,
+                             payload_out, nullptr);
+}
+
+int amp_sort_gather_n(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
+                      float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out, const int* payload_in,
+                      int* payload_out, const int* n_used) {
     AMP_REQUIRE(ctx && sortkey && boxes_in && boxes_out && score_out && cat_out && count_out, "amp_sort_gather: null argument");
     AMP_REQUIRE(B >= 1 && cap >= 1 && cap <= 16384, "amp_sort_gather: cap=%d out of range [1,16384]", cap);
     int N = 64;
@@ -326,7 +342,7 @@ int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned
     AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_gather_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(sort_gather_kernel, dim3(B), dim3(SORT_THREADS), smem, ctx->stream, sortkey, boxes_in, cap, box_stride, N,
-                       boxes_out, score_out, cat_out, count_out, pos_out, payload_in, payload_out);
+                       boxes_out, score_out, cat_out, count_out, pos_out, payload_in, payload_out, n_used);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

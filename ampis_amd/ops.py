@@ -195,13 +195,13 @@ def rpn_decode(ctx, preds, shapes, B, k, sel_idx, sel_logit, sel_count, img_h, i
     return boxes, keys
 
 
-def sort_gather(ctx, keys, boxes_in, box_stride=None):
+def sort_gather(ctx, keys, boxes_in, box_stride=None, n_used=None):
     B, cap = keys.shape
     dev = keys.device
     sb, ss, sc, cnt, pos = torch.empty((B, cap, 4), device=dev), torch.empty((B, cap), device=dev), _i32(B, cap, device=dev), \
         _i32(B, device=dev), _i32(B, cap, device=dev)
-    check(lib().amp_sort_gather(ctx.handle, B, cap, box_stride or boxes_in.shape[1], ptr(keys), ptr(boxes_in), ptr(sb), ptr(ss),
-                                ptr(sc), ptr(cnt), ptr(pos), None, None), "amp_sort_gather")
+    check(lib().amp_sort_gather_n(ctx.handle, B, cap, box_stride or boxes_in.shape[1], ptr(keys), ptr(boxes_in), ptr(sb), ptr(ss),
+                                  ptr(sc), ptr(cnt), ptr(pos), None, None, ptr(n_used) if n_used is not None else None), "amp_sort_gather")
     return sb, ss, sc, cnt, pos
 
 

@@ -233,6 +233,11 @@ int amp_rpn_decode_sized(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, c
 int amp_sort_gather(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
                     float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out,
                     const int* payload_in /* [B,box_stride] or NULL */, int* payload_out /* [B,cap] or NULL */);
+/* the same with a hint: n_used[b] (device, may exceed cap) = the sort words of image b are its first n_used[b] slots and the rest are 0
+ * (the compacted candidate list of amp_box_candidates): only the smallest power of two that holds them is sorted. NULL: all cap slots. */
+int amp_sort_gather_n(amp_ctx* ctx, int B, int cap, int box_stride, const unsigned long long* sortkey, const float* boxes_in,
+                      float* boxes_out, float* score_out, int* cat_out, int* count_out, int* pos_out,
+                      const int* payload_in, int* payload_out, const int* n_used);
 
 /* Stages a12 / a15: batched greedy NMS on score-sorted boxes (cap <= 16384 per image) ---------- */
 /* mask_scratch: [B*cap*ceil(cap/64)] u64. keep_idx [B,max_keep] (positions, ascending), keep_count [B]. */

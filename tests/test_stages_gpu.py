@@ -166,8 +166,12 @@ def test_box_inference_chain(gpu_ctx):
                                                torch.from_numpy(counts).to(DEV), K, cfg.score_thresh, H, W)
     sb, ss, sc, scount, _ = ops.sort_gather(gpu_ctx, keys, dense, box_stride=Rcap * K)
     keep, kc = ops.nms(gpu_ctx, sb, sc, scount, cfg.nms_thresh, D)
+    # the model's form: only the power of two that holds the compacted candidates is sorted (amp_sort_gather_n) -- same outputs
+    sb2, ss2, sc2, scount2, pos2 = ops.sort_gather(gpu_ctx, keys, dense, box_stride=Rcap * K, n_used=cnt)
     torch.cuda.synchronize()
     assert int(ovf.item()) == 0
+    assert int(cnt.max().item()) < keys.shape[1] // 2            # the hint does shrink the sort
+    assert torch.equal(sb, sb2) and torch.equal(ss, ss2) and torch.equal(sc, sc2) and torch.equal(scount, scount2)
     for b in range(B):
         n = counts[b]
         rows = torch.from_numpy(pred[b * Rcap: b * Rcap + n])

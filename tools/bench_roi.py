@@ -63,3 +63,17 @@ for P, n in ((7, 1000), (14, 200)):
         torch.cuda.synchronize()
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), "XCD-major order changed the result"
 L.amp_debug_set_roi_xcd(0)
+
+# sample tables in LDS + fma_mix decode (roi_align_split_tab_kernel, AMP_ROI_TAB / amp_debug_set_roi_tab) against roi_align_split_kernel
+for P, n in ((7, 1000), (14, 200)):
+    rois, bidx = rois_like_proposals(n)
+    same = rois.clone(); same[:] = torch.tensor([100.0, 100.0, 174.0, 174.0])
+    for nm, R_, bi in (("proposal-like boxes", rois, bidx), ("every box the same 74 px box", same, bidx * 0)):
+        outs = []
+        for mode in (0, 1, 0, 1):
+            L.amp_debug_set_roi_tab(mode)
+            run(f"split maps, {nm}, sample tables = {mode}", R_, bi, P, 3, fs)
+            outs.append(ops.roi_align(ctx, fs, R_, bi, P, fmt=3)[0].clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), "the table kernel changed the result"
+L.amp_debug_set_roi_tab(1)
