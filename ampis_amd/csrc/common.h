@@ -158,7 +158,10 @@ int weight_jobs_run(amp_ctx* ctx, const WeightJob* jobs_dev, const void* chunks_
 // train_bwd.hip: amp_sgd_update over a device table of chunks (low 32 bits: offset in floats, a multiple of 4; high 32: length) of the arenas p / g / v
 int sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchunks, float* p, const float* g, float* v, float lr,
                    float momentum, float weight_decay, float grad_scale);
-int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);   // pointwise.hip: y_split = 1 writes split rows
+int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);
+// conv.hip: stem conv + ReLU + max-pool fused (AMP_CONV_F16X3, pre-split weights); returns 1 when it does not apply (caller: conv, then maxpool_run)
+int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const float* w_split, const float* scale, const float* shift, float* pool,
+                  int pool_split);   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
 // only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)
 }

@@ -1616,6 +1616,188 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     else conv_epilogue_fast16<WTM, WTN, MB, NB, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
+// stem_pool_f16x3_kernel: the 7x7 stride-2 stem (conv_f16x3_kernel<64, ., STEM>) and the 3x3 stride-2 max-pool behind it in ONE kernel.
+// Separately the stem writes its [B, H/2, W/2, 64] fp32 output (537 MB for a batch of 8 at 1024^2) and the pool reads it back: 1.07 GB
+// through HBM and a launch for a tensor nobody else reads.  Here a workgroup owns a tile of SP_PH x SP_PW pooled pixels: its M tile is
+// the (2 SP_PH + 1) x (2 SP_PW + 1) = 17 x 15 = 255 convolution outputs under that tile (256 rows of A, 8 waves as 4 x 2 wave tiles of
+// 64 x 32), the accumulators take scale / shift / ReLU as in conv_epilogue_rows, land in LDS as the patch, and 448 threads take the
+// maximum of the nine patch pixels of a pooled pixel, 8 channels each, and write it -- in the split hi | lo' row format when the trunk
+// runs on it.  Every convolution output is the same sum in the same order as in the unfused kernel (7 K-steps of one kernel row each), so the
+// pooled tensor is bit-identical; the halo costs 256 / 224 = 1.14 x the MFMA work of the stem.
+constexpr int SP_PH = 8, SP_PW = 7, SP_CH = 2 * SP_PH + 1, SP_CW = 2 * SP_PW + 1;      // pooled tile, conv patch
+struct StemPoolArgs {
+    float* pool;            // [B][Hq][Wq][64] (fp32 rows or split rows)
+    int Hq, Wq;             // pooled size
+    int tiles_x, tiles_y;
+    int pool_split;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_f16x3_kernel(const ConvArgs a, const StemPoolArgs sp, const unsigned int x_bytes,
+                                                                 const unsigned int w_bytes) {
+    constexpr int BM = 256, BN = 64;
+    constexpr int WTM = 64, WTN = 32, NWN = 2;      // 8 waves: 4 x 2 wave tiles
+    constexpr int RPT = 2;                // activation rows per lane: 256 rows x 4 lanes per row over 512 threads
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int SLD = BN + 4;           // patch row in LDS: 64 channels + pad
+    static_assert(2 * TILE_FLOATS >= BM * SLD, "the patch reuses the operand buffers");
+    static_assert(SP_CH * SP_CW <= BM, "the patch is the M tile");
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    const int tx = blockIdx.x % sp.tiles_x;
+    const int tyb = blockIdx.x / sp.tiles_x;
+    const int ty = tyb % sp.tiles_y, b = tyb / sp.tiles_y;
+    const int oy_first = 2 * ty * SP_PH - 1, ox_first = 2 * tx * SP_PW - 1;      // conv pixel of patch row 0 / column 0
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+
+    // ---- A: lane = 4 * (row in a 16-row group) + kg; a lane owns 8 consecutive k (two taps x 4 channels) of rows ra[0], ra[1] ----
+    const int arow = lane >> 2, akg = lane & 3;
+    int a_iy0[RPT], a_ix0[RPT], a_row[RPT];
+    const int a_pb = b * a.H * a.W;
+#pragma unroll
+    for (int p = 0; p < RPT; ++p) {
+        const int r = p * 128 + wave * 16 + arow;
+        a_row[p] = r;
+        const int pr = r / SP_CW, pc = r - pr * SP_CW;
+        const int oy = oy_first + pr, ox = ox_first + pc;
+        const bool v = pr < SP_CH && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+        a_iy0[p] = v ? oy * a.stride - a.pad : -(1 << 28);
+        a_ix0[p] = v ? ox * a.stride - a.pad : 0;
+    }
+    // ---- B (split weights): LDS-DMA, 8 rows x 128 B per wave-instruction, source chunk XOR-swizzled ----
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned int b_voff;
+    {
+        const int r = wave * 8 + srow;
+        b_voff = (r < a.Cout) ? (unsigned int)(((size_t)r * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+    int kstep = 0;
+    u32x4 ra[RPT][2];
+    auto fetch = [&](int buf) {                 // A(kstep) -> registers, B(kstep) -> LDS[buf]
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) {
+            const int iy = a_iy0[p] + kstep;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int ix = a_ix0[p] + 2 * akg + h;
+                const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned int vo = v ? (unsigned int)((a_pb + iy * a.W + ix) * 16) : OOB_VOFF;
+                ra[p][h] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)vo, 0, 0);
+            }
+        }
+        float* Bs = lds + buf * TILE_FLOATS + BM * BK;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * 8) * BK), 16, (int)b_voff,
+                                                 kstep * (BK * 4), 0, 0);
+        ++kstep;
+    };
+    auto commit = [&](int buf) {                // split the fetched A registers into LDS[buf]
+        float* As = lds + buf * TILE_FLOATS;
+#pragma unroll
+        for (int p = 0; p < RPT; ++p) {
+            f16x8 hi, lo;
+            split8<false>(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo, 1.0f);
+            const int r = a_row[p], sw = (r >> 1) & 7;
+            *reinterpret_cast<f16x8*>(As + r * BK + 4 * (akg ^ sw)) = hi;
+            *reinterpret_cast<f16x8*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
+        }
+    };
+
+    constexpr int MB = WTM / 16, NB = WTN / 16;
+    f32x4 acc[MB][NB], acx[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+
+    fetch(0);
+    commit(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // B(0) has landed
+    __syncthreads();
+    if (a.nsteps > 1) fetch(1);
+    for (int step = 0; step < a.nsteps; ++step) {
+        const int cur = step & 1;
+        f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (wm * WTM + l15) * BK, lds + cur * TILE_FLOATS + BM * BK + (wn * WTN + l15) * BK,
+                             fo16_hi, fo16_lo, acc, acx);
+        if (step + 1 < a.nsteps) commit(cur ^ 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // the weight DMA into LDS[cur^1] has landed (see conv_f16x3_kernel)
+        __syncthreads();
+        if (step + 2 < a.nsteps) fetch(cur);
+    }
+
+    // ---- the patch: fold the cross terms, scale / shift / ReLU (conv_epilogue_rows' arithmetic), -1 for pixels outside the image ----
+    float* patch = lds;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = wn * WTN + j * 16 + l15;
+        const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f, sh = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = wm * WTM + i * 16 + 4 * lq + e;
+                const int pr = r / SP_CW, pc = r - pr * SP_CW;
+                const bool v = pr < SP_CH && (unsigned)(oy_first + pr) < (unsigned)a.Ho && (unsigned)(ox_first + pc) < (unsigned)a.Wo;
+                const float s = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                bad = bad || !(fabsf(s) <= 3.0e38f);
+                float t = __fadd_rn(__fmul_rn(s, sc), sh);
+                if (a.relu) t = fmaxf(t, 0.f);
+                patch[r * SLD + n] = v ? t : -1.0f;
+            }
+    }
+    if (bad) atomicOr(a.range_flag, 1);
+    __syncthreads();
+
+    // ---- pool: thread = (pooled pixel q, 8 channels) ----
+    if (tid < SP_PH * SP_PW * 8) {
+        const int q = tid >> 3, c8 = tid & 7;
+        const int ppy = q / SP_PW, ppx = q - ppy * SP_PW;
+        const int py = ty * SP_PH + ppy, px = tx * SP_PW + ppx;
+        if (py < sp.Hq && px < sp.Wq) {
+            float m[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = -1.0f;         // (the centre of a window is always inside the image and ReLU output is >= 0)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* src = patch + ((2 * ppy + dy) * SP_CW + 2 * ppx + dx) * SLD + 8 * c8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { m[c] = fmaxf(m[c], v0[c]); m[4 + c] = fmaxf(m[4 + c], v1[c]); }
+                }
+            float* orow = sp.pool + ((size_t)(b * sp.Hq + py) * sp.Wq + px) * 64;
+            if (sp.pool_split) {
+                f16x8 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const _Float16 h = (_Float16)m[c];
+                    hi[c] = h;
+                    lo[c] = (_Float16)((m[c] - (float)h) * LO_SCALE);
+                }
+                const int ch = 8 * c8;
+                char* base = reinterpret_cast<char*>(orow) + (ch >> 5) * 128 + (ch & 31) * 2;
+                *reinterpret_cast<f16x8*>(base) = hi;
+                *reinterpret_cast<f16x8*>(base + 64) = lo;
+            } else {
+                reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{m[0], m[1], m[2], m[3]};
+                reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{m[4], m[5], m[6], m[7]};
+            }
+        }
+    }
+}
+
 // w [rows][K] fp32 -> split rows: per K-step of 32, 32 f16 hi halves (64 B) then 32 f16 lo' halves (64 B)
 __global__ void split_weights_kernel(const float* __restrict__ w, size_t rows, int K, unsigned int* __restrict__ out) {
     const size_t total = rows * (size_t)(K / 2);     // one thread per pair of consecutive k
@@ -1977,6 +2159,48 @@ extern "C" int amp_group_expand_weights(amp_ctx* ctx, const float* w, int Cout, 
     hipLaunchKernelGGL(group_expand_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream, w, Cout,
                        KH * KW, cpg, w_win);
     AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+static int g_stem_pool = getenv("AMP_NO_STEM_POOL") ? 0 : 1;      // EXPERIMENT switch: 0 = stem and pool as two kernels
+extern "C" void amp_debug_set_stem_pool(int v) { g_stem_pool = v; }
+// Stem (7x7 stride 2 on the [B,H,W,4] input, weights [64][7][8][4], ReLU) + max-pool 3x3 stride 2 pad 1 in one kernel: AMP_CONV_F16X3 with
+// pre-split weights only.  Returns 1 (nothing launched) when the fused form does not apply -- the caller runs the two kernels.
+int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const float* w_split, const float* scale, const float* shift,
+                       float* pool, int pool_split) {
+    if (!g_stem_pool || ctx->conv_mode != AMP_CONV_F16X3 || !w_split || g_conv_ablate != 0) return 1;
+    ConvArgs a = ConvArgs();
+    a.x = x; a.w = w_split; a.scale = scale; a.shift = shift;
+    a.B = B; a.H = H; a.W = W; a.Cin = 4; a.Cout = 64;
+    a.KH = 7; a.KW = 8; a.stride = 2; a.pad = 3;
+    a.Ho = (H + 2 * 3 - 7) / 2 + 1;
+    a.Wo = (W + 2 * 3 - 7) / 2 + 1;
+    a.cin_win = 4;
+    a.K = 7 * 8 * 4; a.nsteps = 7;
+    a.relu = 1;
+    a.in_scale = a.out_scale = 1.0f;
+    a.range_flag = ctx->d_conv_flag;
+    const size_t x_bytes = (size_t)B * H * W * 4 * sizeof(float), w_bytes = (size_t)64 * a.K * sizeof(float);
+    if (a.Ho < 1 || a.Wo < 1 || x_bytes >= (size_t)OOB_VOFF || (long long)B * H * W >= (1ll << 27)) return 1;
+    StemPoolArgs sp;
+    sp.pool = pool; sp.pool_split = pool_split;
+    sp.Hq = (a.Ho + 2 - 3) / 2 + 1; sp.Wq = (a.Wo + 2 - 3) / 2 + 1;
+    sp.tiles_y = amp::cdiv(sp.Hq, SP_PH); sp.tiles_x = amp::cdiv(sp.Wq, SP_PW);
+    amp_prof_rec* rec = nullptr;
+    if (ctx->prof_on) {
+        if (ctx->prof_used < ctx->prof_pool.size()) {
+            rec = &ctx->prof_pool[ctx->prof_used++];
+            rec->flops = 2.0 * (double)B * a.Ho * a.Wo * 64.0 * 7.0 * 8.0 * 4.0;   // useful work of the stem (as conv_run counts it), not the halo
+            rec->variant = 1;
+            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
+        } else {
+            ctx->prof_truncated = true;
+        }
+    }
+    hipLaunchKernelGGL(stem_pool_f16x3_kernel, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
+                       (unsigned int)x_bytes, (unsigned int)w_bytes);
+    AMP_HIP_CHECK(hipGetLastError());
+    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     return AMP_OK;
 }
 

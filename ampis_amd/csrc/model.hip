@@ -315,10 +315,20 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
 
     int h = Hp / 2, w = Wp / 2;
     AMP_ALLOC(stem, float, (size_t)B * h * w * 64);
-    if (!dry) AMP_TRY(launch_conv(m, CONV("backbone.bottom_up.stem.conv1"), x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
     const int h4 = (h + 2 - 3) / 2 + 1, w4 = (w + 2 - 3) / 2 + 1;
     AMP_ALLOC(pool, float, (size_t)B * h4 * w4 * 64);
-    if (!dry) AMP_TRY(amp::maxpool_run(ctx, stem, B, h, w, 64, pool, native_all ? 1 : 0));
+    if (!dry) {
+        // stem + max-pool in one kernel where that exists (f16x3 arithmetic, fresh split weights); the stem's own output is then never written
+        const ConvW& sw = CONV("backbone.bottom_up.stem.conv1");
+        int fused = 1;
+        if (sw.cin == 4 && sw.kw == 8 && sw.kh == 7 && sw.cout == 64 && !m->split_stale)
+            fused = amp::stem_pool_run(ctx, B, Hp, Wp, x0, sw.w_split, sw.scale, sw.shift, pool, native_all ? 1 : 0);
+        if (fused < 0) return fused;
+        if (fused == 1) {
+            AMP_TRY(launch_conv(m, sw, x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
+            AMP_TRY(amp::maxpool_run(ctx, stem, B, h, w, 64, pool, native_all ? 1 : 0));
+        }
+    }
     if (!dry) tap(m, "stem_pool", pool, native_all ? SPL : 0, {B, h4, w4, 64});
 
     float* cur = pool;

@@ -93,18 +93,21 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_k
         const unsigned int dlo = (unsigned int)(diag & 0xffffffffu), dhi = (unsigned int)(diag >> 32);
         const int nb = min(64, n - c * 64);
         const unsigned long long valid = (nb == 64) ? ~0ull : ((1ull << nb) - 1ull);
+        // wave-uniform scalar loop, in score order, over the alive boxes that overlap another alive box of this chunk: one still alive at
+        // its turn is kept and removes its row; the other alive boxes are kept whatever the order
         unsigned long long cur = ~removed & valid;
-        unsigned long long keep = 0ull;
-        while (cur != 0ull) {   // wave-uniform scalar loop over alive boxes of this chunk, in score order
-            const int bit = __builtin_ctzll(cur);
-            keep |= (1ull << bit);
-            // readlane returns a signed int: cast both halves to unsigned before widening (no sign extension)
-            const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
-            const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
-            const unsigned long long dm = ((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo;
-            cur &= ~dm;
-            cur &= ~(1ull << bit);
+        unsigned long long work = __ballot((diag & cur) != 0ull) & cur;
+        while (work != 0ull) {
+            const int bit = __builtin_ctzll(work);
+            work &= work - 1ull;
+            if ((cur >> bit) & 1ull) {
+                // readlane returns a signed int: cast both halves to unsigned before widening (no sign extension)
+                const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
+                const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
+                cur &= ~(((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo);
+            }
         }
+        const unsigned long long keep = cur;
         // emit kept indices in order
         if ((keep >> lane) & 1ull) {
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -268,16 +271,20 @@ __global__ __launch_bounds__(1024) void lvl_scan_kernel(const LvlArgs a) {
                 const unsigned long long removed = __ballot(acc != 0ull) | spre[cc];
                 const unsigned long long diag = smt[cc * (LVL_SB * 64) + cc * 64 + lane];
                 const unsigned int dlo = (unsigned int)(diag & 0xffffffffu), dhi = (unsigned int)(diag >> 32);
+                // Only a box that overlaps an alive box of its own chunk can change anything: walk those in score order (a box still alive
+                // when its turn comes is kept and removes its row); every other alive box is kept whatever the order.
                 unsigned long long cur = ~removed;       // boxes beyond n and invalid ones are in spre
-                unsigned long long keep = 0ull;
-                while (cur != 0ull) {                    // wave-uniform: alive boxes of the chunk in score order
-                    const int bit = __builtin_ctzll(cur);
-                    keep |= (1ull << bit);
-                    const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
-                    const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
-                    cur &= ~(((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo);
-                    cur &= ~(1ull << bit);
+                unsigned long long work = __ballot((diag & cur) != 0ull) & cur;
+                while (work != 0ull) {                   // wave-uniform
+                    const int bit = __builtin_ctzll(work);
+                    work &= work - 1ull;
+                    if ((cur >> bit) & 1ull) {
+                        const unsigned int dm_hi = (unsigned int)__builtin_amdgcn_readlane((int)dhi, bit);
+                        const unsigned int dm_lo = (unsigned int)__builtin_amdgcn_readlane((int)dlo, bit);
+                        cur &= ~(((unsigned long long)dm_hi << 32) | (unsigned long long)dm_lo);
+                    }
                 }
+                const unsigned long long keep = cur;
                 if (lane == 0) skeep[c] = keep;
                 if ((keep >> lane) & 1ull) {
                     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));

@@ -4,8 +4,8 @@
 // Host restatement: rle_host.hip amp_rle_to_string; this file produces the same bytes without the run lengths ever crossing PCIe
 // (11.5 MB of uint32 runs against 3.6 MB of characters per batch of 1600 masks, and 6 ms of host encoding per batch gone).
 //
-// One wave per mask, a lane per run: the character count of a run depends on its own value only, so the layout is a prefix sum --
-// inside the wave with DPP-free shuffles, across 64-run chunks with a running base, across masks with a one-workgroup scan.
+// One workgroup per mask, a thread per run: the character count of a run depends on its own value only, so the layout is a prefix sum --
+// inside a wave with shuffles, across the four waves and the 256-run chunks with a running base, across masks with a one-workgroup scan.
 #include "common.h"
 
 namespace {
@@ -38,25 +38,28 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
-// str_len[i] = characters of mask i (0 for an empty run list)
+// str_len[i] = characters of mask i (0 for an empty run list).  One 256-thread workgroup per mask: the masks of a batch differ by two
+// orders of magnitude in their number of runs, and with a wave per mask the longest one was the kernel's time.
 __global__ __launch_bounds__(256) void rle_str_len_kernel(const unsigned int* __restrict__ pool, const unsigned long long* __restrict__ off,
                                                           const int* __restrict__ len, int n, int* __restrict__ str_len) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
     const int m = len[i];
     const unsigned int* cnt = pool + off[i];
     int total = 0;
-    for (int r0 = lane; r0 < m; r0 += 4 * 64) {          // four runs per lane in flight: the loop is a chain of L2 round trips otherwise
+    for (int r0 = threadIdx.x; r0 < m; r0 += 4 * 256) {          // four runs per thread in flight
         long long x[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = (r0 + 64 * u < m) ? rle_delta(cnt, r0 + 64 * u) : 0;
+        for (int u = 0; u < 4; ++u) x[u] = (r0 + 256 * u < m) ? rle_delta(cnt, r0 + 256 * u) : 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) total += (r0 + 64 * u < m) ? rle_nchar(x[u]) : 0;
+        for (int u = 0; u < 4; ++u) total += (r0 + 256 * u < m) ? rle_nchar(x[u]) : 0;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d, 64);
-    if (lane == 0) str_len[i] = total;
+    if (lane == 0) wsum[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) str_len[i] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // exclusive scan of str_len -> str_off (one workgroup; n is a batch's detection count: thousands), total -> *total_out
@@ -88,24 +91,35 @@ __global__ __launch_bounds__(1024) void rle_str_scan_kernel(const int* __restric
     if (tid == 0) *total_out = carry;
 }
 
-// the characters of mask i at str + str_off[i]; nothing is written beyond cap (the caller checks *total_out against cap)
+// the characters of mask i at str + str_off[i]; nothing is written beyond cap (the caller checks *total_out against cap).
+// One workgroup per mask, 256 runs per trip: positions from a wave scan + the four wave totals.
 __global__ __launch_bounds__(256) void rle_str_write_kernel(const unsigned int* __restrict__ pool, const unsigned long long* __restrict__ off,
                                                             const int* __restrict__ len, int n, const unsigned long long* __restrict__ str_off,
                                                             char* __restrict__ str, unsigned long long cap) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+    __shared__ int wtot[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
     const int m = len[i];
     const unsigned int* cnt = pool + off[i];
     unsigned long long base = str_off[i];
-    long long x_next = (lane < m) ? rle_delta(cnt, lane) : 0;          // the next chunk's values are fetched while this one is written
-    for (int r0 = 0; r0 < m; r0 += 64) {
-        const int r = r0 + lane;
+    long long x_next = (tid < m) ? rle_delta(cnt, tid) : 0;          // the next chunk's values are fetched while this one is written
+    int buf = 0;
+    for (int r0 = 0; r0 < m; r0 += 256, buf ^= 1) {
+        const int r = r0 + tid;
         long long x = x_next;
-        x_next = (r + 64 < m) ? rle_delta(cnt, r + 64) : 0;
+        x_next = (r + 256 < m) ? rle_delta(cnt, r + 256) : 0;
         const int nc = (r < m) ? rle_nchar(x) : 0;
         const int incl = wave_incl_scan(nc, lane);
-        unsigned long long p = base + (unsigned long long)(incl - nc);
+        if (lane == 63) wtot[buf][wave] = incl;
+        __syncthreads();                       // (two buffers: the next trip's totals do not overwrite what a slower wave still reads)
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int t = wtot[buf][w];
+            if (w < wave) before += t;
+            all += t;
+        }
+        unsigned long long p = base + (unsigned long long)(before + incl - nc);
         if (r < m && p + (unsigned long long)nc <= cap) {
             bool more = true;
             while (more) {
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void rle_str_write_kernel(const unsigned int* 
                 str[p++] = (char)(c + 48);
             }
         }
-        base += (unsigned long long)__shfl(incl, 63, 64);
+        base += (unsigned long long)all;
     }
 }
 
@@ -126,9 +140,9 @@ namespace amp {
 int rle_strings_run(amp_ctx* ctx, const unsigned int* pool, const unsigned long long* off, const int* len, int n, char* str,
                     unsigned long long cap, unsigned long long* str_off, int* str_len, unsigned long long* total) {
     if (n <= 0) return hipMemsetAsync(total, 0, sizeof(unsigned long long), ctx->stream) == hipSuccess ? AMP_OK : AMP_ERR_HIP;
-    hipLaunchKernelGGL(rle_str_len_kernel, dim3((unsigned)amp::cdiv(n, 4)), dim3(256), 0, ctx->stream, pool, off, len, n, str_len);
+    hipLaunchKernelGGL(rle_str_len_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, pool, off, len, n, str_len);
     hipLaunchKernelGGL(rle_str_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, str_len, n, str_off, total);
-    hipLaunchKernelGGL(rle_str_write_kernel, dim3((unsigned)amp::cdiv(n, 4)), dim3(256), 0, ctx->stream, pool, off, len, n, str_off, str, cap);
+    hipLaunchKernelGGL(rle_str_write_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, pool, off, len, n, str_off, str, cap);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -81,29 +81,44 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a
     }
 }
 
-// one workgroup per (image, level with chunks): exact order of the chunks' candidates, first k out
+// one workgroup per (image, level with chunks): exact order of the chunks' candidates, first k out.  The chunks' lists are sorted and
+// their words unique ((key, ~anchor index)): the rank of a word in the merge is its own index plus, per other list, the number of larger
+// words (binary search in LDS) -- no sort.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkArgs a, int lvl, int N) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];        // [nch][k]
+    __shared__ int ccount[8];
     const int b = blockIdx.x;
     const int nch = a.nch[lvl];
+    if (threadIdx.x < nch) ccount[threadIdx.x] = min(a.cand_count[b * a.segs_per_img + a.seg0[lvl] + threadIdx.x], a.k);
+    __syncthreads();
     int total = 0;
-    for (int c = 0; c < nch; ++c) total += a.cand_count[b * a.segs_per_img + a.seg0[lvl] + c];
-    for (int i = threadIdx.x; i < N; i += TOPK_THREADS) {
+    for (int c = 0; c < nch; ++c) total += ccount[c];
+    for (int i = threadIdx.x; i < nch * a.k; i += TOPK_THREADS) {
         const int c = i / a.k, j = i - c * a.k;
-        unsigned long long w = 0ull;
-        if (c < nch) {
-            const int sg = b * a.segs_per_img + a.seg0[lvl] + c;
-            if (j < a.cand_count[sg]) w = a.cand[(size_t)sg * a.k + j];
-        }
-        mkeys[i] = w;
+        mkeys[i] = (j < ccount[c]) ? a.cand[(size_t)(b * a.segs_per_img + a.seg0[lvl] + c) * a.k + j] : 0ull;
     }
-    amp::bitonic_desc<TOPK_THREADS>(mkeys, N);
+    __syncthreads();
     const int k = min(a.k, total);
     const int seg = b * a.nlevels + lvl;
-    for (int i = threadIdx.x; i < k; i += TOPK_THREADS) {
+    for (int i = threadIdx.x; i < nch * a.k; i += TOPK_THREADS) {
+        const int c = i / a.k, j = i - c * a.k;
+        if (j >= ccount[c]) continue;
         const unsigned long long wv = mkeys[i];
-        a.sel_idx[(size_t)seg * a.k + i] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
-        a.sel_logit[(size_t)seg * a.k + i] = ord2f((uint32_t)(wv >> 32));
+        int rank = j;
+        for (int c2 = 0; c2 < nch; ++c2) {
+            if (c2 == c) continue;
+            const unsigned long long* s = mkeys + c2 * a.k;
+            int lo = 0, hi = ccount[c2];
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s[mid] > wv) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            a.sel_idx[(size_t)seg * a.k + rank] = (int)(0xffffffffu - (uint32_t)(wv & 0xffffffffu));
+            a.sel_logit[(size_t)seg * a.k + rank] = ord2f((uint32_t)(wv >> 32));
+        }
     }
     if (threadIdx.x == 0) a.sel_count[seg] = k;
 }
@@ -275,8 +290,7 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
     hipLaunchKernelGGL(rpn_topk_kernel, dim3(B * segs), dim3(TOPK_THREADS), 0, ctx->stream, a);
     for (int l = 0; l < lv->nlevels; ++l)
         if (a.nch[l] > 1) {
-            int N = 64;
-            while (N < a.nch[l] * k) N <<= 1;
+            const int N = a.nch[l] * k;
             AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)(N * sizeof(unsigned long long))));
             hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_THREADS), (size_t)N * sizeof(unsigned long long), ctx->stream, a, l, N);

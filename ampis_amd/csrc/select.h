@@ -13,8 +13,11 @@ constexpr int SELECT_THREADS = 1024;
 constexpr int SELECT_MAX_K = 2048;
 constexpr int SELECT_UNROLL = 8;      // elements in flight per thread in the passes of the memory version
 
+constexpr int SELECT_HCOPIES = 16;      // private histograms (lane & 15): the top digits of a batch of logits fall into two or three bins,
+constexpr int SELECT_HSTRIDE = 257;     // and 64 lanes adding to one LDS word are 64 serial passes; 257: the copies start in different banks
 struct SelectSmem {
     unsigned int hist[256];
+    unsigned int hist_p[SELECT_HCOPIES * SELECT_HSTRIDE];
     unsigned int prefix, remaining, ncand;
     unsigned int wave_gt[16], wave_eq[16];
     unsigned long long sorted[SELECT_MAX_K];
@@ -61,11 +64,62 @@ __device__ inline void bitonic_desc(unsigned long long* s, int N) {
     __syncthreads();
 }
 
+// histogram plumbing shared by the two selections (all threads of the 1024-thread block call these)
+__device__ __forceinline__ void select_hist_clear(SelectSmem& sm) {
+    for (int i = threadIdx.x; i < SELECT_HCOPIES * SELECT_HSTRIDE; i += SELECT_THREADS) sm.hist_p[i] = 0;
+}
+__device__ __forceinline__ void select_hist_add(SelectSmem& sm, unsigned int digit) {
+    atomicAdd(&sm.hist_p[(threadIdx.x & (SELECT_HCOPIES - 1)) * SELECT_HSTRIDE + digit], 1u);
+}
+// after a barrier: hist[d] = sum of the copies; then (another barrier inside) wave 0 finds the digit that holds the `remaining`-th largest
+// key -- lane l owns the four bins 255 - 4 l ... 252 - 4 l, a wave scan gives the number of keys above its group -- and updates
+// sm.prefix / sm.remaining exactly as the serial walk from bin 255 downwards did.
+__device__ __forceinline__ void select_hist_pick(SelectSmem& sm, int shift) {
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        unsigned int c = 0;
+#pragma unroll
+        for (int q = 0; q < SELECT_HCOPIES; ++q) c += sm.hist_p[q * SELECT_HSTRIDE + tid];
+        sm.hist[tid] = c;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned int rem = sm.remaining;
+        unsigned int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = sm.hist[255 - 4 * tid - q];
+        const unsigned int sum = c[0] + c[1] + c[2] + c[3];
+        unsigned int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        const unsigned int excl = incl - sum;
+        if (excl < rem && rem <= incl) {
+            unsigned int r = rem - excl;
+            int q = 3;
+            if (c[0] >= r) q = 0;
+            else {
+                r -= c[0];
+                if (c[1] >= r) q = 1;
+                else {
+                    r -= c[1];
+                    if (c[2] >= r) q = 2; else r -= c[2];
+                }
+            }
+            sm.prefix |= ((uint32_t)(255 - 4 * tid - q) << shift);
+            sm.remaining = r;
+        }
+    }
+    __syncthreads();
+}
+
 template <class KeyFn>
 __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* keys, KeyFn key_fn) {
     const int tid = threadIdx.x;
     __syncthreads();   // previous users of sm are done
-    if (tid < 256) sm.hist[tid] = 0;
+    select_hist_clear(sm);
     if (tid == 0) sm.ncand = 0;
     __syncthreads();
     // (SELECT_UNROLL independent elements per trip in every pass over the keys: the passes are chains of L2 round trips -- 256 per thread at
@@ -82,7 +136,7 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
         for (int u = 0; u < SELECT_UNROLL; ++u) {
             const int i = i0 + u * SELECT_THREADS;
             if (i < n) keys[i] = key[u];
-            if (key[u]) { atomicAdd(&sm.hist[key[u] >> 24], 1u); ++mine; }
+            if (key[u]) { select_hist_add(sm, key[u] >> 24); ++mine; }
         }
     }
     if (mine) atomicAdd(&sm.ncand, mine);
@@ -94,7 +148,7 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
     for (int round = 0; round < 4; ++round) {
         const int shift = 24 - 8 * round;
         if (round > 0) {
-            if (tid < 256) sm.hist[tid] = 0;
+            select_hist_clear(sm);
             __syncthreads();
             const uint32_t prefix = sm.prefix;
             const uint32_t himask = 0xffffffffu << (shift + 8);
@@ -107,22 +161,11 @@ __device__ inline int select_topk(SelectSmem& sm, int n, int kmax, uint32_t* key
                 }
 #pragma unroll
                 for (int u = 0; u < SELECT_UNROLL; ++u)
-                    if (key[u] && (key[u] & himask) == prefix) atomicAdd(&sm.hist[(key[u] >> shift) & 0xff], 1u);
+                    if (key[u] && (key[u] & himask) == prefix) select_hist_add(sm, (key[u] >> shift) & 0xff);
             }
             __syncthreads();
         }
-        if (tid == 0) {
-            unsigned int rem = sm.remaining;
-            int d = 255;
-            for (; d > 0; --d) {
-                const unsigned int c = sm.hist[d];
-                if (c >= rem) break;
-                rem -= c;
-            }
-            sm.prefix |= ((uint32_t)d << shift);
-            sm.remaining = rem;
-        }
-        __syncthreads();
+        select_hist_pick(sm, shift);
     }
     const uint32_t T = sm.prefix;                 // k-th largest key (> 0 because only candidates were counted)
     const unsigned int need_eq = sm.remaining;    // keys == T to take, smallest indices first
@@ -192,7 +235,7 @@ __device__ inline int select_topk_reg(SelectSmem& sm, int n, int kmax, KeyFn key
     const int wave = tid >> 6, lane = tid & 63;
     const int base = wave * PER * 64 + lane;
     __syncthreads();   // previous users of sm are done
-    if (tid < 256) sm.hist[tid] = 0;
+    select_hist_clear(sm);
     if (tid == 0) sm.ncand = 0;
     __syncthreads();
     uint32_t kreg[PER];
@@ -201,7 +244,7 @@ __device__ inline int select_topk_reg(SelectSmem& sm, int n, int kmax, KeyFn key
     for (int j = 0; j < PER; ++j) {
         const int i = base + j * 64;
         kreg[j] = (i < n) ? key_fn(i) : 0u;
-        if (kreg[j]) { atomicAdd(&sm.hist[kreg[j] >> 24], 1u); ++mine; }
+        if (kreg[j]) { select_hist_add(sm, kreg[j] >> 24); ++mine; }
     }
     if (mine) atomicAdd(&sm.ncand, mine);
     __syncthreads();
@@ -212,27 +255,16 @@ __device__ inline int select_topk_reg(SelectSmem& sm, int n, int kmax, KeyFn key
     for (int round = 0; round < 4; ++round) {
         const int shift = 24 - 8 * round;
         if (round > 0) {
-            if (tid < 256) sm.hist[tid] = 0;
+            select_hist_clear(sm);
             __syncthreads();
             const uint32_t prefix = sm.prefix;
             const uint32_t himask = 0xffffffffu << (shift + 8);
 #pragma unroll
             for (int j = 0; j < PER; ++j)
-                if (kreg[j] && (kreg[j] & himask) == prefix) atomicAdd(&sm.hist[(kreg[j] >> shift) & 0xff], 1u);
+                if (kreg[j] && (kreg[j] & himask) == prefix) select_hist_add(sm, (kreg[j] >> shift) & 0xff);
             __syncthreads();
         }
-        if (tid == 0) {
-            unsigned int rem = sm.remaining;
-            int d = 255;
-            for (; d > 0; --d) {
-                const unsigned int c = sm.hist[d];
-                if (c >= rem) break;
-                rem -= c;
-            }
-            sm.prefix |= ((uint32_t)d << shift);
-            sm.remaining = rem;
-        }
-        __syncthreads();
+        select_hist_pick(sm, shift);
     }
     const uint32_t T = sm.prefix;
     const unsigned int need_eq = sm.remaining;

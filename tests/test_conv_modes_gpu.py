@@ -534,3 +534,32 @@ def test_ring_kernel_repeats_bit_for_bit(gpu_ctx, shape):
         y = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw)
         torch.cuda.synchronize()
         assert torch.equal(y.view(torch.int32), first.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 224, 288), (1, 96, 352), (3, 160, 128), (1, 1024, 1024)])
+def test_fused_stem_pool_is_bit_identical(gpu_ctx, B, H, W):
+    """stem_pool_f16x3_kernel (7x7 stem + ReLU + 3x3 max-pool in one kernel, the stem's output never written) against the two kernels it
+    replaces: the pooled tensor bit for bit -- pooled sizes that are not multiples of the 8 x 7 tile, images of a batch, and the bench's
+    size -- and therefore identical detections."""
+    from ampis_amd import params as P
+    from ampis_amd._lib import lib
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    K = 2
+    rng = np.random.default_rng(B * 1000 + H + W)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=40)
+    m.load_params(P.init_params(K, seed=3, style="spread"))
+    outs, taps = [], []
+    try:
+        for on in (1, 0):
+            lib().amp_debug_set_stem_pool(on)
+            outs.append(m.infer(imgs, rle="counts"))
+            taps.append(m.tap("stem_pool"))
+    finally:
+        lib().amp_debug_set_stem_pool(1)
+    m.close()
+    assert taps[0].shape == (B, (H // 2 + 1) // 2, (W // 2 + 1) // 2, 64) and float(np.abs(taps[0]).max()) > 0
+    assert np.array_equal(taps[0].view(np.uint32), taps[1].view(np.uint32))
+    for x, y in zip(*outs):
+        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
