@@ -160,8 +160,12 @@ int sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchun
                    float momentum, float weight_decay, float grad_scale);
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);
 // conv.hip: stem conv + ReLU + max-pool fused (AMP_CONV_F16X3, pre-split weights); returns 1 when it does not apply (caller: conv, then maxpool_run)
-int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const float* w_split, const float* scale, const float* shift, float* pool,
-                  int pool_split);   // pointwise.hip: y_split = 1 writes split rows
+// x_split: the input pixels are in preprocess_run's split form (16 B = 4 hi halves | 4 lo' halves)
+int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_split, const float* w_split, const float* scale, const float* shift,
+                  float* pool, int pool_split);
+bool stem_pool_applies(amp_ctx* ctx, const float* w_split);     // would stem_pool_run launch the fused kernel (mode, switches)?
+int preprocess_run(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std[3],
+                   const int* img_hw, float* out, int out_split);   // pointwise.hip   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3
 // only; a [rows][C] fp32 tensor and its split form have the same byte size and row offsets)
 }

@@ -1632,6 +1632,7 @@ struct StemPoolArgs {
     int pool_split;
 };
 
+template <bool X_SPLIT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_f16x3_kernel(const ConvArgs a, const StemPoolArgs sp, const unsigned int x_bytes,
                                                                  const unsigned int w_bytes) {
     constexpr int BM = 256, BN = 64;
@@ -1700,11 +1701,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         float* As = lds + buf * TILE_FLOATS;
 #pragma unroll
         for (int p = 0; p < RPT; ++p) {
-            f16x8 hi, lo;
-            split8<false>(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo, 1.0f);
             const int r = a_row[p], sw = (r >> 1) & 7;
-            *reinterpret_cast<f16x8*>(As + r * BK + 4 * (akg ^ sw)) = hi;
-            *reinterpret_cast<f16x8*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
+            if (X_SPLIT) {      // the pixels arrive split (preprocess_run): a lane's two taps are {hi4 | lo4} twice -- regroup, no arithmetic
+                const u32x4 hi = {ra[p][0][0], ra[p][0][1], ra[p][1][0], ra[p][1][1]};
+                const u32x4 lo = {ra[p][0][2], ra[p][0][3], ra[p][1][2], ra[p][1][3]};
+                *reinterpret_cast<u32x4*>(As + r * BK + 4 * (akg ^ sw)) = hi;
+                *reinterpret_cast<u32x4*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
+            } else {
+                f16x8 hi, lo;
+                split8<false>(__builtin_bit_cast(f32x4, ra[p][0]), __builtin_bit_cast(f32x4, ra[p][1]), hi, lo, 1.0f);
+                *reinterpret_cast<f16x8*>(As + r * BK + 4 * (akg ^ sw)) = hi;
+                *reinterpret_cast<f16x8*>(As + r * BK + 4 * ((4 + akg) ^ sw)) = lo;
+            }
         }
     };
 
@@ -2166,9 +2174,12 @@ static int g_stem_pool = getenv("AMP_NO_STEM_POOL") ? 0 : 1;      // EXPERIMENT 
 extern "C" void amp_debug_set_stem_pool(int v) { g_stem_pool = v; }
 // Stem (7x7 stride 2 on the [B,H,W,4] input, weights [64][7][8][4], ReLU) + max-pool 3x3 stride 2 pad 1 in one kernel: AMP_CONV_F16X3 with
 // pre-split weights only.  Returns 1 (nothing launched) when the fused form does not apply -- the caller runs the two kernels.
-int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const float* w_split, const float* scale, const float* shift,
+bool amp::stem_pool_applies(amp_ctx* ctx, const float* w_split) {
+    return g_stem_pool && ctx->conv_mode == AMP_CONV_F16X3 && w_split && g_conv_ablate == 0;
+}
+int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_split, const float* w_split, const float* scale, const float* shift,
                        float* pool, int pool_split) {
-    if (!g_stem_pool || ctx->conv_mode != AMP_CONV_F16X3 || !w_split || g_conv_ablate != 0) return 1;
+    if (!amp::stem_pool_applies(ctx, w_split)) return 1;
     ConvArgs a = ConvArgs();
     a.x = x; a.w = w_split; a.scale = scale; a.shift = shift;
     a.B = B; a.H = H; a.W = W; a.Cin = 4; a.Cout = 64;
@@ -2181,7 +2192,10 @@ int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const 
     a.in_scale = a.out_scale = 1.0f;
     a.range_flag = ctx->d_conv_flag;
     const size_t x_bytes = (size_t)B * H * W * 4 * sizeof(float), w_bytes = (size_t)64 * a.K * sizeof(float);
-    if (a.Ho < 1 || a.Wo < 1 || x_bytes >= (size_t)OOB_VOFF || (long long)B * H * W >= (1ll << 27)) return 1;
+    if (a.Ho < 1 || a.Wo < 1 || x_bytes >= (size_t)OOB_VOFF || (long long)B * H * W >= (1ll << 27)) {
+        AMP_REQUIRE(!x_split, "stem_pool_run: a split input needs the fused kernel, which this size does not fit");
+        return 1;
+    }
     StemPoolArgs sp;
     sp.pool = pool; sp.pool_split = pool_split;
     sp.Hq = (a.Ho + 2 - 3) / 2 + 1; sp.Wq = (a.Wo + 2 - 3) / 2 + 1;
@@ -2197,8 +2211,10 @@ int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, const 
             ctx->prof_truncated = true;
         }
     }
-    hipLaunchKernelGGL(stem_pool_f16x3_kernel, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
-                       (unsigned int)x_bytes, (unsigned int)w_bytes);
+    if (x_split) hipLaunchKernelGGL(stem_pool_f16x3_kernel<true>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
+                                    (unsigned int)x_bytes, (unsigned int)w_bytes);
+    else hipLaunchKernelGGL(stem_pool_f16x3_kernel<false>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
+                            (unsigned int)x_bytes, (unsigned int)w_bytes);
     AMP_HIP_CHECK(hipGetLastError());
     if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     return AMP_OK;

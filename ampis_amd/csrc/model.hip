@@ -274,13 +274,18 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     // ---------------- backbone ----------------
     AMP_ALLOC(x0, float, (size_t)B * Hp * Wp * 4);
     AMP_ALLOC(d_img_hw, int, (size_t)2 * B);
+    bool x0_split = false;
     if (!dry) {
         const bool sized = (int)m->img_hw.size() == 2 * B;
         if (sized) {
             AMP_HIP_CHECK(hipMemcpyAsync(d_img_hw, m->img_hw.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, ctx->stream));
             AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         }
-        AMP_TRY(amp_preprocess(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0));
+        // the fused stem + pool kernel takes its pixels already split (hi | lo' halves): the same halves its own split would make
+        const ConvW& sw0 = CONV("backbone.bottom_up.stem.conv1");
+        x0_split = sw0.cin == 4 && sw0.kw == 8 && sw0.kh == 7 && sw0.cout == 64 && !m->split_stale && amp::stem_pool_applies(ctx, sw0.w_split) &&
+                   (size_t)B * Hp * Wp * 16 < 0x80000000ull && (long long)B * Hp * Wp < (1ll << 27);
+        AMP_TRY(amp::preprocess_run(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0, x0_split ? 1 : 0));
         T.img_hw = sized ? d_img_hw : nullptr;
     } else {
         T.img_hw = nullptr;
@@ -322,8 +327,9 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         const ConvW& sw = CONV("backbone.bottom_up.stem.conv1");
         int fused = 1;
         if (sw.cin == 4 && sw.kw == 8 && sw.kh == 7 && sw.cout == 64 && !m->split_stale)
-            fused = amp::stem_pool_run(ctx, B, Hp, Wp, x0, sw.w_split, sw.scale, sw.shift, pool, native_all ? 1 : 0);
+            fused = amp::stem_pool_run(ctx, B, Hp, Wp, x0, x0_split ? 1 : 0, sw.w_split, sw.scale, sw.shift, pool, native_all ? 1 : 0);
         if (fused < 0) return fused;
+        if (fused == 1 && x0_split) { amp::set_error("amp_model: the input was split for the fused stem, which then did not launch"); return AMP_ERR_STATE; }
         if (fused == 1) {
             AMP_TRY(launch_conv(m, sw, x0, B, Hp, Wp, 2, 3, true, 0, nullptr, 0, stem));
             AMP_TRY(amp::maxpool_run(ctx, stem, B, h, w, 64, pool, native_all ? 1 : 0));

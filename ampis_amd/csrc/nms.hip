@@ -2,7 +2,7 @@
 // boxes of different categories never suppress each other, exact coordinates, suppress when IoU > thresh).
 //
 // Two kernels per call, all images of the batch at once:
-//   nms_mask_kernel : 64x64 tiles of the upper-triangular suppression matrix; lane i of a wave owns box i of the row tile
+//   nms_mask_kernel : 64x64 tiles of the upper-triangular suppression matrix, one wave per tile; lane i of a wave owns box i of the row tile
 //                     and builds one 64-bit word (bit j = "i suppresses j", j > i) against the 64 boxes of the column tile
 //                     staged in LDS.  IoU arithmetic in torchvision's op order, fp32, no contraction -> bit-exact vs the oracle.
 //   nms_scan_kernel : ONE wavefront per image walks the rows in score order.  The `removed` bitmask (<= 256 words) lives in
@@ -22,50 +22,59 @@ struct NmsArgs {
     float thresh;
 };
 
-__global__ __launch_bounds__(64) void nms_mask_kernel(const NmsArgs a) {
-    const int b = blockIdx.z;
+// (grid: NMS_MASK_BLOCKS workgroups of four waves per image walk the tiles the image's count needs -- the count is only known on the
+//  device, and a grid for the capacity, 128 x 128 tiles of which a 1500-box image uses 24 x 24, spent the kernel's time starting empty
+//  workgroups)
+constexpr int NMS_MASK_BLOCKS = 128;
+__global__ __launch_bounds__(256) void nms_mask_kernel(const NmsArgs a) {
+    __shared__ float sb_all[4][64][4];
+    __shared__ int sc_all[4][64];
+    const int b = blockIdx.y;
     const int n = min(a.counts[b], a.cap);
-    const int rb = blockIdx.y, cb = blockIdx.x;
-    if (rb * 64 >= n || cb * 64 >= n) return;
-    const int lane = threadIdx.x;
-    const int i = rb * 64 + lane;
-    unsigned long long* mrow = a.mask + ((size_t)b * a.cap + i) * a.W + cb;
-    if (cb < rb) {
-        if (i < n) *mrow = 0ull;
-        return;
-    }
-    __shared__ float sb[64][4];
-    __shared__ int sc[64];
-    const int j0 = cb * 64;
-    {
-        const int j = j0 + lane;
-        if (j < n) {
-            const float* p = a.boxes + ((size_t)b * a.cap + j) * 4;
-            sb[lane][0] = p[0]; sb[lane][1] = p[1]; sb[lane][2] = p[2]; sb[lane][3] = p[3];
-            sc[lane] = a.cats[(size_t)b * a.cap + j];
+    const int nW = (n + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*sb)[4] = sb_all[wave];
+    int* sc = sc_all[wave];
+    for (int t = blockIdx.x * 4 + wave; t < nW * nW; t += NMS_MASK_BLOCKS * 4) {
+        const int rb = t / nW, cb = t - rb * nW;
+        const int i = rb * 64 + lane;
+        unsigned long long* mrow = a.mask + ((size_t)b * a.cap + i) * a.W + cb;
+        if (cb < rb) {
+            if (i < n) *mrow = 0ull;
+            continue;
         }
+        const int j0 = cb * 64;
+        __builtin_amdgcn_wave_barrier();          // the previous tile's readers are done (same wave: LDS accesses stay in order)
+        {
+            const int j = j0 + lane;
+            if (j < n) {
+                const float* p = a.boxes + ((size_t)b * a.cap + j) * 4;
+                sb[lane][0] = p[0]; sb[lane][1] = p[1]; sb[lane][2] = p[2]; sb[lane][3] = p[3];
+                sc[lane] = a.cats[(size_t)b * a.cap + j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (i >= n) continue;
+        const float* p = a.boxes + ((size_t)b * a.cap + i) * 4;
+        const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+        const int ci = a.cats[(size_t)b * a.cap + i];
+        const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+        unsigned long long bits = 0ull;
+        const int jn = min(64, n - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            const int j = j0 + jj;
+            if (j <= i) continue;
+            const float bx1 = sb[jj][0], by1 = sb[jj][1], bx2 = sb[jj][2], by2 = sb[jj][3];
+            const float area_j = __fmul_rn(__fsub_rn(bx2, bx1), __fsub_rn(by2, by1));
+            const float xx1 = fmaxf(x1, bx1), yy1 = fmaxf(y1, by1);
+            const float xx2 = fminf(x2, bx2), yy2 = fminf(y2, by2);
+            const float w = fmaxf(__fsub_rn(xx2, xx1), 0.f), h = fmaxf(__fsub_rn(yy2, yy1), 0.f);
+            const float inter = __fmul_rn(w, h);
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));
+            if (iou > a.thresh && sc[jj] == ci) bits |= (1ull << jj);
+        }
+        *mrow = bits;
     }
-    __syncthreads();
-    if (i >= n) return;
-    const float* p = a.boxes + ((size_t)b * a.cap + i) * 4;
-    const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
-    const int ci = a.cats[(size_t)b * a.cap + i];
-    const float area_i = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
-    unsigned long long bits = 0ull;
-    const int jn = min(64, n - j0);
-    for (int jj = 0; jj < jn; ++jj) {
-        const int j = j0 + jj;
-        if (j <= i) continue;
-        const float bx1 = sb[jj][0], by1 = sb[jj][1], bx2 = sb[jj][2], by2 = sb[jj][3];
-        const float area_j = __fmul_rn(__fsub_rn(bx2, bx1), __fsub_rn(by2, by1));
-        const float xx1 = fmaxf(x1, bx1), yy1 = fmaxf(y1, by1);
-        const float xx2 = fminf(x2, bx2), yy2 = fminf(y2, by2);
-        const float w = fmaxf(__fsub_rn(xx2, xx1), 0.f), h = fmaxf(__fsub_rn(yy2, yy1), 0.f);
-        const float inter = __fmul_rn(w, h);
-        const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_i, area_j), inter));
-        if (iou > a.thresh && sc[jj] == ci) bits |= (1ull << jj);
-    }
-    *mrow = bits;
 }
 
 __global__ __launch_bounds__(64) void nms_scan_kernel(const NmsArgs a, int max_keep, int* keep_idx, int* keep_count) {
@@ -366,7 +375,7 @@ extern "C" int amp_nms(amp_ctx* ctx, int B, int cap, const float* boxes, const i
     NmsArgs a;
     a.boxes = boxes; a.cats = cats; a.counts = counts; a.mask = mask_scratch;
     a.cap = cap; a.W = amp::cdiv(cap, 64); a.thresh = thresh;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(a.W, a.W, B), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(NMS_MASK_BLOCKS, B), dim3(256), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, ctx->stream, a, max_keep, keep_idx, keep_count);
     AMP_HIP_CHECK(hipGetLastError());

@@ -10,6 +10,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 pp_h4 __attribute__((ext_vector_type(4)));
+// SPLIT: a pixel's 16 bytes are the f16 hi halves of its 4 values, then the lo' halves ((v - hi) * 2^11) -- what the f16x3 stem would make
+// of the fp32 pixel tap by tap (conv.hip split8); stem_pool_f16x3_kernel then stages the halves as they are
+template <bool SPLIT>
 __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int B, int H, int W, int Hp,
                                   int Wp, float m0, float m1, float m2, float s0, float s1, float s2, const int* __restrict__ img_hw) {
     const size_t total = (size_t)B * Hp * Wp;
@@ -26,7 +30,19 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __rest
             v[1] = __fdiv_rn(__fsub_rn((float)p[1], m1), s1);
             v[2] = __fdiv_rn(__fsub_rn((float)p[2], m2), s2);
         }
-        reinterpret_cast<f32x4*>(out)[i] = v;
+        if (SPLIT) {
+            pp_h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = (_Float16)v[e];
+                hi[e] = h;
+                lo[e] = (_Float16)((v[e] - (float)h) * 2048.0f);
+            }
+            pp_h4* o = reinterpret_cast<pp_h4*>(out) + 2 * i;
+            o[0] = hi; o[1] = lo;
+        } else {
+            reinterpret_cast<f32x4*>(out)[i] = v;
+        }
     }
 }
 
@@ -101,13 +117,7 @@ extern "C" {
 
 int amp_preprocess(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3],
                    const float std[3], const int* img_hw, float* out) {
-    AMP_REQUIRE(ctx && img_bgr && out && mean && std, "amp_preprocess: null argument");
-    AMP_REQUIRE(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "amp_preprocess: bad shape");
-    const size_t total = (size_t)B * Hp * Wp;
-    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, img_bgr, out, B, H, W,
-                       Hp, Wp, mean[0], mean[1], mean[2], std[0], std[1], std[2], img_hw);
-    AMP_HIP_CHECK(hipGetLastError());
-    return AMP_OK;
+    return amp::preprocess_run(ctx, img_bgr, B, H, W, Hp, Wp, mean, std, img_hw, out, 0);
 }
 
 int amp_maxpool3x3s2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y) {
@@ -126,6 +136,19 @@ int amp_subsample2(amp_ctx* ctx, const float* x, int B, int H, int W, int C, flo
 }
 
 }  // extern "C"
+
+int amp::preprocess_run(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std[3],
+                        const int* img_hw, float* out, int out_split) {
+    AMP_REQUIRE(ctx && img_bgr && out && mean && std, "amp_preprocess: null argument");
+    AMP_REQUIRE(B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W, "amp_preprocess: bad shape");
+    const size_t total = (size_t)B * Hp * Wp;
+    if (out_split) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, img_bgr, out, B, H, W,
+                                      Hp, Wp, mean[0], mean[1], mean[2], std[0], std[1], std[2], img_hw);
+    else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, img_bgr, out, B, H, W,
+                            Hp, Wp, mean[0], mean[1], mean[2], std[0], std[1], std[2], img_hw);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
 
 int amp::maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split) {
     AMP_REQUIRE(ctx && x && y, "amp_maxpool3x3s2: null argument");

@@ -1,4 +1,4 @@
 set -e
-timeout -k 10 900 python -m pytest tests/test_conv_modes_gpu.py tests/test_e2e_gpu.py tests/test_edge_cases_gpu.py tests/test_stages_gpu.py -x -q > gpurun_out/r3_stem_tests.log 2>&1 || { tail -30 gpurun_out/r3_stem_tests.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/test_conv_modes_gpu.py tests/test_e2e_gpu.py tests/test_edge_cases_gpu.py tests/test_stages_gpu.py tests/test_train_fwd_gpu.py -x -q > gpurun_out/r3_stem_tests.log 2>&1 || { tail -30 gpurun_out/r3_stem_tests.log; exit 1; }
 tail -3 gpurun_out/r3_stem_tests.log
-bash tools/kstat_quick.sh kq5 | grep "stem\|maxpool\|f16x3_kernel\|all kernels\|lvl_scan\|nms_scan"
+bash tools/kstat_quick.sh kq6 | grep "stem\|preprocess\|nms_mask\|all kernels"
