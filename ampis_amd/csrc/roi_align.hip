@@ -9,6 +9,7 @@
 // Layout: features NHWC; output [R][P][P][C].  One wavefront per output bin: 64 lanes x float4 = 256 channels, so
 // every tap is one fully coalesced 1 KiB read; HBM/L2-gather bound, no LDS needed.
 #include "common.h"
+#include "select.h"
 
 namespace {
 
@@ -448,8 +449,8 @@ __device__ __forceinline__ void load_tap8(const float* row, int c8, f32x2r (&v)[
     }
 }
 
-// XCD-major processing order (RoiArgs::order).  One workgroup: keys (image | level | Morton tile of the box centre at that level, 8 x 8
-// cells | index) sorted bitonically in LDS (R <= 8192), then every image's sorted RoIs dealt out to the 8 XCDs in contiguous eighths.
+// XCD-major processing order (RoiArgs::order).  Keys (Morton tile of the box centre, 32 x 32 px | level | index) of an image's RoIs sorted
+// bitonically in LDS (R <= 8192), then the sorted RoIs dealt out to the 8 XCDs in contiguous eighths.
 constexpr int ORDER_MAX = 8192;
 __device__ __forceinline__ unsigned int morton6(unsigned int y, unsigned int x) {
     unsigned int m = 0;
@@ -457,64 +458,64 @@ __device__ __forceinline__ unsigned int morton6(unsigned int y, unsigned int x) 
     for (int b = 0; b < 6; ++b) m |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
     return m;
 }
+// One workgroup per image (grid = 32, the images a key can name): it counts the RoIs of every image (the offsets of its chunks in the
+// eight lists depend on the images in front of it), collects and sorts its own, and deals them out.
 __global__ __launch_bounds__(1024) void roi_order_kernel(const RoiArgs a, int* __restrict__ order, int* __restrict__ xlen, int xstride) {
-    __shared__ unsigned int keys[ORDER_MAX];
-    __shared__ int cnt[32], start[33], off[8][33];
-    const int tid = threadIdx.x;
-    int n2 = 1;
-    while (n2 < a.R) n2 <<= 1;
+    __shared__ unsigned long long keys[ORDER_MAX];      // ~key in the low word of a 64-bit word: amp::bitonic_desc sorts descending
+    __shared__ int cnt[32], off[8], n_mine;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int img = blockIdx.x;
     if (tid < 32) cnt[tid] = 0;
+    if (tid == 0) n_mine = 0;
     __syncthreads();
-    for (int r = tid; r < n2; r += 1024) {
-        unsigned int k = 0xffffffffu;
-        if (r < a.R) {
-            const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
-            const int lv = assign_level(x1, y1, x2, y2);
-            const int b = min(a.batch_idx ? a.batch_idx[r] : 0, 31);
-            // tile of the box centre in IMAGE pixels (32 x 32 px = 8 x 8 cells of p2), levels mixed: a chunk of the sorted list then holds the
-            // same mix of cheap (p2, 1-4 samples per bin axis) and expensive (p3..p5, 4-8) RoIs as every other chunk -- sorting by level
-            // first left whole XCDs with the expensive ones
-            const int cx = min(max((int)((x1 + x2) * 0.5f), 0) >> 5, 63), cy = min(max((int)((y1 + y2) * 0.5f), 0) >> 5, 63);
-            k = ((unsigned)b << 27) | (morton6((unsigned)cy, (unsigned)cx) << 15) | ((unsigned)lv << 13) | (unsigned)r;
-            atomicAdd(&cnt[b], 1);
+    for (int r0 = (tid & ~63); r0 < a.R; r0 += 1024) {            // counts: one ballot per image present in the wave's 64 RoIs
+        const int r = r0 + lane;
+        const int b = (r < a.R) ? min(a.batch_idx ? a.batch_idx[r] : 0, 31) : -1;
+        unsigned long long todo = __ballot(b >= 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int bl = __shfl(b, leader, 64);
+            const unsigned long long same = __ballot(b == bl);
+            if (lane == leader) atomicAdd(&cnt[bl], (int)__popcll(same));
+            todo &= ~same;
         }
-        keys[r] = k;
     }
     __syncthreads();
-    for (int size = 2; size <= n2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < (n2 >> 1); i += 1024) {
-                const int lo = ((i / stride) * stride << 1) + (i % stride), hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const unsigned int ka = keys[lo], kb = keys[hi];
-                if ((ka > kb) == up) { keys[lo] = kb; keys[hi] = ka; }
-            }
-            __syncthreads();
-        }
-    if (tid == 0) {
-        start[0] = 0;
-        for (int i = 0; i < 32; ++i) start[i + 1] = start[i] + cnt[i];
-    }
-    __syncthreads();
-    if (tid < 8) {       // chunk x of image i = sorted ranks [ceil(x n / 8), ceil((x + 1) n / 8))
+    const int n = cnt[img];
+    if (img == 0 && tid < 8) {       // chunk x of image i = sorted ranks [ceil(x n / 8), ceil((x + 1) n / 8)): the lists' lengths
         int o = 0;
-        for (int i = 0; i < 32; ++i) {
-            off[tid][i] = o;
-            const int n = cnt[i];
-            o += (((tid + 1) * n + 7) >> 3) - ((tid * n + 7) >> 3);
-        }
-        off[tid][32] = o;
+        for (int i = 0; i < 32; ++i) o += (((tid + 1) * cnt[i] + 7) >> 3) - ((tid * cnt[i] + 7) >> 3);
         xlen[tid] = o;
     }
-    __syncthreads();
-    for (int q = tid; q < a.R; q += 1024) {
-        const unsigned int k = keys[q];
-        const int i = (int)(k >> 27), r = (int)(k & 8191u);
-        const int n = cnt[i], s = q - start[i];
-        int x = min((s * 8) / max(n, 1), 7);
-        while (x < 7 && s >= (((x + 1) * n + 7) >> 3)) ++x;
-        while (x > 0 && s < ((x * n + 7) >> 3)) --x;
-        order[x * xstride + off[x][i] + (s - ((x * n + 7) >> 3))] = r;
+    if (n == 0) return;
+    if (tid < 8) {
+        int o = 0;
+        for (int i = 0; i < img; ++i) o += (((tid + 1) * cnt[i] + 7) >> 3) - ((tid * cnt[i] + 7) >> 3);
+        off[tid] = o;
+    }
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    for (int r = tid; r < a.R; r += 1024) {
+        const int b = min(a.batch_idx ? a.batch_idx[r] : 0, 31);
+        if (b != img) continue;
+        const float x1 = a.rois[4 * r + 0], y1 = a.rois[4 * r + 1], x2 = a.rois[4 * r + 2], y2 = a.rois[4 * r + 3];
+        const int lv = assign_level(x1, y1, x2, y2);
+        // tile of the box centre in IMAGE pixels (32 x 32 px = 8 x 8 cells of p2), levels mixed: a chunk of the sorted list then holds the
+        // same mix of cheap (p2, 1-4 samples per bin axis) and expensive (p3..p5, 4-8) RoIs as every other chunk -- sorting by level
+        // first left whole XCDs with the expensive ones
+        const int cx = min(max((int)((x1 + x2) * 0.5f), 0) >> 5, 63), cy = min(max((int)((y1 + y2) * 0.5f), 0) >> 5, 63);
+        const unsigned int k = (morton6((unsigned)cy, (unsigned)cx) << 15) | ((unsigned)lv << 13) | (unsigned)r;
+        keys[atomicAdd(&n_mine, 1)] = (unsigned long long)(~k);          // slot order does not matter: the keys (with r) are unique
+    }
+    for (int q = n + tid; q < n2; q += 1024) keys[q] = 0ull;
+    amp::bitonic_desc<1024>(keys, n2);          // (steps below stride 64 in registers: select.h)
+    for (int s_ = tid; s_ < n; s_ += 1024) {
+        const unsigned int k = ~(unsigned int)keys[s_];
+        const int r = (int)(k & 8191u);
+        int x = min((s_ * 8) / n, 7);
+        while (x < 7 && s_ >= (((x + 1) * n + 7) >> 3)) ++x;
+        while (x > 0 && s_ < ((x * n + 7) >> 3)) --x;
+        order[x * xstride + off[x] + (s_ - ((x * n + 7) >> 3))] = r;
     }
 }
 
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void roi_align_split_tab_kernel(const RoiArgs 
 }  // namespace
 
 static int g_roi_share = getenv("AMP_ROI_SHARE") ? atoi(getenv("AMP_ROI_SHARE")) : 1;
-static int g_roi_xcd = getenv("AMP_ROI_XCD") ? atoi(getenv("AMP_ROI_XCD")) : 0;      // EXPERIMENT: XCD-major RoI order (roi_order_kernel)
+static int g_roi_xcd = getenv("AMP_ROI_XCD") ? atoi(getenv("AMP_ROI_XCD")) : 1;      // XCD-major RoI order (roi_order_kernel): 1 = for >= 2048 RoIs (the box pooler: -10 %; the mask pooler's 1600 do not pay the sort), 2 = always, 0 = never
 extern "C" void amp_debug_set_roi_xcd(int v) { g_roi_xcd = v; }
 static int g_roi_tab = getenv("AMP_ROI_TAB") ? atoi(getenv("AMP_ROI_TAB")) : 1;      // 1: sample tables in LDS (roi_align_split_tab_kernel); 0: roi_align_split_kernel
 extern "C" void amp_debug_set_roi_tab(int v) { g_roi_tab = v; }
@@ -832,7 +833,7 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
     } else if (in_split && f->C == 256) {
         long long g2 = (nbins + 7) / 8;              // two bins per wave
         if (g2 > 65536) g2 = 65536;
-        if (g_roi_xcd && !roi_count && R <= ORDER_MAX && R >= 64) {
+        if (g_roi_xcd && !roi_count && R <= ORDER_MAX && R >= (g_roi_xcd >= 2 ? 64 : 2048)) {
             const int xstride = R / 8 + 64;
             const size_t need = (size_t)8 * xstride + 8;
             if (ctx->roi_order_ints < need) {
@@ -843,7 +844,7 @@ int amp::roi_align_run(amp_ctx* ctx, const amp_fpn_feats* f, const float* rois, 
                 ctx->roi_order_ints = need;
             }
             int* xlen = ctx->roi_order + (size_t)8 * xstride;
-            hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, a, ctx->roi_order, xlen, xstride);
+            hipLaunchKernelGGL(roi_order_kernel, dim3(32), dim3(1024), 0, ctx->stream, a, ctx->roi_order, xlen, xstride);
             a.order = ctx->roi_order; a.xlen = xlen; a.xstride = xstride;
             // every XCD gets the same number of workgroups: enough for the longest chunk (R / 8 + one RoI of rounding per image, <= 32 images)
             long long per_x = ((long long)(R / 8 + 33) * P * P + 7) / 8;

@@ -331,3 +331,33 @@ def test_fused_rpn_head_matches_the_two_convolutions(gpu_ctx):
     assert e_fused <= max(1.5 * e_chain, 5e-7), (e_fused, e_chain)
     assert float(pred[:, 15].abs().max()) == 0.0                 # the pad row stays a pad row
     assert not gpu_ctx.conv_range_flag()
+
+
+@pytest.mark.parametrize("P,R", [(7, 3000), (14, 700)])
+def test_roi_align_xcd_major_order_is_bit_identical(gpu_ctx, P, R):
+    """RoIAlign in XCD-major order (roi_order_kernel: every image's RoIs sorted by the 32-px Morton tile of their centre and dealt to the
+    eight XCDs in contiguous eighths -- the default for >= 2048 RoIs) writes every output row exactly as the index order does: split maps in,
+    split rows out, several images with unequal RoI counts, an image without RoIs, degenerate boxes."""
+    from ampis_amd import ops
+    from ampis_amd._lib import lib
+    rng = np.random.default_rng(P + R)
+    B, C, S = 4, 256, 256
+    feats = [torch.from_numpy(rng.normal(0, 1, (B, S // s, S // s, C)).astype(np.float32)).to(DEV) for s in (4, 8, 16, 32)]
+    fs = [ops.split_rows(gpu_ctx, f) for f in feats]
+    ctr = rng.uniform(0, S, (R, 2))
+    size = np.exp(rng.normal(3.6, 0.7, (R, 2))).clip(2, 400)
+    rois = np.clip(np.concatenate([ctr - size / 2, ctr + size / 2], 1), 0, S).astype(np.float32)
+    rois[5] = [10, 10, 10, 40]                               # empty
+    bidx = rng.choice([0, 1, 3], R, p=[0.6, 0.1, 0.3]).astype(np.int32)      # image 2 has none
+    d_rois, d_b = torch.from_numpy(rois).to(DEV), torch.from_numpy(bidx).to(DEV)
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib().amp_debug_set_roi_xcd(mode)
+            out, lvl = ops.roi_align(gpu_ctx, fs, d_rois, d_b, P, fmt=3)
+            torch.cuda.synchronize()
+            outs.append((out.clone(), lvl.clone()))
+    finally:
+        lib().amp_debug_set_roi_xcd(1)
+    assert torch.equal(outs[0][0].view(torch.int32), outs[1][0].view(torch.int32)) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0

@@ -1,4 +1,3 @@
 set -e
-timeout -k 10 900 python -m pytest tests/test_conv_modes_gpu.py tests/test_e2e_gpu.py tests/test_edge_cases_gpu.py tests/test_stages_gpu.py tests/test_train_fwd_gpu.py -x -q > gpurun_out/r3_stem_tests.log 2>&1 || { tail -30 gpurun_out/r3_stem_tests.log; exit 1; }
-tail -3 gpurun_out/r3_stem_tests.log
-bash tools/kstat_quick.sh kq6 | grep "stem\|preprocess\|nms_mask\|all kernels"
+timeout -k 10 600 python -m pytest tests/test_stages_gpu.py tests/test_e2e_gpu.py tests/test_pipeline_gpu.py tests/test_concurrency_gpu.py -x -q 2>&1 | tail -2
+bash tools/kstat_quick.sh kq10 | grep "roi_\|all kernels"

@@ -56,13 +56,13 @@ for P, n in ((7, 1000), (14, 200)):
     clustered = clustered.view(-1, 4).contiguous()
     for nm, R_ in (("uniform centres", rois), ("clustered on 150 objects / image", clustered)):
         outs = []
-        for mode in (0, 1, 0, 1):
+        for mode in (0, 2, 0, 2):
             L.amp_debug_set_roi_xcd(mode)
             run(f"split maps, {nm}, XCD-major order = {mode}", R_, bidx, P, 3, fs)
             outs.append(ops.roi_align(ctx, fs, R_, bidx, P, fmt=3)[0].clone())
         torch.cuda.synchronize()
         assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), "XCD-major order changed the result"
-L.amp_debug_set_roi_xcd(0)
+L.amp_debug_set_roi_xcd(1)
 
 # sample tables in LDS + fma_mix decode (roi_align_split_tab_kernel, AMP_ROI_TAB / amp_debug_set_roi_tab) against roi_align_split_kernel
 for P, n in ((7, 1000), (14, 200)):
