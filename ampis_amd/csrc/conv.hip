@@ -867,7 +867,14 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
     constexpr int TILE_FLOATS = (NPL * BM + BN) * BK;
     constexpr int SLD = WTN + 4;
     constexpr int STAGE_FLOATS = NW * WTM * SLD;
-    constexpr int LDS_FLOATS = (2 * TILE_FLOATS > STAGE_FLOATS) ? 2 * TILE_FLOATS : STAGE_FLOATS;
+    // RING (the 64-wide f16x3 tiles: res2's and res5's 3x3 layers, the grouped layers of ResNeXt): three LDS buffers, the DMA of tile s+2
+    // issued when tile s starts computing, counted vmcnt and a bare barrier -- conv_split_kernel's ring without the ping-pong.  A K-step of
+    // this tile is 384 cycles of MFMA per wave and an LDS-DMA request needs ~2300 from issue to landing: with one tile in flight per
+    // workgroup (two workgroups per CU) the matrix pipe waited two thirds of the time (PMC MFMA busy 0.26); 3 x 24.5 KB still fits twice.
+    constexpr bool RING = F16 && BN == 64 && !STEM && !G32;      // (G32: two A planes, 3 x 41 KB would leave one workgroup per CU)
+    constexpr int NBUF = RING ? 3 : 2;
+    constexpr int LDS_FLOATS = (NBUF * TILE_FLOATS > STAGE_FLOATS) ? NBUF * TILE_FLOATS : STAGE_FLOATS;
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
     const int tid = threadIdx.x;
@@ -980,6 +987,28 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 #pragma unroll
     for (int q = 0; q < BK / 8; ++q) foff[q] = 4 * ((2 * q + lh) ^ fswz);
 
+    if constexpr (RING) {
+        constexpr int NDMA = NPL * GA + GB;     // LDS-DMA requests of this wave per tile
+        static_assert(NDMA < 16, "vmcnt immediate");
+        stage(0);
+        if (nsteps > 1) stage(1);
+        int cur = 0, nxt = 2;
+        for (int step = 0; step < nsteps; ++step) {
+            // tile `step` has landed once all but the youngest tile's requests of this wave are done (in-order vmcnt); bare s_barrier: the
+            // fence of __syncthreads() would wait for vmcnt(0), i.e. for the tile the ring keeps in flight (see conv_split_kernel)
+            if (step + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();       // every wave's share of tile `step` is in LDS; everyone is done with tile step-1
+            asm volatile("" ::: "memory");
+            if (step + 2 < nsteps) stage(nxt);  // into the buffer tile step-1 occupied
+            f16x3_step16<MB, NB>(lds + cur * TILE_FLOATS + (G32 ? wn * BM * BK : 0) + (wm * WTM + l15) * BK,
+                                 lds + cur * TILE_FLOATS + NPL * BM * BK + (wn * WTN + l15) * BK, fo16_hi, fo16_lo, acc16, acx16);
+            cur = (cur == 2) ? 0 : cur + 1;
+            nxt = (nxt == 2) ? 0 : nxt + 1;
+        }
+        __syncthreads();                        // all operand reads done: the epilogue re-uses the buffers as its staging tile
+    } else {
     stage(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): the LDS-DMA has landed (explicit: do not rely on the fence lowering)
     __syncthreads();
@@ -1012,6 +1041,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the LDS-DMA of the next tile has landed
         __syncthreads();   // everyone is done with `cur`
+    }
     }
 
     if (F16) {

@@ -1,3 +1,4 @@
 set -e
-timeout -k 10 600 python -m pytest tests/test_stages_gpu.py tests/test_e2e_gpu.py tests/test_pipeline_gpu.py tests/test_concurrency_gpu.py -x -q 2>&1 | tail -2
-bash tools/kstat_quick.sh kq10 | grep "roi_\|all kernels"
+timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_conv_modes_gpu.py tests/test_e2e_gpu.py tests/test_x101_gpu.py -x -q > gpurun_out/r3_ring_tests.log 2>&1 || { tail -30 gpurun_out/r3_ring_tests.log; exit 1; }
+tail -2 gpurun_out/r3_ring_tests.log
+bash tools/kstat_quick.sh kq11 | grep "conv_glds\|all kernels"
