@@ -1,6 +1,7 @@
 // Shared helpers for the ampis_hip kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
@@ -68,6 +69,22 @@ __device__ __forceinline__ int sortkey_cat(unsigned long long k) { return (int)(
 #endif  // __HIPCC__
 
 }  // namespace amp
+
+// Live profile (amp_prof_begin): the timed kernels are launched with their start / stop events ATTACHED to the dispatch
+// (hipExtLaunchKernelGGL) instead of a hipEventRecord in front of and behind them: a recorded event is a packet of its own and cost
+// ~5 us of idle GPU each -- 10 us per convolution, 0.94 ms on every sampled step of the bench.  amp::prof_e0 / prof_e1 are the events of
+// the launch being issued (null outside a profile: a plain launch).
+namespace amp {
+extern thread_local hipEvent_t prof_e0, prof_e1;
+}
+namespace amp {
+struct ProfLaunchScope {          // attaches a profile record's events to the timed launches of the enclosing scope
+    explicit ProfLaunchScope(hipEvent_t e0, hipEvent_t e1) { prof_e0 = e0; prof_e1 = e1; }
+    ~ProfLaunchScope() { prof_e0 = prof_e1 = nullptr; }
+};
+}
+#define AMP_TIMED_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, amp::prof_e0, amp::prof_e1, 0, __VA_ARGS__)
 
 // AMP_NO_PK: compile a kernel without packed-FP32 instructions (v_pk_mul / add / fma_f32).
 // Found in round 3 (tools/_probe_conc.py): with SEVERAL contexts running kernels on the card at once, box_candidates_kernel

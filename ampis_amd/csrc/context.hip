@@ -6,6 +6,10 @@
 #include "common.h"
 
 namespace amp {
+thread_local hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;      // events of the timed launch being issued (common.h AMP_TIMED_LAUNCH)
+}
+
+namespace amp {
 static thread_local char g_err[1024] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;

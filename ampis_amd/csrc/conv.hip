@@ -1948,9 +1948,9 @@ __global__ __launch_bounds__(256) void weight_jobs_kernel(const amp::WeightJob* 
 template <int BN, bool STEM>
 void launch_glds(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_glds_kernel<BN, STEM, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+        case 1: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, STEM, 1>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        case 2: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, STEM, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        default: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, STEM, 0>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     }
 }
 
@@ -1958,17 +1958,17 @@ template <int BN>
 void launch_f16x3s(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BN == 256) ? 512 : 256;
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 1, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 2, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_glds_kernel<BN, false, 0, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+        case 1: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, false, 1, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, false, 2, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: AMP_TIMED_LAUNCH((conv_glds_kernel<BN, false, 0, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     }
 }
 
 void launch_f16x3s_g32(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {     // grouped, <= 32 channels per group: one K-step per tap
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_glds_kernel<64, false, 1, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_glds_kernel<64, false, 2, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_glds_kernel<64, false, 0, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+        case 1: AMP_TIMED_LAUNCH((conv_glds_kernel<64, false, 1, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        case 2: AMP_TIMED_LAUNCH((conv_glds_kernel<64, false, 2, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb); break;
+        default: AMP_TIMED_LAUNCH((conv_glds_kernel<64, false, 0, true, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     }
 }
 
@@ -1976,24 +1976,24 @@ template <int BM, int BN>
 void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BM / 64) * (BN / 64) * 64;
     if constexpr (BM == 128 && BN == 256) {
-        if (epi == 3) { hipLaunchKernelGGL((conv_split_kernel<128, 256, 3>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); return; }
+        if (epi == 3) { AMP_TIMED_LAUNCH((conv_split_kernel<128, 256, 3>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); return; }
     }
-    if (epi == 2) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
-    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+    if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+    else AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
 }
 
 void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
-    if (epi == 1) hipLaunchKernelGGL((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
-    else hipLaunchKernelGGL((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    if (epi == 1) AMP_TIMED_LAUNCH((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    else AMP_TIMED_LAUNCH((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
 }
 
 template <int BN>
 void launch_f16x3_scaled(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BN == 256) ? 512 : 256;
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+        case 1: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 1, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 2, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 0, false, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     }
 }
 
@@ -2002,9 +2002,9 @@ void launch_f16x3(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, u
     if (a.in_scale != 1.0f) { launch_f16x3_scaled<BN>(a, epi, st, xb, wb); return; }
     constexpr int NT_ = (BN == 256) ? 512 : 256;
     switch (epi) {
-        case 1: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        case 2: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
-        default: hipLaunchKernelGGL((conv_f16x3_kernel<BN, 0>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+        case 1: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        case 2: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); break;
+        default: AMP_TIMED_LAUNCH((conv_f16x3_kernel<BN, 0>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     }
 }
 
@@ -2236,17 +2236,16 @@ int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)B * a.Ho * a.Wo * 64.0 * 7.0 * 8.0 * 4.0;   // useful work of the stem (as conv_run counts it), not the halo
             rec->variant = 1;
-            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
         } else {
             ctx->prof_truncated = true;
         }
     }
-    if (x_split) hipLaunchKernelGGL(stem_pool_f16x3_kernel<true>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
+    amp::ProfLaunchScope timed(rec ? rec->e0 : nullptr, rec ? rec->e1 : nullptr);      // attached to the launch below (AMP_TIMED_LAUNCH)
+    if (x_split) AMP_TIMED_LAUNCH(stem_pool_f16x3_kernel<true>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
                                     (unsigned int)x_bytes, (unsigned int)w_bytes);
-    else hipLaunchKernelGGL(stem_pool_f16x3_kernel<false>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
+    else AMP_TIMED_LAUNCH(stem_pool_f16x3_kernel<false>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
                             (unsigned int)x_bytes, (unsigned int)w_bytes);
     AMP_HIP_CHECK(hipGetLastError());
-    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     return AMP_OK;
 }
 
@@ -2305,11 +2304,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)cpg;   // useful work
             rec->variant = (!a.grouped && a.Cout > 64 && (a.Cin % BK != 0 || ntm * amp::cdiv(a.Cout, 128) >= 512)) ? 0 : 1;
-            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
         } else {
             ctx->prof_truncated = true;
         }
     }
+    amp::ProfLaunchScope timed(rec ? rec->e0 : nullptr, rec ? rec->e1 : nullptr);      // the convolution kernel launched below carries the events
     const size_t x_bytes = (size_t)a.B * a.H * a.W * a.Cin * sizeof(float);
     const size_t w_bytes = (size_t)a.Cout * a.K * sizeof(float);
     // LDS-DMA kernel: every layer but the stem (Cin = 4); buffers must stay below the out-of-range marker (2 GiB)
@@ -2437,17 +2436,16 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         a.ntn = amp::cdiv(a.Cout, 128);
         a.nblk = ntm * a.ntn;
         switch (g_conv_ablate) {
-            case 1: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 1>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
-            case 2: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 2>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
-            case 3: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 3>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
-            default: hipLaunchKernelGGL((conv_mfma_kernel<BM, 128, 0>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+            case 1: AMP_TIMED_LAUNCH((conv_mfma_kernel<BM, 128, 1>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            case 2: AMP_TIMED_LAUNCH((conv_mfma_kernel<BM, 128, 2>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            case 3: AMP_TIMED_LAUNCH((conv_mfma_kernel<BM, 128, 3>), dim3(a.nblk), dim3(256), 0, ctx->stream, a); break;
+            default: AMP_TIMED_LAUNCH((conv_mfma_kernel<BM, 128, 0>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
         }
     } else {
         a.ntn = 1;
         a.nblk = ntm;
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, 64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
+        AMP_TIMED_LAUNCH((conv_mfma_kernel<BM, 64>), dim3(a.nblk), dim3(256), 0, ctx->stream, a);
     }
     AMP_HIP_CHECK(hipGetLastError());
-    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
     return AMP_OK;
 }

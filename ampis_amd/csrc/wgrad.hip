@@ -627,9 +627,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
 
 template <bool XS, bool BIAS>
 void launch_wgrad_f16x3_v(const WgradArgs& a, int blocks, int dy_shift, int x_shift, float sc, float osc, hipStream_t st, int* flag) {
-    if (dy_shift) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-    else if (x_shift && !XS) hipLaunchKernelGGL((wgrad_f16x3_kernel<2, false, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-    else hipLaunchKernelGGL((wgrad_f16x3_kernel<0, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    if (dy_shift) AMP_TIMED_LAUNCH((wgrad_f16x3_kernel<1, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else if (x_shift && !XS) AMP_TIMED_LAUNCH((wgrad_f16x3_kernel<2, false, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+    else AMP_TIMED_LAUNCH((wgrad_f16x3_kernel<0, XS, BIAS>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
 }
 // fmt: bit 0 = x in the split row format, bit 1 = dy in the split row format AND already multiplied by 2^dy_shift
 void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shift, hipStream_t st, int* flag, int fmt = 0) {
@@ -637,8 +637,8 @@ void launch_wgrad_f16x3(const WgradArgs& a, int blocks, int dy_shift, int x_shif
     const float sc = ldexpf(1.0f, sh), osc = ldexpf(1.0f, -sh);     // exact powers of two
     const bool bias = a.bias_partial != nullptr;
     if (fmt & 2) {          // (no bias sums from a scaled split dy: the FrozenBN convolutions that use it have none)
-        if (fmt & 1) hipLaunchKernelGGL((wgrad_f16x3_kernel<1, true, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
-        else hipLaunchKernelGGL((wgrad_f16x3_kernel<1, false, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+        if (fmt & 1) AMP_TIMED_LAUNCH((wgrad_f16x3_kernel<1, true, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
+        else AMP_TIMED_LAUNCH((wgrad_f16x3_kernel<1, false, false, true>), dim3(blocks), dim3(256), 0, st, a, sc, osc, flag);
     } else if (fmt & 1) { if (bias) launch_wgrad_f16x3_v<true, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<true, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
     else { if (bias) launch_wgrad_f16x3_v<false, true>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); else launch_wgrad_f16x3_v<false, false>(a, blocks, dy_shift, x_shift, sc, osc, st, flag); }
 }
@@ -954,11 +954,12 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)M * (double)a.N * (double)a.Kp;
             rec->variant = 2;
-            AMP_HIP_CHECK(hipEventRecord(rec->e0, ctx->stream));
         } else {
             ctx->prof_truncated = true;
         }
     }
+    {
+    amp::ProfLaunchScope timed(rec ? rec->e0 : nullptr, rec ? rec->e1 : nullptr);      // the MFMA kernel below carries the events (not the reduce pass)
     static const bool ring_on = getenv("AMP_NO_WGRAD_RING") == nullptr;      // EXPERIMENT switch
     if (ctx->conv_mode == AMP_CONV_F16X3 && ring_on && (x_split & 3) == 3 && ring_shape(a.N, a.Cin, a.Kp)) {
         // both operands in the split row format: LDS-DMA ring + transposing reads (wgrad_split_kernel), 128 x 256 tiles.  The slab count
@@ -969,14 +970,14 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
         const int rtiles = r.ntn * r.ntc;
         r.nsplit = pick_nsplit_ring(M, rtiles);      // (amp_conv_wgrad_scratch_floats reserves the larger of the two slab counts)
         r.rows_per_split = amp::cdiv(amp::cdiv(r.M, r.nsplit), BKW) * BKW;
-        hipLaunchKernelGGL(wgrad_split_kernel, dim3(rtiles * r.nsplit), dim3(512), 0, ctx->stream, r, ldexpf(1.0f, -dy_shift), ctx->d_conv_flag);
+        AMP_TIMED_LAUNCH(wgrad_split_kernel, dim3(rtiles * r.nsplit), dim3(512), 0, ctx->stream, r, ldexpf(1.0f, -dy_shift), ctx->d_conv_flag);
         a.nsplit = r.nsplit;                       // the reduce below adds this many slabs
     } else if (ctx->conv_mode == AMP_CONV_F16X3) {
         launch_wgrad_f16x3(a, tiles * a.nsplit, dy_shift, x_shift, ctx->stream, ctx->d_conv_flag, x_split);   // the fp32 kernel needs no shift
     } else {
-        hipLaunchKernelGGL(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
+        AMP_TIMED_LAUNCH(wgrad_mfma_kernel, dim3(tiles * a.nsplit), dim3(256), 0, ctx->stream, a);
     }
-    if (rec) AMP_HIP_CHECK(hipEventRecord(rec->e1, ctx->stream));
+    }
     const size_t nk = (size_t)a.N * a.Kp;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, ctx->stream, scratch,
                        a.nsplit, nk, a.Kp, scale, grad, accumulate, a.bias_partial, a.N, bias_grad, bias_accumulate);

@@ -78,7 +78,9 @@ PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 # register-only back-to-back v_mfma_f32_32x32x16_f16 on random operands 1655 TFLOP/s, on constant operands 2475; the fp32 MFMA holds
 # 155 either way).  Reported beside `peak`, never instead of it.
 SUSTAINED_F16_MFMA_RANDOM_TFLOPS = 1655.0
-PROF_EVERY = 5                 # HIP-event pairs around the conv launches on every 5th timed step
+PROF_EVERY = 10                # timed launches (events attached to the dispatch) on every 10th timed step: an attached event still costs ~8 us of idle GPU per
+                               # launch (0.8 ms on a sampled inference step, rocprofv3 trace), i.e. 0.08 ms per step on average at this cadence; 5 of the
+                               # default 50 steps = 270 launches of the dominant kernel
 
 
 def log(msg):
@@ -472,8 +474,8 @@ def main(args):
             step()
             log(f"[{mode}] warmup step {i}: {(time.perf_counter() - t) * 1e3:.1f} ms")
         ranks.barrier()
-        # per-launch HIP event pairs on every PROF_EVERY-th timed step: the pairs themselves cost ~5 us of idle GPU per launch (0.55 ms
-        # = 2.7 % of a step when every step carries them)
+        # per-launch HIP events on every PROF_EVERY-th timed step: they cost ~8 us of idle GPU per launch (0.8 ms
+        # = 4.7 % of a step when every step carries them)
         ctx.prof_begin(max_launches=(steps // PROF_EVERY + 1) * 96)
         t0 = time.perf_counter()
         ndet = 0

@@ -1,4 +1,5 @@
 set -e
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_conv_modes_gpu.py tests/test_e2e_gpu.py tests/test_x101_gpu.py -x -q > gpurun_out/r3_ring_tests.log 2>&1 || { tail -30 gpurun_out/r3_ring_tests.log; exit 1; }
-tail -2 gpurun_out/r3_ring_tests.log
-bash tools/kstat_quick.sh kq11 | grep "conv_glds\|all kernels"
+OUT=$GRAFT_REPO_ROOT/gpurun_out/trace1; rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --train-steps 0 --x101-steps 0 --no-two-pipelines --no-host-inclusive --no-strict > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+ls $OUT/*/ | head -3
