@@ -91,6 +91,7 @@ struct amp_model {
     int rle_mode = 0;                   // amp_model_set_rle_output: 0 run lengths, 1 counts strings (encoded on the device), 2 both
     char* h_str = nullptr;              // pinned: the counts strings of one call
     size_t h_str_bytes = 0;
+    size_t str_bytes_last = 0;      // bytes of counts strings the previous inference produced (the size of the speculative read-back)
     std::vector<unsigned long long> r_str_off;
     std::vector<int> r_str_len;
     std::vector<int> r_out_h, r_out_w;
@@ -726,9 +727,17 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     const float* hb = nullptr; const float* hs = nullptr; const int* hv = nullptr; const int* hc = nullptr; const int* hl = nullptr;
     const unsigned long long* ho = nullptr;
     const unsigned long long* hso = nullptr; const int* hsl = nullptr;
+    bool str_tail_done = false;
     if (N > 0) {
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_res, ws.base + res0, res1 - res0, hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        // The strings' size is only known after this block has arrived, and a second copy behind a second synchronisation is 30 us of
+        // idle GPU: copy what the previous call needed plus a margin along with the block, and only a longer tail afterwards.
+        size_t str_guess = 0;
+        if (m->rle_mode && m->str_bytes_last) {
+            str_guess = std::min<size_t>({(size_t)str_cap, m->h_str_bytes, m->str_bytes_last + m->str_bytes_last / 8 + 4096});
+            AMP_HIP_CHECK(hipMemcpyAsync(m->h_str, str_pool, str_guess, hipMemcpyDeviceToHost, ctx->stream));
+        }
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (m->h_counts[B + 1]) { amp::set_error("amp_model_infer: RLE pool (%zu counts) exhausted; raise cfg.rle_pool_counts", (size_t)c.rle_pool_counts); return AMP_ERR_NOMEM; }
         hb = (const float*)host_of(o_boxes); hs = (const float*)host_of(m_scores); hc = (const int*)host_of(m_classes);
@@ -742,11 +751,13 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
                                std::min<unsigned long long>(str_cap, m->h_str_bytes));
                 return AMP_ERR_NOMEM;
             }
-            if (sbytes) AMP_HIP_CHECK(hipMemcpyAsync(m->h_str, str_pool, (size_t)sbytes, hipMemcpyDeviceToHost, ctx->stream));
+            m->str_bytes_last = (size_t)sbytes;
+            if (sbytes > str_guess) AMP_HIP_CHECK(hipMemcpyAsync(m->h_str + str_guess, str_pool + str_guess, (size_t)sbytes - str_guess, hipMemcpyDeviceToHost, ctx->stream));
+            else str_tail_done = true;
         }
         // the pool holds run lengths only (positions live in their own scratch pool): the used prefix is exactly what the caller gets
         if (m->rle_mode == 1) {
-            AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // strings only: the run lengths stay on the device
+            if (!str_tail_done) AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // strings only: the run lengths stay on the device
             m->r_pool_ptr = nullptr;
         } else if (m->h_pool && used <= m->h_pool_counts) {
             // DMA into host-cacheable pinned memory and hand that out: a pageable destination made the runtime stage the bytes and
