@@ -105,8 +105,13 @@ __global__ void gather_dets_kernel(int B, int cap, int D, const float* sboxes, c
 // compact list of the detections of a batch: row off[b] + i <- (image b, detection i), off = exclusive prefix of min(count, D)
 __global__ void compact_dets_kernel(int B, int D, const int* __restrict__ det_count, const float* __restrict__ det_boxes,
                                     const float* __restrict__ det_scores, const int* __restrict__ det_classes, float* __restrict__ boxes,
-                                    float* __restrict__ scores, int* __restrict__ classes, int* __restrict__ batch) {
+                                    float* __restrict__ scores, int* __restrict__ classes, int* __restrict__ batch, int* __restrict__ n_total) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && n_total) {          // the length of the compact list, for kernels that are queued before the host knows it
+        int s = 0;
+        for (int q = 0; q < B; ++q) s += min(det_count[q], D);
+        *n_total = s;
+    }
     if (t >= B * D) return;
     const int b = t / D, i = t - b * D;
     if (i >= min(det_count[b], D)) return;
@@ -126,12 +131,7 @@ extern "C" {
 
 int amp_compact_dets(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
                      float* boxes, float* scores, int* classes, int* batch) {
-    AMP_REQUIRE(ctx && det_count && det_boxes && det_scores && det_classes && boxes && scores && classes && batch && B >= 1 && D >= 1,
-                "amp_compact_dets: bad argument");
-    hipLaunchKernelGGL(compact_dets_kernel, dim3(amp::cdiv(B * D, 256)), dim3(256), 0, ctx->stream, B, D, det_count, det_boxes, det_scores,
-                       det_classes, boxes, scores, classes, batch);
-    AMP_HIP_CHECK(hipGetLastError());
-    return AMP_OK;
+    return amp::compact_dets_run(ctx, B, D, det_count, det_boxes, det_scores, det_classes, boxes, scores, classes, batch, nullptr);
 }
 
 
@@ -150,6 +150,16 @@ int amp_box_candidates_sized(amp_ctx* ctx, const float* pred, int ld, const floa
 }
 
 }  // extern "C"
+
+int amp::compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
+                          float* boxes, float* scores, int* classes, int* batch, int* n_total) {
+    AMP_REQUIRE(ctx && det_count && det_boxes && det_scores && det_classes && boxes && scores && classes && batch && B >= 1 && D >= 1,
+                "amp_compact_dets: bad argument");
+    hipLaunchKernelGGL(compact_dets_kernel, dim3(amp::cdiv(B * D, 256)), dim3(256), 0, ctx->stream, B, D, det_count, det_boxes, det_scores,
+                       det_classes, boxes, scores, classes, batch, n_total);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
 
 // thresh_img: optional device [B] per-image score floors (model.hip raises them for an image with more than ccap candidates)
 int amp::box_candidates_run(amp_ctx* ctx, const float* pred, int ld, const float* proposals, const int* prop_count, int B, int Rcap, int K,

@@ -176,6 +176,8 @@ int weight_jobs_run(amp_ctx* ctx, const WeightJob* jobs_dev, const void* chunks_
 int sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchunks, float* p, const float* g, float* v, float lr,
                    float momentum, float weight_decay, float grad_scale);
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);
+int compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
+                     float* boxes, float* scores, int* classes, int* batch, int* n_total /* device, optional: length of the compact list */);   // box_infer.hip
 // conv.hip: stem conv + ReLU + max-pool fused (AMP_CONV_F16X3, pre-split weights); returns 1 when it does not apply (caller: conv, then maxpool_run)
 // x_split: the input pixels are in preprocess_run's split form (16 B = 4 hi halves | 4 lo' halves)
 int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_split, const float* w_split, const float* scale, const float* shift,

@@ -91,6 +91,7 @@ struct amp_model {
     int rle_mode = 0;                   // amp_model_set_rle_output: 0 run lengths, 1 counts strings (encoded on the device), 2 both
     char* h_str = nullptr;              // pinned: the counts strings of one call
     size_t h_str_bytes = 0;
+    hipEvent_t ev_counts = nullptr;     // marks the arrival of the detection counts on the host (run(): the wait that is not a stream sync)
     size_t str_bytes_last = 0;      // bytes of counts strings the previous inference produced (the size of the speculative read-back)
     std::vector<unsigned long long> r_str_off;
     std::vector<int> r_str_len;
@@ -571,6 +572,38 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_ALLOC(det_scores, float, (size_t)B * D);
     AMP_ALLOC(det_classes, int, (size_t)B * D);
     AMP_ALLOC(d_floor, float, (size_t)B);          // per-image score floors (only used when an image has more than ccap candidates)
+    const int Ncap = std::max(B * D, 1);
+    // compact detection list over the batch (allocated for B * D detections: its first kernels are queued before the host knows the count).  Everything the host reads back at the end sits in ONE contiguous block of the
+    // workspace ([res0, res1): scores, classes, rescaled boxes, validity, run offsets / lengths, pool fill) and comes back with one
+    // copy into pinned memory: eight pageable copies cost 0.3 ms of idle GPU per step.
+    AMP_ALLOC(m_boxes, float, (size_t)Ncap * 4);
+    AMP_ALLOC(m_batch, int, (size_t)Ncap);
+    AMP_ALLOC(d_out_hw, int, (size_t)2 * B);
+    AMP_ALLOC(mpooled, float, (size_t)Ncap * 196 * 256);
+    AMP_ALLOC(mt_a, float, (size_t)Ncap * 196 * 256);
+    AMP_ALLOC(mt_b, float, (size_t)Ncap * 784 * 256);
+    const int Kp = (K + 3) / 4 * 4;
+    AMP_ALLOC(mlogits, float, (size_t)Ncap * 784 * Kp);
+    AMP_ALLOC(mprob, float, (size_t)Ncap * 784);
+    const size_t res0 = (ws.off + 255) & ~(size_t)255;
+    AMP_ALLOC(m_scores, float, (size_t)Ncap);
+    AMP_ALLOC(m_classes, int, (size_t)Ncap);
+    AMP_ALLOC(o_boxes, float, (size_t)Ncap * 4);
+    AMP_ALLOC(o_valid, int, (size_t)Ncap);
+    AMP_ALLOC(o_off, unsigned long long, (size_t)Ncap);
+    AMP_ALLOC(o_len, int, (size_t)Ncap);
+    AMP_ALLOC(pool_used, unsigned long long, 2);      // [0] run lengths (read back), [1] position scratch
+    AMP_ALLOC(o_soff, unsigned long long, (size_t)Ncap);   // counts strings (rle_mode != 0): offset / length per detection, bytes in all
+    AMP_ALLOC(o_slen, int, (size_t)Ncap);
+    AMP_ALLOC(str_total, unsigned long long, 1);
+    const size_t res1 = ws.off;
+    AMP_ALLOC(rle_pool, unsigned int, (size_t)c.rle_pool_counts);
+    AMP_ALLOC(pos_pool, unsigned int, (size_t)c.rle_pool_counts);
+    const unsigned long long str_cap = (unsigned long long)c.rle_pool_counts * 4;      // bytes: a run needs 1-7 characters, 1.3 on average
+    AMP_ALLOC(str_pool, char, (size_t)str_cap);
+    AMP_ALLOC(d_ntotal, int, 1);
+    bool mask_queued = false;     // compact list + mask RoIAlign already on the stream
+    bool mchain = false;
     if (!dry) {
         const bool bchain = split_chain(m, {"roi_heads.box_head.fc1", "roi_heads.box_head.fc2"});
         AMP_TRY(amp::roi_align_run(ctx, &ff, prop_boxes, m->d_batch_iota, nullptr, R, 7, pooled, nullptr, bchain ? 1 : 0, T.feat_split ? 1 : 0));
@@ -596,8 +629,23 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         // ---------------- sync point: detection counts decide the mask-branch GEMM sizes ----------------
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts, det_count, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         AMP_HIP_CHECK(hipMemcpyAsync(m->h_counts + B, m->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // The host needs the counts for the GEMM sizes of the mask head, the GPU does not need the host for what comes first: the compact
+        // detection list and the mask pooler read the counts on the device and are queued BEFORE the wait, so the ~50 us round trip (copy
+        // lands -> host wakes -> next launches arrive) passes under 0.3 ms of RoIAlign instead of an idle GPU.
+        if (!m->ev_counts) AMP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_counts, hipEventDisableTiming));
+        AMP_HIP_CHECK(hipEventRecord(m->ev_counts, ctx->stream));
+        AMP_REQUIRE(res1 - res0 <= m->h_res_bytes, "amp_model_infer: result staging too small");
+        mchain = split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2", "roi_heads.mask_head.mask_fcn3",
+                                 "roi_heads.mask_head.mask_fcn4", "roi_heads.mask_head.deconv"});
+        auto queue_mask_inputs = [&]() -> int {
+            AMP_TRY(amp::compact_dets_run(ctx, B, D, det_count, det_boxes, det_scores, det_classes, m_boxes, m_scores, m_classes, m_batch, d_ntotal));
+            return amp::roi_align_run(ctx, &ff, m_boxes, m_batch, d_ntotal, Ncap, 14, mpooled, nullptr, mchain ? 1 : 0, T.feat_split ? 1 : 0);
+        };
+        AMP_TRY(queue_mask_inputs());
+        mask_queued = true;
+        AMP_HIP_CHECK(hipEventSynchronize(m->ev_counts));
         if (m->h_counts[B + 0]) {
+            mask_queued = false;      // the detections are about to be recomputed: the compact list and the pooled features with them
             // An image has more than ccap candidates above SCORE_THRESH_TEST (many classes, a low threshold).  Greedy NMS takes its
             // decisions in score order, so the detections are decided by a PREFIX of the candidate list: raise that image's score floor
             // (bisection on the candidate count) until the prefix fits, run the chain again, and the result is the exact one as long as
@@ -638,6 +686,8 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
                     return AMP_ERR_NOMEM;
                 }
             if (m->h_counts[B + 0]) { amp::set_error("amp_model_infer: box candidates overflowed after the score floor was raised"); return AMP_ERR_STATE; }
+            AMP_TRY(queue_mask_inputs());
+            mask_queued = true;
         }
     }
 
@@ -648,36 +698,7 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
         N = off[B];
     }
 
-    // compact detection list over the batch.  Everything the host reads back at the end sits in ONE contiguous block of the
-    // workspace ([res0, res1): scores, classes, rescaled boxes, validity, run offsets / lengths, pool fill) and comes back with one
-    // copy into pinned memory: eight pageable copies cost 0.3 ms of idle GPU per step.
-    AMP_ALLOC(m_boxes, float, (size_t)std::max(N, 1) * 4);
-    AMP_ALLOC(m_batch, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(d_out_hw, int, (size_t)2 * B);
-    AMP_ALLOC(mpooled, float, (size_t)std::max(N, 1) * 196 * 256);
-    AMP_ALLOC(mt_a, float, (size_t)std::max(N, 1) * 196 * 256);
-    AMP_ALLOC(mt_b, float, (size_t)std::max(N, 1) * 784 * 256);
-    const int Kp = (K + 3) / 4 * 4;
-    AMP_ALLOC(mlogits, float, (size_t)std::max(N, 1) * 784 * Kp);
-    AMP_ALLOC(mprob, float, (size_t)std::max(N, 1) * 784);
-    const size_t res0 = (ws.off + 255) & ~(size_t)255;
-    AMP_ALLOC(m_scores, float, (size_t)std::max(N, 1));
-    AMP_ALLOC(m_classes, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(o_boxes, float, (size_t)std::max(N, 1) * 4);
-    AMP_ALLOC(o_valid, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(o_off, unsigned long long, (size_t)std::max(N, 1));
-    AMP_ALLOC(o_len, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(pool_used, unsigned long long, 2);      // [0] run lengths (read back), [1] position scratch
-    AMP_ALLOC(o_soff, unsigned long long, (size_t)std::max(N, 1));   // counts strings (rle_mode != 0): offset / length per detection, bytes in all
-    AMP_ALLOC(o_slen, int, (size_t)std::max(N, 1));
-    AMP_ALLOC(str_total, unsigned long long, 1);
-    const size_t res1 = ws.off;
-    AMP_ALLOC(rle_pool, unsigned int, (size_t)c.rle_pool_counts);
-    AMP_ALLOC(pos_pool, unsigned int, (size_t)c.rle_pool_counts);
-    const unsigned long long str_cap = (unsigned long long)c.rle_pool_counts * 4;      // bytes: a run needs 1-7 characters, 1.3 on average
-    AMP_ALLOC(str_pool, char, (size_t)str_cap);
     if (dry) return AMP_OK;
-    AMP_REQUIRE(res1 - res0 <= m->h_res_bytes, "amp_model_infer: result staging too small");
 
     m->r_out_h.assign(out_h, out_h + B);
     m->r_out_w.assign(out_w, out_w + B);
@@ -688,12 +709,9 @@ int run(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const int* out
     AMP_HIP_CHECK(hipMemcpyAsync(d_out_hw, m->h_small, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     AMP_HIP_CHECK(hipMemsetAsync(pool_used, 0, 2 * sizeof(unsigned long long), ctx->stream));
     if (N > 0) {
-        AMP_TRY(amp_compact_dets(ctx, B, D, det_count, det_boxes, det_scores, det_classes, m_boxes, m_scores, m_classes, m_batch));
-        // ---------------- mask head ----------------
-        const bool mchain = split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2", "roi_heads.mask_head.mask_fcn3",
-                                            "roi_heads.mask_head.mask_fcn4", "roi_heads.mask_head.deconv"});
+        // ---------------- mask head (the compact list and the pooled features are on the stream already) ----------------
+        AMP_REQUIRE(mask_queued, "amp_model_infer: internal: the mask branch's inputs were not queued");
         const int io = mchain ? 3 : 0;      // split in, split out
-        AMP_TRY(amp::roi_align_run(ctx, &ff, m_boxes, m_batch, nullptr, N, 14, mpooled, nullptr, mchain ? 1 : 0, T.feat_split ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn1"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn2"), mt_a, N, 14, 14, 1, 1, true, 0, nullptr, 0, mpooled, io));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.mask_fcn3"), mpooled, N, 14, 14, 1, 1, true, 0, nullptr, 0, mt_a, io));
@@ -1539,6 +1557,7 @@ void amp_model_destroy(amp_model* m) {
     (void)hipHostFree(m->h_res);
     if (m->h_pool) (void)hipHostFree(m->h_pool);
     if (m->h_str) (void)hipHostFree(m->h_str);
+    if (m->ev_counts) (void)hipEventDestroy(m->ev_counts);
     delete m;
 }
 
