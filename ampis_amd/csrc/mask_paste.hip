@@ -267,6 +267,8 @@ __global__ __launch_bounds__(PT2) void paste_rle_seg_kernel(const PasteArgs a) {
     int* row_i0 = s_misc + 8;                                            // [max_rows]
     float* row_w1 = reinterpret_cast<float*>(row_i0 + a.max_rows);       // [max_rows]
     int* ucnt = reinterpret_cast<int*>(row_w1 + a.max_rows);             // [max(MAX_UNITS, max_rows)]: transitions per unit, index cx * nseg + seg
+    // the bits of a unit (segments of <= 64 rows): pass 2 walks the transitions of the stored word instead of evaluating every pixel again
+    unsigned long long* ubits = reinterpret_cast<unsigned long long*>(ucnt + ((max(MAX_UNITS, a.max_rows) + 1) & ~1));   // [MAX_UNITS]
 
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(PT2) void paste_rle_seg_kernel(const PasteArgs a) {
     const int SEG = (ny + nseg - 1) / nseg;
     nseg = (ny + SEG - 1) / SEG;
     const int nunits = nx * nseg;
+    const bool keep_bits = SEG <= 64 && nunits <= MAX_UNITS;
 
     for (int i = tid; i < MS * MS; i += PT2) sp[i] = a.prob[(size_t)n * MS * MS + i];
     for (int i = tid; i < ny; i += PT2) {
@@ -324,13 +327,16 @@ __global__ __launch_bounds__(PT2) void paste_rle_seg_kernel(const PasteArgs a) {
         const int x = x0i + cx;
         const Axis ax = axis_param(x, x0, x1);
         const int iy0 = seg * SEG, iy1 = min(iy0 + SEG, ny);
-        int prev = bit_before(cx, x, ax, iy0);
+        const int first = bit_before(cx, x, ax, iy0);
+        int prev = first;
         int cnt = 0;
+        unsigned long long word = 0ull;
         ColTaps ct; ct.i0 = -(1 << 30);
         for (int iy = iy0; iy < iy1; ++iy) {
             Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
             const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
             cnt += bit ^ prev;          // (both are 0 / 1)
+            word |= (unsigned long long)(bit ^ prev) << ((iy - iy0) & 63);      // bit r: a transition in front of row iy0 + r
             prev = bit;
         }
         // closing transition back to 0 when the next pixel in linear order lies outside the region
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(PT2) void paste_rle_seg_kernel(const PasteArgs a) {
             else if (!(wrap && cx + 1 < nx) && x + 1 < W) cnt += 1;
         }
         ucnt[cx * nseg + seg] = cnt;
+        if (keep_bits) ubits[u] = word;
     }
     __syncthreads();
 
@@ -400,15 +407,29 @@ __global__ __launch_bounds__(PT2) void paste_rle_seg_kernel(const PasteArgs a) {
         const int x = x0i + cx;
         const Axis ax = axis_param(x, x0, x1);
         const int iy0 = seg * SEG, iy1 = min(iy0 + SEG, ny);
-        int prev = bit_before(cx, x, ax, iy0);
         int w = ucnt[cx * nseg + seg];
         const unsigned int base = (unsigned int)x * (unsigned int)H + (unsigned int)y0i;
-        ColTaps ct; ct.i0 = -(1 << 30);
-        for (int iy = iy0; iy < iy1; ++iy) {
-            Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
-            const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
-            if (bit != prev) posbuf[w++] = base + (unsigned int)iy;
-            prev = bit;
+        int prev;
+        if (keep_bits) {
+            // the transitions of the unit were recorded in pass 1: a few set bits instead of iy1 - iy0 evaluations
+            unsigned long long word = ubits[u];
+            const int ntr = __popcll(word);
+            while (word) {
+                const int r = __builtin_ctzll(word);
+                word &= word - 1ull;
+                posbuf[w++] = base + (unsigned int)(iy0 + r);
+            }
+            // the unit's last bit = the bit in front of it, flipped once per transition
+            prev = (bit_before(cx, x, ax, iy0) + ntr) & 1;
+        } else {
+            prev = bit_before(cx, x, ax, iy0);
+            ColTaps ct; ct.i0 = -(1 << 30);
+            for (int iy = iy0; iy < iy1; ++iy) {
+                Axis ay; ay.i0 = row_i0[iy]; ay.w1 = row_w1[iy];
+                const int bit = paste_bit_cached(sp, ax, ay, thr, ct);
+                if (bit != prev) posbuf[w++] = base + (unsigned int)iy;
+                prev = bit;
+            }
         }
         if (iy1 == ny && prev == 1) {
             if (y1i < H) posbuf[w++] = (unsigned int)x * (unsigned int)H + (unsigned int)y1i;
@@ -471,7 +492,8 @@ int amp_paste_rle_sized(amp_ctx* ctx, const float* prob, const float* det_boxes,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(paste_rle_kernel, dim3(N), dim3(PT), smem, ctx->stream, a);
     } else {
-        const size_t smem = (size_t)(MS * MS + PT2 + 8) * 4 + (size_t)a.max_rows * 8 + (size_t)std::max(MAX_UNITS, a.max_rows) * 4;
+        const size_t smem = (size_t)(MS * MS + PT2 + 8) * 4 + (size_t)a.max_rows * 8 + (size_t)((std::max(MAX_UNITS, a.max_rows) + 1) & ~1) * 4 + 8 +
+                            (size_t)MAX_UNITS * 8;
         AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(paste_rle_seg_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(paste_rle_seg_kernel, dim3(N), dim3(PT2), smem, ctx->stream, a);
