@@ -183,6 +183,9 @@ int compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const flo
 int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_split, const float* w_split, const float* scale, const float* shift,
                   float* pool, int pool_split);
 bool stem_pool_applies(amp_ctx* ctx, const float* w_split);     // would stem_pool_run launch the fused kernel (mode, switches)?
+bool stem_u8_applies(amp_ctx* ctx, const float* w_split);       // ... and straight from the uint8 image (stem_pool_u8_kernel: no preprocess pass)?
+int stem_pool_u8_run(amp_ctx* ctx, const uint8_t* img, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std_[3],
+                     const int* img_hw, const float* w_split, const float* scale, const float* shift, float* pool, int pool_split);
 int preprocess_run(amp_ctx* ctx, const uint8_t* img_bgr, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std[3],
                    const int* img_hw, float* out, int out_split);   // pointwise.hip   // pointwise.hip: y_split = 1 writes split rows
 // fmt bit 0: x is in the split hi|lo' row format (written by a producer with bit 1); bit 1: write y in that format (AMP_CONV_F16X3

@@ -2200,6 +2200,202 @@ extern "C" int amp_group_expand_weights(amp_ctx* ctx, const float* w, int Cout, 
     return AMP_OK;
 }
 
+// stem_pool_u8_kernel: the fused stem + pool straight from the uint8 image.  stem_pool_f16x3_kernel fetches its A tile from the
+// preprocessed [B,H,W,4] tensor once per kernel row: 2.1 GB of L2 -> LDS traffic per batch for 134 MB of pixels (every input pixel is
+// the tap of ~12 convolution outputs of a tile, seven K-steps over), after a kernel that wrote those 134 MB.  Here a workgroup reads the
+// 39 x 36 input pixels under its 17 x 15 convolution patch ONCE -- three bytes each, normalised and split exactly as preprocess_kernel<true>
+// does -- into two LDS planes (hi halves, lo' halves: 8 B per pixel each), and the MFMA A fragments are read straight out of the planes:
+// a lane's 8 consecutive k of kernel row ky are taps 2 lq, 2 lq + 1 x 4 channels = the 16 bytes at pixel (2 pr + ky, 2 pc + 2 lq) of a
+// plane (stride-2 pixels: 16 lanes cover 256 contiguous bytes, conflict-free).  No A staging, no preprocess pass, only the 8-KB weight
+// tile per K-step by LDS-DMA.  Same products, same 7 K-steps in the same order: the pooled tensor is bit-identical.
+constexpr int SP_IH = 2 * (SP_CH - 1) + 7, SP_IW = 2 * (SP_CW - 1) + 8;      // 39 x 36 input pixels (the 8th tap of a row has zero weights)
+struct StemU8Args {
+    const uint8_t* img;       // [B][H][W][3] BGR
+    int H, W;                 // image size (the padded size the conv sees is a.H x a.W; beyond the valid size everything is 0)
+    const int* img_hw;        // optional device [B][2]: per-image valid size
+    float m0, m1, m2, s0, s1, s2;
+};
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_u8_kernel(const ConvArgs a, const StemPoolArgs sp, const StemU8Args u,
+                                                                                                       const unsigned int w_bytes) {
+    constexpr int BM = 256, BN = 64;
+    constexpr int WTM = 64, WTN = 32, NWN = 2;      // 8 waves: 4 x 2 wave tiles
+    constexpr int SLD = BN + 4;
+    constexpr int PLANE_BYTES = SP_IH * SP_IW * 8;                 // 11 232
+    constexpr int BT_FLOATS = BN * BK;                              // one weight tile: 64 rows x 128 B
+    constexpr int NKS = 7;                                          // kernel rows = K-steps: ALL weight tiles are resident (57 KB), so the K loop
+    constexpr int OPER_BYTES = 2 * PLANE_BYTES + NKS * BT_FLOATS * 4;   // has no barrier and no wait (a K-step is 0.2 us of MFMAs, a weight DMA 1.1 us)
+    constexpr int LDS_BYTES = (OPER_BYTES > BM * SLD * 4) ? OPER_BYTES : BM * SLD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    unsigned char* plane_hi = lds_raw;
+    unsigned char* plane_lo = lds_raw + PLANE_BYTES;
+    float* Bt = reinterpret_cast<float*>(lds_raw + 2 * PLANE_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int tx = blockIdx.x % sp.tiles_x;
+    const int tyb = blockIdx.x / sp.tiles_x;
+    const int ty = tyb % sp.tiles_y, b = tyb / sp.tiles_y;
+    const int oy_first = 2 * ty * SP_PH - 1, ox_first = 2 * tx * SP_PW - 1;      // conv pixel of patch row 0 / column 0
+    const int iy_first = 2 * oy_first - 3, ix_first = 2 * ox_first - 3;           // input pixel of plane row 0 / column 0
+
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned int b_voff;
+    {
+        const int r = wave * 8 + srow;
+        b_voff = (r < a.Cout) ? (unsigned int)(((size_t)r * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+    auto stage_b = [&](int kstep, int buf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bt + buf * BT_FLOATS + (wave * 8) * BK), 16, (int)b_voff,
+                                                 kstep * (BK * 4), 0, 0);
+    };
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) stage_b(ks, ks);
+
+    // ---- the input patch: normalise (preprocess_kernel's operations) and split into the two planes ----
+    {
+        const int vh = u.img_hw ? u.img_hw[2 * b] : u.H, vw = u.img_hw ? u.img_hw[2 * b + 1] : u.W;
+        const uint8_t* ib = u.img + (size_t)b * u.H * u.W * 3;
+        constexpr int NPX = (SP_IH * SP_IW + 511) / 512;            // pixels per thread: all their byte loads are issued before the first use
+        unsigned char pxb[NPX][3];
+        bool pv[NPX];
+#pragma unroll
+        for (int t = 0; t < NPX; ++t) {
+            const int q = tid + 512 * t;
+            const int r = q / SP_IW, cidx = q - r * SP_IW;
+            const int iy = iy_first + r, ix = ix_first + cidx;
+            pv[t] = q < SP_IH * SP_IW && (unsigned)iy < (unsigned)vh && (unsigned)ix < (unsigned)vw;
+            const uint8_t* px = ib + ((size_t)(pv[t] ? iy : 0) * u.W + (pv[t] ? ix : 0)) * 3;
+            pxb[t][0] = px[0]; pxb[t][1] = px[1]; pxb[t][2] = px[2];
+        }
+#pragma unroll
+        for (int t = 0; t < NPX; ++t) {
+            const int q = tid + 512 * t;
+            f16x4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+            if (pv[t]) {
+                float v[3];
+                v[0] = __fdiv_rn(__fsub_rn((float)pxb[t][0], u.m0), u.s0);
+                v[1] = __fdiv_rn(__fsub_rn((float)pxb[t][1], u.m1), u.s1);
+                v[2] = __fdiv_rn(__fsub_rn((float)pxb[t][2], u.m2), u.s2);
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const _Float16 h = (_Float16)v[e];
+                    hi[e] = h;
+                    lo[e] = (_Float16)((v[e] - (float)h) * LO_SCALE);
+                }
+            }
+            if (q < SP_IH * SP_IW) {
+                *reinterpret_cast<f16x4*>(plane_hi + q * 8) = hi;
+                *reinterpret_cast<f16x4*>(plane_lo + q * 8) = lo;
+            }
+        }
+    }
+
+    constexpr int MB = WTM / 16, NB = WTN / 16;
+    f32x4 acc[MB][NB], acx[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+    int a_off[MB];                                   // byte offset of this lane's A fragment inside a plane, kernel row 0
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int r = wm * WTM + i * 16 + l15;
+        const int pr = min(r / SP_CW, SP_CH - 1), pc = r - (r / SP_CW) * SP_CW;      // (row 255 is no patch pixel: it reads patch row 16, its result is dropped)
+        a_off[i] = ((2 * pr) * SP_IW + 2 * pc + 2 * lq) * 8;
+    }
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // the weight tiles have landed
+    __syncthreads();                        // planes and weights complete
+#pragma unroll
+    for (int step = 0; step < NKS; ++step) {
+        const int cur = step;
+        F16x3Frags<MB, NB> f;
+        const int krow = step * (SP_IW * 8);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            f.ah[i] = *reinterpret_cast<const f16x8*>(plane_hi + a_off[i] + krow);
+            f.al[i] = *reinterpret_cast<const f16x8*>(plane_lo + a_off[i] + krow);
+        }
+        const float* Bs = Bt + cur * BT_FLOATS + (wn * WTN + l15) * BK;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            f.bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo16_hi);
+            f.bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo16_lo);
+        }
+        f16x3_mfma16<MB, NB>(f, acc, acx);
+    }
+    __syncthreads();                        // every wave is done with the planes and the weights: the patch takes their place
+
+    // ---- the patch: fold the cross terms, scale / shift / ReLU (conv_epilogue_rows' arithmetic), -1 for pixels outside the image ----
+    float* patch = reinterpret_cast<float*>(lds_raw);
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = wn * WTN + j * 16 + l15;
+        const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f, sh = (a.shift && n < a.Cout) ? a.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = wm * WTM + i * 16 + 4 * lq + e;
+                const int pr = r / SP_CW, pc = r - pr * SP_CW;
+                const bool v = pr < SP_CH && (unsigned)(oy_first + pr) < (unsigned)a.Ho && (unsigned)(ox_first + pc) < (unsigned)a.Wo;
+                const float s_ = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                bad = bad || !(fabsf(s_) <= 3.0e38f);
+                float t = __fadd_rn(__fmul_rn(s_, sc), sh);
+                if (a.relu) t = fmaxf(t, 0.f);
+                patch[r * SLD + n] = v ? t : -1.0f;
+            }
+    }
+    if (bad) atomicOr(a.range_flag, 1);
+    __syncthreads();
+
+    // ---- pool: thread = (pooled pixel q, 8 channels) ----
+    if (tid < SP_PH * SP_PW * 8) {
+        const int q = tid >> 3, c8 = tid & 7;
+        const int ppy = q / SP_PW, ppx = q - ppy * SP_PW;
+        const int py = ty * SP_PH + ppy, px = tx * SP_PW + ppx;
+        if (py < sp.Hq && px < sp.Wq) {
+            float m[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m[c] = -1.0f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* src = patch + ((2 * ppy + dy) * SP_CW + 2 * ppx + dx) * SLD + 8 * c8;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { m[c] = fmaxf(m[c], v0[c]); m[4 + c] = fmaxf(m[4 + c], v1[c]); }
+                }
+            float* orow = sp.pool + ((size_t)(b * sp.Hq + py) * sp.Wq + px) * 64;
+            if (sp.pool_split) {
+                f16x8 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const _Float16 h = (_Float16)m[c];
+                    hi[c] = h;
+                    lo[c] = (_Float16)((m[c] - (float)h) * LO_SCALE);
+                }
+                const int ch = 8 * c8;
+                char* base = reinterpret_cast<char*>(orow) + (ch >> 5) * 128 + (ch & 31) * 2;
+                *reinterpret_cast<f16x8*>(base) = hi;
+                *reinterpret_cast<f16x8*>(base + 64) = lo;
+            } else {
+                reinterpret_cast<f32x4*>(orow)[2 * c8] = f32x4{m[0], m[1], m[2], m[3]};
+                reinterpret_cast<f32x4*>(orow)[2 * c8 + 1] = f32x4{m[4], m[5], m[6], m[7]};
+            }
+        }
+    }
+}
+
 static int g_stem_pool = getenv("AMP_NO_STEM_POOL") ? 0 : 1;      // EXPERIMENT switch: 0 = stem and pool as two kernels
 extern "C" void amp_debug_set_stem_pool(int v) { g_stem_pool = v; }
 // Stem (7x7 stride 2 on the [B,H,W,4] input, weights [64][7][8][4], ReLU) + max-pool 3x3 stride 2 pad 1 in one kernel: AMP_CONV_F16X3 with
@@ -2245,6 +2441,48 @@ int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_
                                     (unsigned int)x_bytes, (unsigned int)w_bytes);
     else AMP_TIMED_LAUNCH(stem_pool_f16x3_kernel<false>, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp,
                             (unsigned int)x_bytes, (unsigned int)w_bytes);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+static int g_stem_u8 = getenv("AMP_NO_STEM_U8") ? 0 : 1;      // EXPERIMENT switch: 0 = preprocess_kernel + stem_pool_f16x3_kernel
+extern "C" void amp_debug_set_stem_u8(int v) { g_stem_u8 = v; }
+bool amp::stem_u8_applies(amp_ctx* ctx, const float* w_split) { return g_stem_u8 && amp::stem_pool_applies(ctx, w_split); }
+// The fused stem + pool from the uint8 image (stem_pool_u8_kernel): Hp x Wp is the padded frame the convolution sees.
+int amp::stem_pool_u8_run(amp_ctx* ctx, const uint8_t* img, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std_[3],
+                          const int* img_hw, const float* w_split, const float* scale, const float* shift, float* pool, int pool_split) {
+    AMP_REQUIRE(amp::stem_u8_applies(ctx, w_split) && img && mean && std_ && pool && B > 0 && Hp >= H && Wp >= W, "stem_pool_u8_run: bad argument");
+    ConvArgs a = ConvArgs();
+    a.w = w_split; a.scale = scale; a.shift = shift;
+    a.B = B; a.H = Hp; a.W = Wp; a.Cin = 4; a.Cout = 64;
+    a.KH = 7; a.KW = 8; a.stride = 2; a.pad = 3;
+    a.Ho = (Hp + 2 * 3 - 7) / 2 + 1;
+    a.Wo = (Wp + 2 * 3 - 7) / 2 + 1;
+    a.cin_win = 4;
+    a.K = 7 * 8 * 4; a.nsteps = 7;
+    a.relu = 1;
+    a.in_scale = a.out_scale = 1.0f;
+    a.range_flag = ctx->d_conv_flag;
+    const size_t w_bytes = (size_t)64 * a.K * sizeof(float);
+    StemPoolArgs sp;
+    sp.pool = pool; sp.pool_split = pool_split;
+    sp.Hq = (a.Ho + 2 - 3) / 2 + 1; sp.Wq = (a.Wo + 2 - 3) / 2 + 1;
+    sp.tiles_y = amp::cdiv(sp.Hq, SP_PH); sp.tiles_x = amp::cdiv(sp.Wq, SP_PW);
+    StemU8Args u;
+    u.img = img; u.H = H; u.W = W; u.img_hw = img_hw;
+    u.m0 = mean[0]; u.m1 = mean[1]; u.m2 = mean[2]; u.s0 = std_[0]; u.s1 = std_[1]; u.s2 = std_[2];
+    amp_prof_rec* rec = nullptr;
+    if (ctx->prof_on) {
+        if (ctx->prof_used < ctx->prof_pool.size()) {
+            rec = &ctx->prof_pool[ctx->prof_used++];
+            rec->flops = 2.0 * (double)B * a.Ho * a.Wo * 64.0 * 7.0 * 8.0 * 4.0;   // useful work of the stem (as conv_run counts it), not the halo
+            rec->variant = 1;
+        } else {
+            ctx->prof_truncated = true;
+        }
+    }
+    amp::ProfLaunchScope timed(rec ? rec->e0 : nullptr, rec ? rec->e1 : nullptr);
+    AMP_TIMED_LAUNCH(stem_pool_u8_kernel, dim3((unsigned)(B * sp.tiles_y * sp.tiles_x)), dim3(512), 0, ctx->stream, a, sp, u, (unsigned int)w_bytes);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -276,7 +276,7 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
     // ---------------- backbone ----------------
     AMP_ALLOC(x0, float, (size_t)B * Hp * Wp * 4);
     AMP_ALLOC(d_img_hw, int, (size_t)2 * B);
-    bool x0_split = false;
+    bool x0_split = false, stem_from_u8 = false;
     if (!dry) {
         const bool sized = (int)m->img_hw.size() == 2 * B;
         if (sized) {
@@ -287,7 +287,9 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         const ConvW& sw0 = CONV("backbone.bottom_up.stem.conv1");
         x0_split = sw0.cin == 4 && sw0.kw == 8 && sw0.kh == 7 && sw0.cout == 64 && !m->split_stale && amp::stem_pool_applies(ctx, sw0.w_split) &&
                    (size_t)B * Hp * Wp * 16 < 0x80000000ull && (long long)B * Hp * Wp < (1ll << 27);
-        AMP_TRY(amp::preprocess_run(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0, x0_split ? 1 : 0));
+        // ... and the uint8 form of that kernel normalises and splits the pixels itself: no preprocessed tensor at all
+        stem_from_u8 = x0_split && amp::stem_u8_applies(ctx, sw0.w_split);
+        if (!stem_from_u8) AMP_TRY(amp::preprocess_run(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, sized ? d_img_hw : nullptr, x0, x0_split ? 1 : 0));
         T.img_hw = sized ? d_img_hw : nullptr;
     } else {
         T.img_hw = nullptr;
@@ -328,7 +330,9 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         // stem + max-pool in one kernel where that exists (f16x3 arithmetic, fresh split weights); the stem's own output is then never written
         const ConvW& sw = CONV("backbone.bottom_up.stem.conv1");
         int fused = 1;
-        if (sw.cin == 4 && sw.kw == 8 && sw.kh == 7 && sw.cout == 64 && !m->split_stale)
+        if (stem_from_u8)
+            fused = amp::stem_pool_u8_run(ctx, imgs_d, B, H, W, Hp, Wp, c.pixel_mean, c.pixel_std, T.img_hw, sw.w_split, sw.scale, sw.shift, pool, native_all ? 1 : 0);
+        else if (sw.cin == 4 && sw.kw == 8 && sw.kh == 7 && sw.cout == 64 && !m->split_stale)
             fused = amp::stem_pool_run(ctx, B, Hp, Wp, x0, x0_split ? 1 : 0, sw.w_split, sw.scale, sw.shift, pool, native_all ? 1 : 0);
         if (fused < 0) return fused;
         if (fused == 1 && x0_split) { amp::set_error("amp_model: the input was split for the fused stem, which then did not launch"); return AMP_ERR_STATE; }

@@ -538,8 +538,8 @@ def test_ring_kernel_repeats_bit_for_bit(gpu_ctx, shape):
 
 @pytest.mark.parametrize("B,H,W", [(2, 224, 288), (1, 96, 352), (3, 160, 128), (1, 1024, 1024)])
 def test_fused_stem_pool_is_bit_identical(gpu_ctx, B, H, W):
-    """stem_pool_f16x3_kernel (7x7 stem + ReLU + 3x3 max-pool in one kernel, the stem's output never written) against the two kernels it
-    replaces: the pooled tensor bit for bit -- pooled sizes that are not multiples of the 8 x 7 tile, images of a batch, and the bench's
+    """stem_pool_u8_kernel / stem_pool_f16x3_kernel (7x7 stem + ReLU + 3x3 max-pool in one kernel, the stem's output never written; the first
+    also normalises and splits the uint8 pixels itself) against the kernels they replace: the pooled tensor bit for bit -- pooled sizes that are not multiples of the 8 x 7 tile, images of a batch, and the bench's
     size -- and therefore identical detections."""
     from ampis_amd import params as P
     from ampis_amd._lib import lib
@@ -552,14 +552,18 @@ def test_fused_stem_pool_is_bit_identical(gpu_ctx, B, H, W):
     m.load_params(P.init_params(K, seed=3, style="spread"))
     outs, taps = [], []
     try:
-        for on in (1, 0):
-            lib().amp_debug_set_stem_pool(on)
+        # (fused from the uint8 image: stem_pool_u8_kernel) | (preprocess<split> + stem_pool_f16x3_kernel) | (preprocess, stem, max-pool)
+        for pool_on, u8_on in ((1, 1), (1, 0), (0, 0)):
+            lib().amp_debug_set_stem_pool(pool_on)
+            lib().amp_debug_set_stem_u8(u8_on)
             outs.append(m.infer(imgs, rle="counts"))
             taps.append(m.tap("stem_pool"))
     finally:
         lib().amp_debug_set_stem_pool(1)
+        lib().amp_debug_set_stem_u8(1)
     m.close()
     assert taps[0].shape == (B, (H // 2 + 1) // 2, (W // 2 + 1) // 2, 64) and float(np.abs(taps[0]).max()) > 0
-    assert np.array_equal(taps[0].view(np.uint32), taps[1].view(np.uint32))
-    for x, y in zip(*outs):
-        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
+    for k in (1, 2):
+        assert np.array_equal(taps[0].view(np.uint32), taps[k].view(np.uint32)), k
+        for x, y in zip(outs[0], outs[k]):
+            assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
