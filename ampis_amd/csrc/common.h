@@ -86,6 +86,10 @@ struct ProfLaunchScope {          // attaches a profile record's events to the t
 #define AMP_TIMED_LAUNCH(kernel, grid, block, shmem, stream, ...) \
     hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, amp::prof_e0, amp::prof_e1, 0, __VA_ARGS__)
 
+// __syncthreads() spelled with builtins: inside an AMP_NO_PK kernel the header's inline function has other target features than the
+// kernel and is CALLED instead of inlined
+#define AMP_SYNCTHREADS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 // AMP_NO_PK: compile a kernel without packed-FP32 instructions (v_pk_mul / add / fma_f32).
 // Found in round 3 (tools/_probe_conc.py): with SEVERAL contexts running kernels on the card at once, box_candidates_kernel
 // occasionally wrote a box whose x1 (or y1) was the box CENTRE -- for 16 consecutive lanes, i.e. exp(dw) * w had come out as 0 there.  The

@@ -2215,7 +2215,7 @@ struct StemU8Args {
     const int* img_hw;        // optional device [B][2]: per-image valid size
     float m0, m1, m2, s0, s1, s2;
 };
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_u8_kernel(const ConvArgs a, const StemPoolArgs sp, const StemU8Args u,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) AMP_NO_PK void stem_pool_u8_kernel(const ConvArgs a, const StemPoolArgs sp, const StemU8Args u,
                                                                                                        const unsigned int w_bytes) {
     constexpr int BM = 256, BN = 64;
     constexpr int WTM = 64, WTN = 32, NWN = 2;      // 8 waves: 4 x 2 wave tiles
@@ -2247,12 +2247,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int r = wave * 8 + srow;
         b_voff = (r < a.Cout) ? (unsigned int)(((size_t)r * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
     }
-    auto stage_b = [&](int kstep, int buf) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bt + buf * BT_FLOATS + (wave * 8) * BK), 16, (int)b_voff,
-                                                 kstep * (BK * 4), 0, 0);
-    };
+    // (no lambda here: AMP_NO_PK changes the kernel's target features, and a closure compiled with the default ones is then CALLED, not inlined)
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) stage_b(ks, ks);
+    for (int ks = 0; ks < NKS; ++ks)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bt + ks * BT_FLOATS + (wave * 8) * BK), 16, (int)b_voff,
+                                                 ks * (BK * 4), 0, 0);
 
     // ---- the input patch: normalise (preprocess_kernel's operations) and split into the two planes ----
     {
@@ -2312,7 +2311,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 
     __builtin_amdgcn_s_waitcnt(0x0F70);     // the weight tiles have landed
-    __syncthreads();                        // planes and weights complete
+    AMP_SYNCTHREADS();                        // planes and weights complete
 #pragma unroll
     for (int step = 0; step < NKS; ++step) {
         const int cur = step;
@@ -2331,7 +2330,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         f16x3_mfma16<MB, NB>(f, acc, acx);
     }
-    __syncthreads();                        // every wave is done with the planes and the weights: the patch takes their place
+    AMP_SYNCTHREADS();                        // every wave is done with the planes and the weights: the patch takes their place
 
     // ---- the patch: fold the cross terms, scale / shift / ReLU (conv_epilogue_rows' arithmetic), -1 for pixels outside the image ----
     float* patch = reinterpret_cast<float*>(lds_raw);
@@ -2354,8 +2353,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 patch[r * SLD + n] = v ? t : -1.0f;
             }
     }
-    if (bad) atomicOr(a.range_flag, 1);
-    __syncthreads();
+    if (bad) (void)__hip_atomic_fetch_or(a.range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the builtin: atomicOr() would be a call here, see AMP_SYNCTHREADS)
+    AMP_SYNCTHREADS();
 
     // ---- pool: thread = (pooled pixel q, 8 channels) ----
     if (tid < SP_PH * SP_PW * 8) {
