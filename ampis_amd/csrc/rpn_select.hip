@@ -41,7 +41,7 @@ struct TopkArgs {
 #include "select.h"
 namespace {
 
-constexpr int TOPK_CHUNK = 49152;    // anchors per workgroup: the 196 608 anchors of p2 of a 1024 x 1024 image become 4 chunks (8 chunks of 24 576 were
+constexpr int TOPK_CHUNK = 49152;    // anchors per workgroup: the 196 608 anchors of p2 of a 1024 x 1024 image become 4 chunks (8 chunks of 24 576: the select halves, 87 -> 46 us, and the merge of eight lists takes it back, 18 -> 55 us; round 2: 8 chunks were
                                      // slower: the select has ~100 us of fixed cost and the merge sorts twice as many words)
 
 __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a) {
@@ -84,10 +84,13 @@ __global__ __launch_bounds__(TOPK_THREADS) void rpn_topk_kernel(const TopkArgs a
 // one workgroup per (image, level with chunks): exact order of the chunks' candidates, first k out.  The chunks' lists are sorted and
 // their words unique ((key, ~anchor index)): the rank of a word in the merge is its own index plus, per other list, the number of larger
 // words (binary search in LDS) -- no sort.
-__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkArgs a, int lvl, int N) {
+__global__ __launch_bounds__(TOPK_THREADS) void topk_merge_kernel(const TopkArgs a, int lvl_mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long mkeys[];        // [nch][k]
     __shared__ int ccount[8];
     const int b = blockIdx.x;
+    int lvl = 0;                        // blockIdx.y-th level among those cut into chunks (bits of lvl_mask): all of them in one launch
+    for (int seen = -1; lvl < MAX_LEVELS; ++lvl)
+        if ((lvl_mask >> lvl) & 1) { if (++seen == (int)blockIdx.y) break; }
     const int nch = a.nch[lvl];
     if (threadIdx.x < nch) ccount[threadIdx.x] = min(a.cand_count[b * a.segs_per_img + a.seg0[lvl] + threadIdx.x], a.k);
     __syncthreads();
@@ -288,13 +291,14 @@ int amp_rpn_topk(amp_ctx* ctx, const amp_rpn_levels* lv, int B, int k, uint32_t*
         a.cand_count = reinterpret_cast<int*>(a.cand + (size_t)B * segs * k);
     }
     hipLaunchKernelGGL(rpn_topk_kernel, dim3(B * segs), dim3(TOPK_THREADS), 0, ctx->stream, a);
+    int lvl_mask = 0, nmerge = 0, nmax = 0;
     for (int l = 0; l < lv->nlevels; ++l)
-        if (a.nch[l] > 1) {
-            const int N = a.nch[l] * k;
-            AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)(N * sizeof(unsigned long long))));
-            hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_THREADS), (size_t)N * sizeof(unsigned long long), ctx->stream, a, l, N);
-        }
+        if (a.nch[l] > 1) { lvl_mask |= 1 << l; ++nmerge; nmax = std::max(nmax, a.nch[l] * k); }
+    if (nmerge) {
+        AMP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(nmax * sizeof(unsigned long long))));
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(B, nmerge), dim3(TOPK_THREADS), (size_t)nmax * sizeof(unsigned long long), ctx->stream, a, lvl_mask);
+    }
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }
