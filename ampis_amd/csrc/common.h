@@ -132,6 +132,15 @@ struct amp_ctx {
     struct RowTab { int key[9]; unsigned int* tab; size_t n; };
     std::vector<RowTab> rowtabs;
     size_t rowtab_bytes = 0;
+    // weight-gradient reductions on a second stream (wgrad.hip amp::wgrad_async_*): the MFMA kernel of a layer stays on `stream`, its
+    // slab reduction runs on `side` behind an event, two scratch buffers alternate; the next layers' kernels do not wait for it
+    bool reduce_async = false;
+    hipStream_t side = nullptr;
+    hipEvent_t wg_ev[2] = {nullptr, nullptr};      // the MFMA kernel that wrote scratch p is done
+    hipEvent_t side_ev[2] = {nullptr, nullptr};    // the reduction that read scratch p is done
+    bool side_used[2] = {false, false};
+    int side_parity = 0, side_last = -1;
+    float* side_scratch1 = nullptr;                // the second scratch buffer (the first is the one the calls pass)
 };
 
 namespace amp {
@@ -179,6 +188,12 @@ int weight_jobs_run(amp_ctx* ctx, const WeightJob* jobs_dev, const void* chunks_
 // train_bwd.hip: amp_sgd_update over a device table of chunks (low 32 bits: offset in floats, a multiple of 4; high 32: length) of the arenas p / g / v
 int sgd_chunks_run(amp_ctx* ctx, const unsigned long long* chunks_dev, int nchunks, float* p, const float* g, float* v, float lr,
                    float momentum, float weight_decay, float grad_scale);
+// wgrad.hip: slab reductions on a second stream.  begin(scratch1): every amp_conv2d_wgrad* call from here on launches its reduction on
+// ctx->side (alternating between the scratch it is given and scratch1); join: `stream` waits for every reduction issued so far (before
+// anything on it reads or adds to a gradient); end: join + off.
+int wgrad_async_begin(amp_ctx* ctx, float* scratch1);
+int wgrad_async_join(amp_ctx* ctx);
+int wgrad_async_end(amp_ctx* ctx);
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);
 int compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
                      float* boxes, float* scores, int* classes, int* batch, int* n_total /* device, optional: length of the compact list */);   // box_infer.hip

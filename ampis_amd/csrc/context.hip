@@ -144,6 +144,8 @@ void amp_destroy(amp_ctx* ctx) {
     for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    for (int p = 0; p < 2; ++p) { if (ctx->wg_ev[p]) (void)hipEventDestroy(ctx->wg_ev[p]); if (ctx->side_ev[p]) (void)hipEventDestroy(ctx->side_ev[p]); }
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     (void)hipFree(ctx->zero_page);
     (void)hipFree(ctx->d_conv_flag);
     (void)hipFree(ctx->split_scratch);

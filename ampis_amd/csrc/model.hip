@@ -238,6 +238,7 @@ void tap(amp_model* m, const char* name, void* p, int dtype, std::initializer_li
 int issue_bucket(amp_model* m, int b) {
     amp_ctx* ctx = m->ctx;
     if (m->ws.dry || !ctx->comm || m->grad_overlap == 0) return AMP_OK;
+    AMP_TRY(amp::wgrad_async_join(ctx));      // the bucket's last reductions may still be on the side stream
     // every range of the bucket, in groups of at most 64 per grouped RCCL call (a fragmented arena may hold more than 64)
     size_t off[64], n[64];
     int nr = 0;
@@ -1065,6 +1066,15 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     const size_t WT_SCRATCH = (size_t)13 << 20;     // floats: transformed weights of the largest layer (fc1: 12.85 M)
     AMP_ALLOC(wg_scratch, float, WG_SCRATCH);
     AMP_ALLOC(wt_scratch, float, WT_SCRATCH);
+    // The slab reductions (69 launches of ~20 us between MFMA kernels) run on a second stream behind an event (amp::wgrad_async_*), with
+    // a second scratch so that the next layer's kernel does not wait for the previous layer's reduction.  AMP_ASYNC_REDUCE=0: on the main stream.
+    static const bool async_on = getenv("AMP_ASYNC_REDUCE") ? atoi(getenv("AMP_ASYNC_REDUCE")) != 0 : true;
+    AMP_ALLOC(wg_scratch1, float, async_on ? WG_SCRATCH : 64);
+    struct AsyncScope {          // every exit from the backward pass joins the side stream and leaves the context in the plain mode
+        amp_ctx* c; bool on;
+        ~AsyncScope() { if (on) (void)amp::wgrad_async_end(c); }
+    } async_scope{ctx, false};
+    if (!dry && async_on) { AMP_TRY(amp::wgrad_async_begin(ctx, wg_scratch1)); async_scope.on = true; }
     AMP_ALLOC(cs_scratch, float, (size_t)4 << 20);   // ceil(M/512) * N floats of the largest bias-gradient reduction
     const size_t DYS_SCRATCH = (size_t)B * T.fh[0] * T.fw[0] * 256;      // floats: the largest dy converted to a scaled split operand (p2 level)
     AMP_ALLOC(dys_scratch, float, DYS_SCRATCH);
@@ -1171,6 +1181,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             d.B = N; d.H = 28; d.W = 28; d.Cin = 256; d.Cout = 256; d.KH = 2; d.KW = 2; d.stride = 2; d.pad = 0; d.relu = 0; d.res_mode = 0; d.out_mode = 0;
             AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
             AMP_TRY(amp_conv2d_wgrad_scaled(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0, 0, 16));   // here the gradient is the 'x' operand
+            AMP_TRY(amp::wgrad_async_join(ctx));      // dwd_t is read right away
             AMP_TRY(amp_deconv_grad_transpose(ctx, dwd_t, GW(cd), 256, 4, 256, 0));
             AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
             for (int q = 0; q < 4; ++q) AMP_HIP_CHECK(hipMemcpyAsync(GB(cd) + q * 256, dbd_t, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1328,6 +1339,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                 amp_conv_desc dw;
                 dw.B = B; dw.H = h1; dw.W = w1; dw.Cin = ba.mid; dw.Cout = ba.mid; dw.KH = 3; dw.KW = 3; dw.stride = st2; dw.pad = 1; dw.relu = 0; dw.res_mode = 0; dw.out_mode = 0;
                 AMP_REQUIRE(amp_grouped_wgrad_scratch_floats(&dw) <= WG_SCRATCH && (size_t)ba.mid * 9 * 64 <= WT_SCRATCH, "backward: grouped scratch too small");
+                AMP_TRY(amp::wgrad_async_join(ctx));      // the grouped kernels use wg_scratch on the main stream: no reduction may still be reading it
                 AMP_TRY(amp_conv2d_grouped_wgrad(ctx, &dw, c2.groups, ba.t1, d_t2, c2.scale, wg_scratch, GW(c2)));
                 AMP_TRY(amp_group_dgrad_weights(ctx, c2.w, c2.scale, ba.mid, 3, 3, wt_scratch));
                 amp_conv_desc dd = dw;
@@ -1412,6 +1424,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         }
         if (bi == 0 || m->blocks[bi - 1].stage != ba.stage) AMP_TRY(issue_bucket(m, 7 - ba.stage));   // res5 -> 4, res4 -> 5, res3 -> 6
     }
+    if (async_scope.on) { async_scope.on = false; AMP_TRY(amp::wgrad_async_end(ctx)); }
     if (!dry) {
         if (m->grad_overlap != 0) AMP_TRY(amp::comm_mark_producer_end(ctx));
         m->grads_valid = true;

@@ -895,6 +895,12 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
                 "amp_conv2d_wgrad: shifts must be in [0, 24] and at most one of them non-zero");
     AMP_REQUIRE(d->Cin % TC == 0, "amp_conv2d_wgrad: Cin=%d must be a multiple of %d", d->Cin, TC);
     AMP_REQUIRE(d->Cout % 4 == 0, "amp_conv2d_wgrad: Cout=%d must be a multiple of 4", d->Cout);
+    int par = -1;
+    if (ctx->reduce_async) {              // alternate the scratch; the reduction that last read this one must be done before it is overwritten
+        par = ctx->side_parity; ctx->side_parity ^= 1;
+        if (par == 1) scratch = ctx->side_scratch1;
+        if (ctx->side_used[par]) AMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_ev[par], 0));
+    }
     WgradArgs a;
     a.dy = dy; a.x = x; a.partial = scratch;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.N = d->Cout;
@@ -979,9 +985,19 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
     }
     }
     const size_t nk = (size_t)a.N * a.Kp;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, ctx->stream, scratch,
+    hipStream_t rs = ctx->stream;
+    if (par >= 0) {
+        AMP_HIP_CHECK(hipEventRecord(ctx->wg_ev[par], ctx->stream));
+        AMP_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->wg_ev[par], 0));
+        rs = ctx->side;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((nk + 255) / 256, 4096)), dim3(256), 0, rs, scratch,
                        a.nsplit, nk, a.Kp, scale, grad, accumulate, a.bias_partial, a.N, bias_grad, bias_accumulate);
     AMP_HIP_CHECK(hipGetLastError());
+    if (par >= 0) {
+        AMP_HIP_CHECK(hipEventRecord(ctx->side_ev[par], ctx->side));
+        ctx->side_used[par] = true; ctx->side_last = par;
+    }
     return AMP_OK;
 }
 
@@ -1025,3 +1041,35 @@ int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout
 }
 
 }  // extern "C"
+
+int amp::wgrad_async_begin(amp_ctx* ctx, float* scratch1) {
+    AMP_REQUIRE(ctx && scratch1 && !ctx->reduce_async, "wgrad_async_begin: bad argument or already on");
+    if (!ctx->side) {
+        AMP_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        for (int p = 0; p < 2; ++p) {
+            AMP_HIP_CHECK(hipEventCreateWithFlags(&ctx->wg_ev[p], hipEventDisableTiming));
+            AMP_HIP_CHECK(hipEventCreateWithFlags(&ctx->side_ev[p], hipEventDisableTiming));
+        }
+    }
+    ctx->side_scratch1 = scratch1;
+    ctx->side_used[0] = ctx->side_used[1] = false;
+    ctx->side_parity = 0; ctx->side_last = -1;
+    ctx->reduce_async = true;
+    return AMP_OK;
+}
+
+int amp::wgrad_async_join(amp_ctx* ctx) {
+    AMP_REQUIRE(ctx, "wgrad_async_join: null context");
+    if (!ctx->reduce_async) return AMP_OK;
+    // the side stream runs its reductions in order: waiting for both parities' last events covers everything issued
+    for (int p = 0; p < 2; ++p)
+        if (ctx->side_used[p]) AMP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->side_ev[p], 0));
+    return AMP_OK;
+}
+
+int amp::wgrad_async_end(amp_ctx* ctx) {
+    AMP_REQUIRE(ctx, "wgrad_async_end: null context");
+    const int st = amp::wgrad_async_join(ctx);
+    ctx->reduce_async = false;
+    return st;
+}
