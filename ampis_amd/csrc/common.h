@@ -1,7 +1,9 @@
 // Shared helpers for the ampis_hip kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>      // hipExtLaunchKernelGGL (AMP_TIMED_LAUNCH); not a header for the host-only sanitizer build (tests/test_sanitize.py)
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <algorithm>
