@@ -40,10 +40,9 @@ for b in range(B):
         print(f"img{b} lvl{l} k={kk} topk idx equal frac", float((ref_idx == got_idx).mean()), "logit maxdiff", float(np.abs(sl[b, l, :kk] - c[1][o:o + kk].numpy()).max()))
         o += kk
 pb, pc = m.tap("prop_boxes"), m.tap("prop_count")
-cs, cc = m.tap("rpn_cand_sorted_boxes"), m.tap("rpn_cand_count")
 for b in range(B):
     r = st["props"][b][0].numpy(); g = pb[b, :pc[b]]
-    print(f"img{b} proposals ref {len(r)} got {len(g)} cand_count {cc[b]} match", _match_boxes(r, g, 5e-3), "exact-order maxdiff", float(np.abs(r[:min(len(r),len(g))] - g[:min(len(r),len(g))]).max()))
+    print(f"img{b} proposals ref {len(r)} got {len(g)} match", _match_boxes(r, g, 5e-3), "exact-order maxdiff", float(np.abs(r[:min(len(r),len(g))] - g[:min(len(r),len(g))]).max()))
 dc = m.tap("det_count"); db = m.tap("det_boxes"); ds = m.tap("det_scores"); dcl = m.tap("det_classes")
 for b in range(B):
     r = st["dets"][b]
