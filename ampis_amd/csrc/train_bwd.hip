@@ -488,10 +488,10 @@ __global__ __launch_bounds__(256) AMP_NO_PK void small_k_dgrad_split_kernel(cons
                 *reinterpret_cast<sk_h8*>(ob + 64) = lo;
             }
         }
-        __syncthreads();
+        AMP_SYNCTHREADS();      // (builtins: under AMP_NO_PK the header's inline __syncthreads() is a call)
 #pragma unroll
         for (int q = 0; q < 8; ++q) red[rl][cg][q] = acc[q];
-        __syncthreads();
+        AMP_SYNCTHREADS();
         if (rl == 0 && ch < C) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
