@@ -202,7 +202,30 @@ struct RpnLossArgs {
     int* sampled;                 // [B][batch] anchor indices: positives then negatives, ascending hash
     int* counts;                  // [B][2] npos, nneg
     float* partial;               // [B][2] sum BCE, sum L1 (unnormalised)
+    // chunked selection (rpn_sample_select_kernel): the anchors of an image are cut into nch chunks of <= SAMPLE_CHUNK, every (image,
+    // positives | negatives, chunk) keeps its best `batch` words; rpn_sample_loss_kernel then orders the <= nch * batch words of a class
+    unsigned long long* cand;     // [B][2][nch][batch] sorted words (key << 32 | ~anchor), null: one workgroup per image selects from all anchors
+    int* cand_count;              // [B][2][nch]
+    int nch;
 };
+constexpr int SAMPLE_CHUNK = 49152;      // = 48 keys per thread in registers (select_topk_reg), as the RPN top-k
+
+// One workgroup per (image, class, chunk).  The same keys and the same order as the one-workgroup selection (key descending, anchor ascending):
+// the best `batch` of a class are among the best `batch` of its chunks.
+__global__ __launch_bounds__(1024) void rpn_sample_select_kernel(const RpnLossArgs a) {
+    __shared__ amp::SelectSmem sm;
+    const int c = blockIdx.x % a.nch, which = (blockIdx.x / a.nch) & 1, b = blockIdx.x / (2 * a.nch);
+    const int n = a.g.total;
+    const int i0 = c * SAMPLE_CHUNK, nc = min(SAMPLE_CHUNK, n - i0);
+    const signed char* lab = a.label + (size_t)b * n + i0;
+    const uint32_t seed = a.seed;
+    const signed char want = which == 0 ? 1 : 0;
+    const int kmax = which == 0 ? a.num_pos_max : a.batch;
+    const int k = amp::select_topk_reg<SAMPLE_CHUNK / 1024>(sm, nc, kmax, [&](int i) { return lab[i] == want ? sample_key(seed, b, which, i0 + i) : 0u; });
+    unsigned long long* out = a.cand + (size_t)blockIdx.x * a.batch;
+    for (int i = threadIdx.x; i < k; i += 1024) out[i] = sm.sorted[i] - (unsigned long long)(uint32_t)i0;      // chunk-local index -> anchor index (~(i0 + i) = ~i - i0)
+    if (threadIdx.x == 0) a.cand_count[blockIdx.x] = k;
+}
 
 __global__ __launch_bounds__(1024) void rpn_sample_loss_kernel(const RpnLossArgs a) {
     __shared__ amp::SelectSmem sm;
@@ -213,12 +236,36 @@ __global__ __launch_bounds__(1024) void rpn_sample_loss_kernel(const RpnLossArgs
     const signed char* lab = a.label + (size_t)b * n;
     uint32_t* keys = a.keys_scratch + (size_t)b * n;
     const uint32_t seed = a.seed;
-    const int npos = amp::select_topk(sm, n, a.num_pos_max, keys, [&](int i) { return lab[i] == 1 ? sample_key(seed, b, 0, i) : 0u; });
+    int npos, nneg;
+    if (a.cand) {
+        // the chunks' candidates of a class: at most nch * batch <= 2048 sorted words -> one LDS sort, the first k are the selection
+        auto from_chunks = [&](int which, int kmax) -> int {
+            __syncthreads();
+            const int base = (b * 2 + which) * a.nch;
+            int total = 0;
+            for (int c = 0; c < a.nch; ++c) total += a.cand_count[base + c];
+            int N = 64;
+            while (N < a.nch * a.batch) N <<= 1;
+            for (int i = tid; i < N; i += 1024) {
+                const int c = i / a.batch, j = i - c * a.batch;
+                sm.sorted[i] = (c < a.nch && j < a.cand_count[base + c]) ? a.cand[(size_t)(base + c) * a.batch + j] : 0ull;
+            }
+            amp::bitonic_desc<1024>(sm.sorted, N);
+            return min(kmax, total);
+        };
+        npos = from_chunks(0, a.num_pos_max);
+        for (int i = tid; i < npos; i += 1024) s_idx[i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+        nneg = from_chunks(1, a.batch - npos);
+        for (int i = tid; i < nneg; i += 1024) s_idx[npos + i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
+        __syncthreads();
+    } else {
+    npos = amp::select_topk(sm, n, a.num_pos_max, keys, [&](int i) { return lab[i] == 1 ? sample_key(seed, b, 0, i) : 0u; });
     for (int i = tid; i < npos; i += 1024) s_idx[i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
     __syncthreads();
-    const int nneg = amp::select_topk(sm, n, a.batch - npos, keys, [&](int i) { return lab[i] == 0 ? sample_key(seed, b, 1, i) : 0u; });
+    nneg = amp::select_topk(sm, n, a.batch - npos, keys, [&](int i) { return lab[i] == 0 ? sample_key(seed, b, 1, i) : 0u; });
     for (int i = tid; i < nneg; i += 1024) s_idx[npos + i] = (int)(0xffffffffu - (uint32_t)(sm.sorted[i] & 0xffffffffu));
     __syncthreads();
+    }
     float bce = 0.f, l1 = 0.f;
     if (tid < npos + nneg) {
         const int an = s_idx[tid];
@@ -741,6 +788,16 @@ int amp_rpn_sample_loss(amp_ctx* ctx, const amp_rpn_levels* lv, float* const dpr
     a.gt_boxes = gt_boxes; a.gt_off = gt_off; a.label = label; a.match_idx = match_idx; a.keys_scratch = keys_scratch;
     a.batch = batch; a.num_pos_max = (int)(batch * pos_frac); a.seed = seed; a.inv_norm = 1.0f / (float)(batch * B);
     a.sampled = sampled; a.counts = counts; a.partial = partial;
+    // chunked selection when the chunks' candidate lists fit the caller's scratch ([B][total] uint32) and one LDS sort (nch * batch <= 2048)
+    a.cand = nullptr; a.cand_count = nullptr; a.nch = amp::cdiv(a.g.total, SAMPLE_CHUNK);
+    static const bool one_wg = getenv("AMP_SAMPLE_ONE_WG") != nullptr;      // EXPERIMENT switch: the one-workgroup-per-image selection
+    const size_t cand_words = (size_t)B * 2 * a.nch * batch;
+    const size_t need_bytes = cand_words * 8 + (size_t)B * 2 * a.nch * 4;
+    if (!one_wg && a.nch * batch <= amp::SELECT_MAX_K && need_bytes <= (size_t)B * a.g.total * 4 && batch <= amp::SELECT_MAX_K) {
+        a.cand = reinterpret_cast<unsigned long long*>(keys_scratch);
+        a.cand_count = reinterpret_cast<int*>(a.cand + cand_words);
+        hipLaunchKernelGGL(rpn_sample_select_kernel, dim3(B * 2 * a.nch), dim3(1024), 0, ctx->stream, a);
+    }
     hipLaunchKernelGGL(rpn_sample_loss_kernel, dim3(B), dim3(1024), 0, ctx->stream, a);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
