@@ -1161,8 +1161,10 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     for (int l = 0; l < 5; ++l) {
         AMP_ALLOC(df, float, (size_t)B * T.fh[l] * T.fw[l] * 256);
         d_feat[l] = df;
-        if (!dry) AMP_HIP_CHECK(hipMemsetAsync(df, 0, (size_t)B * T.fh[l] * T.fw[l] * 256 * 4, ctx->stream));
+        // p2..p5: the first RoIAlign backward below writes every cell (amp::roi_align_bwd_run, init): no zero fill of 1.3 GB at B = 16; p6 has no pooler
+        if (!dry && l == 4) AMP_HIP_CHECK(hipMemsetAsync(df, 0, (size_t)B * T.fh[l] * T.fw[l] * 256 * 4, ctx->stream));
     }
+    int dfeat_init = 1;      // handed to the first RoIAlign backward, 0 afterwards
     int fstr[4] = {4, 8, 16, 32};
 
     // ---- mask head ----
@@ -1201,7 +1203,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext, m->mask_acts_split));
             std::swap(dcur, dnext);
         }
-        AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur, B));
+        AMP_TRY(amp::roi_align_bwd_run(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur, B, dfeat_init));
+        dfeat_init = 0;
     } else if (!dry) {
         for (const char* key : {"roi_heads.mask_head.predictor", "roi_heads.mask_head.deconv", "roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2",
                                 "roi_heads.mask_head.mask_fcn3", "roi_heads.mask_head.mask_fcn4"}) {
@@ -1226,7 +1229,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         const ConvW& c1 = CONV("roi_heads.box_head.fc1");
         AMP_TRY(wgrad(c1, pooled, 1, 1, R, 1, 0, d_fc1, false, true, AS && c1.w_split != nullptr));
         AMP_TRY(dgrad(c1, d_fc1, 1, 1, R, 0, nullptr, nullptr, d_pooled));
-        AMP_TRY(amp_roi_align_bwd_batched(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled, B));
+        AMP_TRY(amp::roi_align_bwd_run(ctx, d_feat, T.fh, T.fw, fstr, 256, rois, roi_batch_idx, R, 7, d_pooled, B, dfeat_init));
+        dfeat_init = 0;
     }
     AMP_TRY(issue_bucket(m, 1));
 

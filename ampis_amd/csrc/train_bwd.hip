@@ -146,6 +146,7 @@ struct RoiBwdTileArgs {
     RoiPar* par;
     int* range;                                  // [B] first RoI of image b, then [B] one past its last (a tile scans only its image's RoIs)
     int R, P, B;
+    int init;                 // 1: the maps hold garbage: every tile is written (zeros where no RoI reaches), nothing is read back
 };
 
 __global__ void roi_bwd_meta_kernel(const RoiBwdTileArgs a) {
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTil
             }
         }
     }
-    if (!any) return;
+    if (!any && !a.init) return;
     float* f = a.dfeat[lv] + (size_t)b * H * W * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -283,10 +284,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTil
             const int y = ty0 + r, x = tx0 + c;
             if (y < H && x < W) {
                 f32x4* p = reinterpret_cast<f32x4*>(f + ((size_t)y * W + x) * 256) + lane;
-                f32x4 v = *p;
+                if (a.init) {            // first writer of the map: 0 + acc, bit for bit what the zero-filled map would end with (-0 + 0 = +0), zeros elsewhere
+                    f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], acc[r][c][e]);
-                *p = v;
+                    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(0.f, acc[r][c][e]);
+                    *p = v;
+                } else {
+                    f32x4 v = *p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], acc[r][c][e]);
+                    *p = v;
+                }
             }
         }
 }
@@ -581,10 +589,25 @@ int amp_roi_align_bwd(amp_ctx* ctx, float* const dfeat[4], const int fh[4], cons
 
 int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
                               const int* batch_idx, int R, int P, const float* dout, int B) {
-    AMP_REQUIRE(ctx && dfeat && fh && fw && stride && rois && dout, "amp_roi_align_bwd_batched: null argument");
-    if (R == 0) return AMP_OK;
+    return amp::roi_align_bwd_run(ctx, dfeat, fh, fw, stride, C, rois, batch_idx, R, P, dout, B, 0);
+}
+
+}  // extern "C"
+
+// init = 1: the gradient maps are uninitialised and this call is their first writer (B > 0 required): the owner-computes kernel visits
+// every tile anyway, so it writes zeros where no RoI reaches instead of a separate 1.3-GB zero fill of the maps of a B = 16 step
+int amp::roi_align_bwd_run(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
+                           const int* batch_idx, int R, int P, const float* dout, int B, int init) {
+    AMP_REQUIRE(ctx && dfeat && fh && fw && stride && (R == 0 || (rois && dout)), "amp_roi_align_bwd_batched: null argument");
+    AMP_REQUIRE(!init || B > 0, "roi_align_bwd_run: init needs the number of images");
     static const bool env_atomics = getenv("AMP_ROI_BWD_ATOMICS") != nullptr;
-    if (C != 256 || P > 16 || env_atomics || g_roi_bwd_atomics) {     // other widths / more than 16 bins per axis (the tile kernel's lane
+    const bool tile_path = !(C != 256 || P > 16 || env_atomics || g_roi_bwd_atomics);
+    if (init && (R == 0 || !tile_path)) {         // no kernel that visits every tile will run: zero the maps here
+        for (int l = 0; l < 4; ++l) AMP_HIP_CHECK(hipMemsetAsync(dfeat[l], 0, (size_t)B * fh[l] * fw[l] * C * sizeof(float), ctx->stream));
+        init = 0;
+    }
+    if (R == 0) return AMP_OK;
+    if (!tile_path) {     // other widths / more than 16 bins per axis (the tile kernel's lane
         // layout), or the round-1 kernel for comparison: float atomics
         RoiBwdArgs a;
         for (int l = 0; l < 4; ++l) { a.dfeat[l] = dfeat[l]; a.fh[l] = fh[l]; a.fw[l] = fw[l]; a.scale[l] = 1.0f / (float)stride[l]; }
@@ -620,7 +643,7 @@ int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[
         off += B * ((fh[l] + 3) / 4) * a.tiles_x[l];
     }
     a.tile_off[4] = off;
-    a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.B = B;
+    a.rois = rois; a.batch_idx = batch_idx; a.dout = dout; a.R = R; a.P = P; a.B = B; a.init = init;
     a.par = reinterpret_cast<RoiPar*>(ctx->topk_scratch);                      // 32-B entries first (alignment), then keys, then ranges
     a.key = reinterpret_cast<RoiKey*>(a.par + R);
     a.range = reinterpret_cast<int*>(a.key + R);
@@ -631,6 +654,8 @@ int amp_roi_align_bwd_batched(amp_ctx* ctx, float* const dfeat[4], const int fh[
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }
+
+extern "C" {
 
 int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C) {
     AMP_REQUIRE(ctx && dfine && dcoarse && C % 4 == 0, "amp_upsample2_bwd: bad argument");
