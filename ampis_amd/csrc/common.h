@@ -198,6 +198,7 @@ int wgrad_async_join(amp_ctx* ctx);
 int wgrad_async_end(amp_ctx* ctx);
 int roi_align_bwd_run(amp_ctx* ctx, float* const dfeat[4], const int fh[4], const int fw[4], const int stride[4], int C, const float* rois,
                       const int* batch_idx, int R, int P, const float* dout, int B, int init);   // train_bwd.hip: amp_roi_align_bwd_batched + first-writer mode
+int upsample2_bwd_run(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C, int init);   // train_bwd.hip
 int maxpool_run(amp_ctx* ctx, const float* x, int B, int H, int W, int C, float* y, int y_split);
 int compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const float* det_boxes, const float* det_scores, const int* det_classes,
                      float* boxes, float* scores, int* classes, int* batch, int* n_total /* device, optional: length of the compact list */);   // box_infer.hip

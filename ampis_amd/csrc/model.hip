@@ -1279,8 +1279,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_TRY(wgrad(co, m->lat[s_], B, fh_, fw_, 1, 1, d_feat[s_], false, true, AS));
         AMP_TRY(dgrad(co, d_feat[s_], B, fh_, fw_, 1, d_lat_prev, nullptr, d_lat));      // + top-down share from the finer level
         if (l < 5) {
-            AMP_HIP_CHECK(hipMemsetAsync(d_lat_next, 0, (size_t)B * T.fh[s_ + 1] * T.fw[s_ + 1] * 256 * 4, ctx->stream));
-            AMP_TRY(amp_upsample2_bwd(ctx, d_lat, d_lat_next, B, T.fh[s_ + 1], T.fw[s_ + 1], 256));
+            AMP_TRY(amp::upsample2_bwd_run(ctx, d_lat, d_lat_next, B, T.fh[s_ + 1], T.fw[s_ + 1], 256, 1));      // first writer: no zero fill
         }
         const float* res_in = nullptr;   // input of the lateral conv = output of stage s_
         for (auto& ba : m->blocks) if (ba.stage == s_) res_in = ba.out;

@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(const RoiBwdTil
 }
 
 // d_coarse[b,y,x,:] += sum of the 2x2 fine cells (backward of nearest x2 upsampling in the FPN top-down path)
+template <bool INIT>      // INIT: dcoarse is written (0 + sum, bit for bit what a zero-filled map would hold), not read
 __global__ void upsample2_bwd_kernel(const float* __restrict__ dfine, float* __restrict__ dcoarse, int B, int Hc, int Wc, int C4) {
     const size_t total = (size_t)B * Hc * Wc * C4;
     const f32x4* f = reinterpret_cast<const f32x4*>(dfine);
@@ -312,7 +313,8 @@ __global__ void upsample2_bwd_kernel(const float* __restrict__ dfine, float* __r
         const int b = (int)(t / Hc);
         const size_t base = ((size_t)(b * 2 * Hc + 2 * y) * (2 * Wc) + 2 * x) * C4 + c;
         const f32x4 v00 = f[base], v01 = f[base + C4], v10 = f[base + (size_t)2 * Wc * C4], v11 = f[base + (size_t)2 * Wc * C4 + C4];
-        f32x4 acc = o[i];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!INIT) acc = o[i];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = __fadd_rn(acc[q], __fadd_rn(__fadd_rn(v00[q], v01[q]), __fadd_rn(v10[q], v11[q])));
         o[i] = acc;
@@ -655,14 +657,20 @@ int amp::roi_align_bwd_run(amp_ctx* ctx, float* const dfeat[4], const int fh[4],
     return AMP_OK;
 }
 
+// init = 1: dcoarse = the 2 x 2 sums (no zero fill in front, no read-back); 0: dcoarse += them
+int amp::upsample2_bwd_run(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C, int init) {
+    AMP_REQUIRE(ctx && dfine && dcoarse && C % 4 == 0, "amp_upsample2_bwd: bad argument");
+    const size_t total = (size_t)B * Hc * Wc * (C / 4);
+    if (init) hipLaunchKernelGGL(upsample2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dfine, dcoarse, B, Hc, Wc, C / 4);
+    else hipLaunchKernelGGL(upsample2_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dfine, dcoarse, B, Hc, Wc, C / 4);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
 extern "C" {
 
 int amp_upsample2_bwd(amp_ctx* ctx, const float* dfine, float* dcoarse, int B, int Hc, int Wc, int C) {
-    AMP_REQUIRE(ctx && dfine && dcoarse && C % 4 == 0, "amp_upsample2_bwd: bad argument");
-    const size_t total = (size_t)B * Hc * Wc * (C / 4);
-    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dfine, dcoarse, B, Hc, Wc, C / 4);
-    AMP_HIP_CHECK(hipGetLastError());
-    return AMP_OK;
+    return amp::upsample2_bwd_run(ctx, dfine, dcoarse, B, Hc, Wc, C, 0);
 }
 
 int amp_subsample2_bwd(amp_ctx* ctx, const float* dy, float* dx, int B, int H, int W, int C) {
