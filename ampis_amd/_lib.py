@@ -53,6 +53,10 @@ class ProfSummary(C.Structure):
     _fields_ = [("launches", C.c_longlong * 3), ("ms", C.c_double * 3), ("flops", C.c_double * 3), ("truncated", C.c_int)]
 
 
+class ProfLaunch(C.Structure):
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("slot", C.c_int)]
+
+
 class Dets(C.Structure):
     _fields_ = [("B", C.c_int), ("D", C.c_int), ("n", C.POINTER(C.c_int)), ("boxes", C.POINTER(C.c_float)),
                 ("scores", C.POINTER(C.c_float)), ("classes", C.POINTER(C.c_int)),
@@ -90,6 +94,7 @@ def _declare(L):
         "amp_prof_begin": ([vp, i], i),
         "amp_prof_end": ([vp, C.POINTER(ProfSummary)], i),
         "amp_prof_pause": ([vp, i], i),
+        "amp_prof_launches": ([vp, C.POINTER(ProfLaunch), i, C.POINTER(i)], i),
         "amp_timer_stop": ([vp, C.POINTER(f)], i),
         "amp_destroy": ([vp], None),
         "amp_sync": ([vp], i),
@@ -270,6 +275,14 @@ class Context:
         s = ProfSummary()
         check(lib().amp_prof_end(self._h, C.byref(s)), "amp_prof_end")
         return {"launches": list(s.launches), "ms": list(s.ms), "flops": list(s.flops), "truncated": bool(s.truncated)}
+
+    def prof_launches(self):
+        """After prof_end: the recorded launches in launch order, dicts of ms / flops / bytes (algorithmic) / M / N / K / slot."""
+        n = C.c_int(0)
+        check(lib().amp_prof_launches(self._h, None, 0, C.byref(n)), "amp_prof_launches")
+        buf = (ProfLaunch * max(n.value, 1))()
+        check(lib().amp_prof_launches(self._h, buf, n.value, C.byref(n)), "amp_prof_launches")
+        return [{"ms": r.ms, "flops": r.flops, "bytes": r.bytes, "M": r.M, "N": r.N, "K": r.K, "slot": r.slot} for r in buf[:n.value]]
 
     # ---- RCCL communicator of this context (include/ampis_hip.h "Multi-GPU exchange") ----
     COMM_ID_BYTES = 128

@@ -108,7 +108,7 @@ struct ProfLaunchScope {          // attaches a profile record's events to the t
 
 #include <vector>
 struct amp_comm;   // comm.hip: RCCL communicator + its stream and events
-struct amp_prof_rec { hipEvent_t e0, e1; double flops; int variant; };
+struct amp_prof_rec { hipEvent_t e0, e1; double flops; int variant; double bytes = 0; int M = 0, N = 0, K = 0; };   // bytes: algorithmic (every operand once)
 struct amp_ctx {
     int device;
     hipStream_t stream;

@@ -106,6 +106,7 @@ int amp_prof_begin(amp_ctx* ctx, int max_launches) {
         AMP_HIP_CHECK(hipEventCreate(&r.e0));
         AMP_HIP_CHECK(hipEventCreate(&r.e1));
         r.flops = 0; r.variant = 0;
+        r.bytes = 0; r.M = r.N = r.K = 0;
         ctx->prof_pool.push_back(r);
     }
     ctx->prof_used = 0;
@@ -135,6 +136,20 @@ int amp_prof_end(amp_ctx* ctx, amp_prof_summary* out) {
         out->flops[v] += r.flops;
     }
     out->truncated = ctx->prof_truncated ? 1 : 0;
+    return AMP_OK;
+}
+
+int amp_prof_launches(amp_ctx* ctx, amp_prof_launch* out, int cap, int* n_out) {
+    AMP_REQUIRE(ctx && n_out && (out || cap == 0) && cap >= 0, "amp_prof_launches: bad argument");
+    AMP_REQUIRE(!ctx->prof_on, "amp_prof_launches: call amp_prof_end first (it waits for the events)");
+    *n_out = (int)ctx->prof_used;
+    for (size_t i = 0; i < ctx->prof_used && (int)i < cap; ++i) {
+        const amp_prof_rec& r = ctx->prof_pool[i];
+        float ms = 0.f;
+        AMP_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        out[i].ms = ms; out[i].flops = r.flops; out[i].bytes = r.bytes;
+        out[i].M = r.M; out[i].N = r.N; out[i].K = r.K; out[i].slot = r.variant;
+    }
     return AMP_OK;
 }
 

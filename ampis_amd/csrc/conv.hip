@@ -466,28 +466,49 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
         }
     }
     f32x2 chk = {0.f, 0.f};
+    // The residual rows of ALL four row groups are requested before the first store: y and res may alias as far as the compiler knows, so
+    // it keeps a group's loads behind the previous group's stores -- and loads return in order BEHIND older stores (one vmcnt queue), so
+    // every group paid a store round trip plus a load round trip.  The 64 registers are the cross-term accumulators', dead since the fold.
+    f16x8 rha[4][2], rla[4][2];
+#ifdef AMP_NO_HOIST
+    constexpr bool HOIST = false;
+#else
+    constexpr bool HOIST = true;
+#endif
+    auto load_res = [&](int i) {
+        {
+            const unsigned int m = min((unsigned int)(mw0 + i * 16 + l15), (unsigned int)(a.M - 1));
+            size_t rrow = (size_t)m * a.Cout;
+            if (SPATIAL && a.res_mode == 2) {
+                const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+                const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
+                const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+                const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+                rrow = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout;
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const char* rb = reinterpret_cast<const char*>(a.res + rrow) + colb[g];
+                rha[i][g] = *reinterpret_cast<const f16x8*>(rb);
+                rla[i][g] = *reinterpret_cast<const f16x8*>(rb + 64);
+            }
+        }
+    };
+    if (has_res && HOIST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_res(i);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int mrow = mw0 + i * 16 + l15;
         const bool mv = mrow < a.M;
         const unsigned int m = min((unsigned int)mrow, (unsigned int)(a.M - 1));
         const size_t yrow = (size_t)m * a.Cout;
-        size_t rrow = yrow;
-        if (SPATIAL && a.res_mode == 2) {
-            const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
-            const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
-            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
-            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
-            rrow = ((size_t)(b * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * a.Cout;
-        }
         f16x8 rh[2], rl[2], mh[2], ml[2];
         if (has_res) {
+            if (!HOIST) load_res(i);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const char* rb = reinterpret_cast<const char*>(a.res + rrow) + colb[g];
-                rh[g] = *reinterpret_cast<const f16x8*>(rb);
-                rl[g] = *reinterpret_cast<const f16x8*>(rb + 64);
-            }
+            for (int g = 0; g < 2; ++g) { rh[g] = rha[i][g]; rl[g] = rla[i][g]; }
         }
         if (has_mask) {                                  // the gating activation (training), split rows indexed like y
 #pragma unroll
@@ -1224,16 +1245,16 @@ __device__ unsigned long long g_stamp[8 * 8];
 #define STAMP_T(var)
 #define STAMP_ADD(slot, t0, t1)
 #endif
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, 1) void conv_split_kernel(const ConvArgs a, const unsigned int x_bytes,
-                                                                                    const unsigned int w_bytes) {
+template <int BM, int BN, int EPI, int NSTAGE = 3>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) void conv_split_kernel(const ConvArgs a, const unsigned int x_bytes,
+                                                                                                     const unsigned int w_bytes) {
     constexpr int WTM = 64, WTN = 64;
     constexpr int NWM = BM / WTM, NWN = BN / WTN, NW = NWM * NWN;
     constexpr int MB = WTM / 16, NB = WTN / 16;
     constexpr int GA = BM / NW / 8;       // DMA instructions per wave per K-step for A (8 rows x 128 B each)
     constexpr int GB = BN / NW / 8;       // ... for B
     constexpr int NDMA = GA + GB;
-    constexpr int NSTAGE = 3;
+    // NSTAGE = 2 (128 x 128 tiles, K <= 64: both K-steps staged at once, nothing restaged): 68 KB of LDS, 4 waves -> TWO workgroups per CU
     constexpr int TILE_FLOATS = (BM + BN) * BK;
     constexpr int SLD = WTN + 4;
     constexpr int STAGE_FLOATS = NW * WTM * SLD;
@@ -1981,6 +2002,11 @@ void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, u
     if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     else AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
 }
+// the two-workgroups-per-CU form for K <= 64 (both K-steps resident, no ping-pong: the SIMD partner is the other workgroup's wave)
+static void launch_split_short(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
+    if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<128, 128, 2, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+    else AMP_TIMED_LAUNCH((conv_split_kernel<128, 128, 1, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+}
 
 void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (epi == 1) AMP_TIMED_LAUNCH((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
@@ -2019,6 +2045,8 @@ void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
 
 static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles where Cout % 256 == 0
 extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
+static int g_short_k = getenv("AMP_NO_SHORT_K") ? 0 : 1;      // EXPERIMENT switch: K <= 64 layers on 128 x 128 tiles, two workgroups per CU (0: the 128 x 256 ring tiles)
+extern "C" void amp_debug_set_short_k(int v) { g_short_k = v; }
 static int g_split_ring = getenv("AMP_SPLIT_RING") ? atoi(getenv("AMP_SPLIT_RING")) : 1;    // EXPERIMENT switch: the 3-buffer conv_split_kernel for pre-split inputs (0: the 2-buffer conv_glds_kernel<.., F16>)
 extern "C" void amp_debug_set_split_ring(int v) { g_split_ring = v; }
 #ifdef AMP_STAMP
@@ -2431,6 +2459,8 @@ int amp::stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)B * a.Ho * a.Wo * 64.0 * 7.0 * 8.0 * 4.0;   // useful work of the stem (as conv_run counts it), not the halo
             rec->variant = 1;
+            rec->bytes = (double)x_bytes + (double)w_bytes + 4.0 * (double)B * sp.Hq * sp.Wq * 64.0;   // input + weights + the pooled tensor
+            rec->M = B * a.Ho * a.Wo; rec->N = 64; rec->K = 7 * 8 * 4;
         } else {
             ctx->prof_truncated = true;
         }
@@ -2476,6 +2506,8 @@ int amp::stem_pool_u8_run(amp_ctx* ctx, const uint8_t* img, int B, int H, int W,
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)B * a.Ho * a.Wo * 64.0 * 7.0 * 8.0 * 4.0;   // useful work of the stem (as conv_run counts it), not the halo
             rec->variant = 1;
+            rec->bytes = 3.0 * (double)B * H * W + (double)w_bytes + 4.0 * (double)B * sp.Hq * sp.Wq * 64.0;       // uint8 pixels + weights + the pooled tensor
+            rec->M = B * a.Ho * a.Wo; rec->N = 64; rec->K = 7 * 8 * 4;
         } else {
             ctx->prof_truncated = true;
         }
@@ -2577,6 +2609,13 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         a.y_split = 0;
         a.rpn_w = rpn->w_split; a.rpn_b = rpn->bias; a.rpn_pred = rpn->pred;
     }
+    if (rec) {      // algorithmic bytes of this launch: every operand once (amp_prof_launches; a 1x1 conv reads only the pixels its stride samples)
+        const double in_rows = (a.KH == 1 && a.KW == 1) ? (double)a.M : (double)a.B * a.H * a.W;
+        const double out_vals = a.out_mode == 3 ? (double)a.M * 4.0 : a.out_mode == 4 ? (double)a.M * 16.0 : (double)a.M * a.Cout;
+        const double res_vals = !res ? 0.0 : (a.res_mode == 2 ? (double)a.M * a.Cout / 4.0 : (double)a.M * a.Cout);
+        rec->bytes = 4.0 * (in_rows * a.Cin + (double)a.Cout * a.K + out_vals + res_vals + (mask ? (double)a.M * a.Cout : 0.0));
+        rec->M = a.M; rec->N = a.Cout; rec->K = d->KH * d->KW * cpg;
+    }
     AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
     AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
@@ -2613,6 +2652,13 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         } else if (a.out_mode == 4) {                                        // fused RPN tail: one N tile
             a.ntn = 1; a.nblk = ntm;
             launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (x_is_split && g_split_ring && g_short_k && epi != 0 && !a.grouped && a.nsteps <= 2 && res && a.res_mode == 1 && a.res_split && a.y_split && !mask &&
+                   a.Cout % 128 == 0 && ntm * (a.Cout / 128) >= 1024) {
+            // res2's conv3 + residual (K = 64, byte-bound): 128 x 128 tiles, both K-steps resident, TWO workgroups per CU -- one's residual
+            // loads and stores overlap the other's staging: -5 % on these launches (A/B in one call); without a residual it is 4 % slower
+            a.ntn = a.Cout / 128; a.nblk = ntm * a.ntn;
+            a.stagger = 0;
+            launch_split_short(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

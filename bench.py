@@ -83,6 +83,37 @@ PROF_EVERY = 10                # timed launches (events attached to the dispatch
                                # default 50 steps = 270 launches of the dominant kernel
 
 
+PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def by_bound(launches, mode, steps):
+    """Per-LAUNCH roofline of the conv launches of the sampled steps (amp_prof_launches: HIP-event duration, algorithmic flops and algorithmic
+    bytes of each): a launch is bounded by whichever of flops / matrix peak and bytes / HBM peak is the longer time (the short-K 1x1 layers of
+    res2-res4 and the FPN laterals move 2-4 x more bytes than the matrix pipe needs time for).  Returns, per bound, the launches, their measured
+    time, the achieved rate and frac = sum of the bound's ideal times / sum of the measured times; `all` = the same over every launch."""
+    peak = (PEAK_F16X3_TFLOPS if mode == "f16x3" else PEAK_F32_MFMA_TFLOPS) * 1e12
+    g = {"mfma": [0, 0.0, 0.0, 0.0, 0.0], "hbm": [0, 0.0, 0.0, 0.0, 0.0]}      # launches, ms, ideal ms, flops, bytes
+    for r in launches:
+        if r["slot"] == 2 or r["ms"] <= 0:
+            continue
+        t_m, t_h = r["flops"] / peak * 1e3, r["bytes"] / (PEAK_HBM_TBS * 1e12) * 1e3
+        k = "mfma" if t_m >= t_h else "hbm"
+        g[k][0] += 1; g[k][1] += r["ms"]; g[k][2] += max(t_m, t_h); g[k][3] += r["flops"]; g[k][4] += r["bytes"]
+    out = {}
+    for k, (n, ms, ideal, fl, by) in g.items():
+        if n == 0:
+            continue
+        out[k] = {"launches_per_step": round(n / max(steps, 1), 1), "kernel_ms_per_step": round(ms / max(steps, 1), 3),
+                  "achieved": round(fl / (ms * 1e-3) / 1e12, 2) if k == "mfma" else round(by / (ms * 1e-3) / 1e12, 3),
+                  "peak": round(peak / 1e12, 1) if k == "mfma" else PEAK_HBM_TBS, "unit": "TFLOP/s" if k == "mfma" else "TB/s (algorithmic bytes)",
+                  "frac": round(ideal / ms, 4)}
+    tot_ms = sum(v[1] for v in g.values())
+    if tot_ms > 0:
+        out["all"] = {"frac": round(sum(v[2] for v in g.values()) / tot_ms, 4),
+                      "what": "sum over launches of max(flops / matrix peak, algorithmic bytes / HBM peak) / sum of measured durations"}
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -490,6 +521,7 @@ def main(args):
         el = time.perf_counter() - t0
         prof = ctx.prof_end()
         prof["steps"] = prof_steps
+        prof["by_bound"] = by_bound(ctx.prof_launches(), mode, prof_steps)
         log(f"[{mode}] timed {steps} steps in {el:.3f} s")
         ranks.barrier()
         return ranks.max(el), prof, ndet
@@ -549,7 +581,7 @@ def main(args):
                          "all_conv_ms_per_step": round(all_conv_ms, 3),
                          "non_conv_ms_per_step": round(ms_per_step - all_conv_ms, 3),
                          "events_on": f"every {PROF_EVERY}th timed step ({prof['steps']} of {args.steps} steps, {prof['launches'][0]} launches of the dominant kernel)",
-                         "all_conv_tflops": round(conv_all, 2), "truncated": prof["truncated"]},
+                         "all_conv_tflops": round(conv_all, 2), "by_bound": prof["by_bound"], "truncated": prof["truncated"]},
         }
         rp = rocprof_reported("infer") if mode == "f16x3" else None
         if rp:

@@ -68,6 +68,16 @@ int  amp_prof_begin(amp_ctx* ctx, int max_launches);
 int  amp_prof_end(amp_ctx* ctx, amp_prof_summary* out);
 /* between begin and end: stop / resume recording (the event pairs themselves cost ~5 us of idle GPU per launch: sample some steps) */
 int  amp_prof_pause(amp_ctx* ctx, int paused);
+/* After amp_prof_end: the recorded launches one by one, in launch order -- duration, algorithmic FLOPs and algorithmic BYTES (every
+ * operand the launch must read and every value it must write, once: sampled input rows + weights + output + residual / mask), and the
+ * GEMM shape M x N x K.  What a per-layer roofline needs: a short-K 1x1 layer is bounded by its bytes, not by the matrix pipe
+ * (tools/layer_roofline.py).  *n_out = number of recorded launches (may exceed cap; the first cap are written). */
+typedef struct amp_prof_launch {
+    double ms, flops, bytes;
+    int M, N, K;
+    int slot;                 /* index into amp_prof_summary's arrays */
+} amp_prof_launch;
+int  amp_prof_launches(amp_ctx* ctx, amp_prof_launch* out, int cap, int* n_out);
 
 /* Device memory helpers (so that hosts without torch can drive the library) ----------------- */
 int amp_malloc(amp_ctx* ctx, size_t bytes, void** out);

@@ -567,3 +567,33 @@ def test_fused_stem_pool_is_bit_identical(gpu_ctx, B, H, W):
         assert np.array_equal(taps[0].view(np.uint32), taps[k].view(np.uint32)), k
         for x, y in zip(outs[0], outs[k]):
             assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 256, 64, 256, True, True), (3, 250, 237, 64, 256, True, False),
+                                   (8, 128, 128, 32, 128, True, True), (2, 256, 256, 64, 128, True, True)])
+def test_short_k_two_workgroup_tiles_are_bit_identical(gpu_ctx, shape):
+    """K <= 64 layers (res2's conv3 and shortcut: byte-bound) run on 128 x 128 tiles with both K-steps resident, two workgroups per CU
+    (`conv_split_kernel<128, 128, ., 2>`), instead of one 128 x 256 ring tile per CU: same products in the same order, same epilogue -- bit
+    for bit with and without residual / scale / ReLU, on pixel counts that are not multiples of the tile; launches reproduce."""
+    from ampis_amd import ops
+    from ampis_amd._lib import lib
+    B, H, W, Cin, Cout, res, relu = shape
+    g = torch.Generator().manual_seed(B * H + W + Cin)
+    x = ops.split_rows(gpu_ctx, torch.randn(B, H, W, Cin, generator=g).cuda())
+    w = (torch.randn(Cout, 1, 1, Cin, generator=g) * 0.1).cuda()
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() if res else None
+    sh = torch.randn(Cout, generator=g).cuda()
+    kw = dict(stride=1, pad=0, relu=relu, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+    if res:
+        kw.update(res=ops.split_rows(gpu_ctx, torch.randn(B, H, W, Cout, generator=g).cuda()), res_mode=1, fmt=kw["fmt"] | ops.FMT_RES_SPLIT)
+    try:
+        lib().amp_debug_set_short_k(0)
+        ref = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw).clone()
+        lib().amp_debug_set_short_k(1)
+        for _ in range(10):
+            y = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int32), ref.view(torch.int32))
+    finally:
+        lib().amp_debug_set_short_k(1)
+    assert float(ops.unsplit_rows(gpu_ctx, ref).abs().max()) > 0

@@ -19,6 +19,9 @@ def main():
         w = torch.randn(Cout, k, k, Cin, device="cuda:0") * 0.05
         sc = torch.ones(Cout, device="cuda:0"); sh = torch.zeros(Cout, device="cuda:0")
         kw = dict(stride=1, pad=p, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+        if os.environ.get("AMP_STAMP_RES"):      # with a split residual (the trunk's conv3)
+            kw.update(res=ops.split_rows(ctx, torch.randn(B, H, W, Cout, device="cuda:0")), res_mode=1, fmt=kw["fmt"] | ops.FMT_RES_SPLIT)
+            name = name + "+res"
         for _ in range(2):
             ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
         torch.cuda.synchronize()
