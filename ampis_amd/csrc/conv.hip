@@ -498,6 +498,21 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_res(i);
     }
+    // the same for the gating activation (training: data gradients): all four row groups up front
+    f16x8 mha[4][2], mla[4][2];
+    auto load_mask = [&](int i) {
+        const unsigned int m = min((unsigned int)(mw0 + i * 16 + l15), (unsigned int)(a.M - 1));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const char* mb = reinterpret_cast<const char*>(a.mask + (size_t)m * a.Cout) + colb[g];
+            mha[i][g] = *reinterpret_cast<const f16x8*>(mb);
+            mla[i][g] = *reinterpret_cast<const f16x8*>(mb + 64);
+        }
+    };
+    if (has_mask && HOIST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_mask(i);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int mrow = mw0 + i * 16 + l15;
@@ -511,12 +526,9 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
             for (int g = 0; g < 2; ++g) { rh[g] = rha[i][g]; rl[g] = rla[i][g]; }
         }
         if (has_mask) {                                  // the gating activation (training), split rows indexed like y
+            if (!HOIST) load_mask(i);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const char* mb = reinterpret_cast<const char*>(a.mask + yrow) + colb[g];
-                mh[g] = *reinterpret_cast<const f16x8*>(mb);
-                ml[g] = *reinterpret_cast<const f16x8*>(mb + 64);
-            }
+            for (int g = 0; g < 2; ++g) { mh[g] = mha[i][g]; ml[g] = mla[i][g]; }
         }
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
