@@ -960,7 +960,8 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)M * (double)a.N * (double)a.Kp;
             rec->variant = 2;
-            rec->bytes = 4.0 * ((double)M * a.N + (double)a.B * a.H * a.W * a.Cin + (double)a.N * a.Kp);     // dY + X + dW once (the split-K slabs not counted)
+            // dY + X (a 1x1 layer reads only the pixels its stride samples) + dW once; the split-K slabs are not counted
+            rec->bytes = 4.0 * ((double)M * a.N + ((a.KH == 1 && a.KW == 1) ? (double)M : (double)a.B * a.H * a.W) * a.Cin + (double)a.N * a.Kp);
             rec->M = a.N; rec->N = a.Kp; rec->K = M;
         } else {
             ctx->prof_truncated = true;
