@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
     constexpr int GA = BM / NW / 8;       // DMA instructions per wave per K-step for A (8 rows x 128 B each)
     constexpr int GB = BN / NW / 8;       // ... for B
     constexpr int NDMA = GA + GB;
-    // NSTAGE = 2 (128 x 128 tiles, K <= 64: both K-steps staged at once, nothing restaged): 68 KB of LDS, 4 waves -> TWO workgroups per CU
+    // NSTAGE = 2 (128 x 128 tiles, byte-bound short-K layers): 68 KB of LDS, 4 waves -> TWO workgroups per CU
     constexpr int TILE_FLOATS = (BM + BN) * BK;
     constexpr int SLD = WTN + 4;
     constexpr int STAGE_FLOATS = NW * WTM * SLD;
@@ -1408,6 +1408,16 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
             f16x3_load16<MB, NB>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
             __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t2);
+            if constexpr (NSTAGE == 2) {
+                // two buffers: tile step+2 goes into the buffer of tile `step` itself, once every wave holds its fragments in registers
+                if (step + 2 < a.nsteps) {
+                    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): this wave's fragment reads have returned
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    stage(cur);
+                }
+            } else
             if (step + 2 < a.nsteps) stage(nxt);   // into the buffer tile step-1 occupied
             __builtin_amdgcn_sched_barrier(0);
             STAMP_T(t3);
@@ -2014,7 +2024,7 @@ void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, u
     if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
     else AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 1>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
 }
-// the two-workgroups-per-CU form for K <= 64 (both K-steps resident, no ping-pong: the SIMD partner is the other workgroup's wave)
+// the two-workgroups-per-CU form (two buffers, no ping-pong: the SIMD partner is the other workgroup's wave)
 static void launch_split_short(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<128, 128, 2, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     else AMP_TIMED_LAUNCH((conv_split_kernel<128, 128, 1, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
@@ -2057,6 +2067,7 @@ void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
 
 static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles where Cout % 256 == 0
 extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
+static int g_short_k_steps = getenv("AMP_SHORT_K_STEPS") ? atoi(getenv("AMP_SHORT_K_STEPS")) : 16;     // K <= 512 (2: K <= 64 only)
 static int g_short_k = getenv("AMP_NO_SHORT_K") ? 0 : 1;      // EXPERIMENT switch: K <= 64 layers on 128 x 128 tiles, two workgroups per CU (0: the 128 x 256 ring tiles)
 extern "C" void amp_debug_set_short_k(int v) { g_short_k = v; }
 static int g_split_ring = getenv("AMP_SPLIT_RING") ? atoi(getenv("AMP_SPLIT_RING")) : 1;    // EXPERIMENT switch: the 3-buffer conv_split_kernel for pre-split inputs (0: the 2-buffer conv_glds_kernel<.., F16>)
@@ -2664,10 +2675,12 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         } else if (a.out_mode == 4) {                                        // fused RPN tail: one N tile
             a.ntn = 1; a.nblk = ntm;
             launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-        } else if (x_is_split && g_split_ring && g_short_k && epi != 0 && !a.grouped && a.nsteps <= 2 && res && a.res_mode == 1 && a.res_split && a.y_split && !mask &&
+        } else if (x_is_split && g_split_ring && g_short_k && epi != 0 && !a.grouped && a.nsteps <= g_short_k_steps && res && a.res_mode == 1 && a.res_split && a.y_split && !mask &&
                    a.Cout % 128 == 0 && ntm * (a.Cout / 128) >= 1024) {
-            // res2's conv3 + residual (K = 64, byte-bound): 128 x 128 tiles, both K-steps resident, TWO workgroups per CU -- one's residual
-            // loads and stores overlap the other's staging: -5 % on these launches (A/B in one call); without a residual it is 4 % slower
+            // the trunk's conv3 + residual (K = 64 ... 256 into 4 K channels: byte-bound): 128 x 128 tiles on TWO buffers -- tile s + 2 goes into
+            // the buffer of tile s once every wave holds its fragments, same prefetch distance as the three-buffer ring -- so that TWO
+            // workgroups fit a CU and one's residual loads and stores overlap the other's staging: res2 -5 %, res3 -8 %, res4 -3 % on these
+            // launches (A/B in one call; bit-identical); without a residual it is 4 % slower
             a.ntn = a.Cout / 128; a.nblk = ntm * a.ntn;
             a.stagger = 0;
             launch_split_short(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -570,9 +570,9 @@ def test_fused_stem_pool_is_bit_identical(gpu_ctx, B, H, W):
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 256, 64, 256, True, True), (3, 250, 237, 64, 256, True, False),
-                                   (8, 128, 128, 32, 128, True, True), (2, 256, 256, 64, 128, True, True)])
+                                   (8, 128, 128, 32, 128, True, True), (2, 256, 256, 64, 128, True, True), (2, 128, 128, 128, 512, True, True), (4, 64, 64, 256, 1024, True, True), (4, 130, 127, 512, 256, True, False)])
 def test_short_k_two_workgroup_tiles_are_bit_identical(gpu_ctx, shape):
-    """K <= 64 layers (res2's conv3 and shortcut: byte-bound) run on 128 x 128 tiles with both K-steps resident, two workgroups per CU
+    """K <= 512 layers with a residual (the trunk.s conv3: byte-bound) run on 128 x 128 tiles on two buffers, two workgroups per CU
     (`conv_split_kernel<128, 128, ., 2>`), instead of one 128 x 256 ring tile per CU: same products in the same order, same epilogue -- bit
     for bit with and without residual / scale / ReLU, on pixel counts that are not multiples of the tile; launches reproduce."""
     from ampis_amd import ops
