@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
@@ -91,7 +92,41 @@ __global__ void fill16_hash(f32x4* __restrict__ out, size_t n, unsigned int seed
     }
 }
 
-int main() {
+// `hbm_probe chain`: a producer -> consumer chain (copy x -> y, then y -> x, ...) on buffers of S MiB: what a layer gets that reads the
+// tensor the previous launch wrote, as a function of the tensor size against the 256-MB Infinity Cache
+static int chain_main() {
+    const size_t cap = (size_t)512 << 20;
+    char *x, *y; CK(hipMalloc(&x, cap)); CK(hipMalloc(&y, cap)); CK(hipMemset(x, 1, cap)); CK(hipMemset(y, 2, cap));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("producer -> consumer chain, split-row shape copy x -> y -> x ... (grid 8192 x 256):\n");
+    for (int mib : {16, 32, 48, 64, 96, 128, 192, 256, 512}) {
+        const size_t bytes = (size_t)mib << 20, nrows = bytes / 1024;
+        const int reps = 24;
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL((rows64<true, true>), dim3(8192), dim3(256), 0, 0, (i & 1) ? y : x, (i & 1) ? x : y, nrows);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((rows64<true, true>), dim3(8192), dim3(256), 0, 0, (i & 1) ? y : x, (i & 1) ? x : y, nrows);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  tensor %4d MiB (working set %4d MiB)  %8.1f us  %6.2f TB/s\n", mib, 2 * mib, ms / reps * 1e3, 2.0 * bytes / (ms / reps * 1e-3) / 1e12);
+    }
+    printf("read-only sweeps of one buffer, repeated (float4 read, grid 8192 x 256):\n");
+    for (int mib : {16, 32, 64, 128, 192, 256, 512}) {
+        const size_t bytes = (size_t)mib << 20;
+        const int reps = 24;
+        for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)y, bytes / 16);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const f32x4*)x, (f32x4*)y, bytes / 16);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  buffer %4d MiB  %8.1f us  %6.2f TB/s\n", mib, ms / reps * 1e3, 1.0 * bytes / (ms / reps * 1e-3) / 1e12);
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "chain") return chain_main();
     const size_t bytes = (size_t)512 << 20, n16 = bytes / 16, nrows = bytes / 1024;
     std::vector<char*> a(3), b(3);
     for (int i = 0; i < 3; ++i) { CK(hipMalloc(&a[i], bytes)); CK(hipMalloc(&b[i], bytes)); CK(hipMemset(a[i], 1, bytes)); CK(hipMemset(b[i], 2, bytes)); }
