@@ -103,6 +103,7 @@ struct amp_model {
     bool saving = false;                // run_trunk keeps every activation the backward pass needs
     bool acts_split = false;            // ... and kept them in the split row format (training on the native trunk, AMP_CONV_F16X3)
     bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
+    bool mask_tail_split = false;       // ... and fcn4's output (the deconv's input): the deconv and its three gradient launches on pre-split operands
     struct BlockAct { std::string key; float *x_in, *t1, *t2, *sc, *out; int in_h, in_w, oh, ow, cin, mid, cout, stride, stage; bool has_sc; };
     std::vector<BlockAct> blocks;
     float* lat[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -136,6 +137,8 @@ struct amp_model {
 
 static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
 extern "C" void amp_debug_set_split_chain(int on) { g_split_chain = on; }
+static int g_mask_tail_split = -1;   // -1: from the environment (AMP_NO_MASK_TAIL_SPLIT), 0 / 1: set by amp_debug_set_mask_tail_split (tests)
+extern "C" void amp_debug_set_mask_tail_split(int on) { g_mask_tail_split = on; }
 
 namespace {
 
@@ -1001,13 +1004,19 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // hb/hc/hp are temporaries
         const bool MS = backward && m->acts_split && split_chain(m, {"roi_heads.mask_head.mask_fcn1", "roi_heads.mask_head.mask_fcn2",
                                                                       "roi_heads.mask_head.mask_fcn3", "roi_heads.mask_head.mask_fcn4"});
-        m->mask_acts_split = MS;          // macts[0..3] split, macts[4] (the deconv's input: an operand of ITS weight gradient) fp32
+        m->mask_acts_split = MS;          // macts[0..3] split
+        // macts[4] (the deconv's input, the 'dy' operand of ITS weight gradient and the mask of its data gradient) split as well: the deconv runs on
+        // the ring kernel, the predictor's data gradient leaves d(deconv out) * 2^16 as split rows with the deconv's bias sums on the side, and the
+        // deconv's weight- and data-gradient launches stage both operands as they are (AMP_NO_MASK_TAIL_SPLIT: fp32 macts[4] and d_mtb as before)
+        static const bool no_mt = getenv("AMP_NO_MASK_TAIL_SPLIT") != nullptr;      // EXPERIMENT switch
+        const bool MT = MS && (g_mask_tail_split < 0 ? !no_mt : g_mask_tail_split != 0) && Kp <= 16 && (size_t)N * 784 * 256 * 4 < 0x80000000ull && ((long long)N * 196 + 127) / 128 >= 512 /* the ring kernel takes the deconv's data gradient */ && split_chain(m, {"roi_heads.mask_head.deconv"});
+        m->mask_tail_split = MT;
         AMP_TRY(amp::roi_align_run(ctx, &T.ff, m_rois, m_batch, nullptr, N, 14, mpooled, nullptr, MS ? 1 : 0, T.feat_split ? 1 : 0));
         for (int i = 1; i <= 4; ++i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
-            AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i], MS ? (i < 4 ? 3 : 1) : 0));
+            AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i], MS ? ((i < 4 || MT) ? 3 : 1) : 0));
         }
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, MT ? 1 : 0));
         AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
         if (n_runs) {
             // bitmask ground truth: BitMasks.crop_and_resize from the run lengths.  The runs travel in a buffer of their own (their
@@ -1176,23 +1185,27 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     if (!dry && N > 0) {
         const ConvW& cp = CONV("roi_heads.mask_head.predictor");
         AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false, true));
-        AMP_TRY(amp_small_k_dgrad(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, (size_t)N * 784));
+        const bool MT = m->mask_tail_split && ctx->conv_mode == AMP_CONV_F16X3;
+        if (MT) AMP_TRY(amp_small_k_dgrad_split_f32act(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, N * 784, 16, cs_scratch, dbd_t, 0));    // + the deconv's bias sums
+        else AMP_TRY(amp_small_k_dgrad(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, (size_t)N * 784));
         const ConvW& cd = CONV("roi_heads.mask_head.deconv");
         {   // weight gradient in [ci][tap][co] form, then transposed into the forward layout [(tap,co)][ci]
             amp_conv_desc d;
             d.B = N; d.H = 28; d.W = 28; d.Cin = 256; d.Cout = 256; d.KH = 2; d.KW = 2; d.stride = 2; d.pad = 0; d.relu = 0; d.res_mode = 0; d.out_mode = 0;
             AMP_REQUIRE(amp_conv_wgrad_scratch_floats(&d) <= WG_SCRATCH, "backward: wgrad scratch too small");
-            AMP_TRY(amp_conv2d_wgrad_scaled(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0, 0, 16));   // here the gradient is the 'x' operand
+            // here the gradient is the 'x' operand (MT: both operands split rows, the 2^16 sits in x and is undone like a dy shift)
+            if (MT) AMP_TRY(amp_conv2d_wgrad_fmt(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0, 16, 0, 3, nullptr, 0));
+            else AMP_TRY(amp_conv2d_wgrad_scaled(ctx, &d, d_mtb, macts[4], nullptr, wg_scratch, dwd_t, 0, 0, 16));
             AMP_TRY(amp::wgrad_async_join(ctx));      // dwd_t is read right away
             AMP_TRY(amp_deconv_grad_transpose(ctx, dwd_t, GW(cd), 256, 4, 256, 0));
-            AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
+            if (!MT) AMP_TRY(amp_colsum(ctx, d_mtb, N * 784, 256, cs_scratch, dbd_t, 0));
             for (int q = 0; q < 4; ++q) AMP_HIP_CHECK(hipMemcpyAsync(GB(cd) + q * 256, dbd_t, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
             // data gradient: a 2x2 stride-2 convolution of d_mtb with w[ci][ky][kx][co], masked by fcn4's ReLU
             const float* wsp = (cd.scale == nullptr && cd.cout == 1024 && cd.cin == 256) ? dgrad_wsplit(cd, N, 28, 28) : nullptr;   // [ci][(tap, co)] = the 2x2 window rows
             if (!wsp) AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
             amp_conv_desc g;
             g.B = N; g.H = 28; g.W = 28; g.Cin = 256; g.Cout = 256; g.KH = 2; g.KW = 2; g.stride = 2; g.pad = 0; g.relu = 0; g.res_mode = 0; g.out_mode = 0;
-            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16));
+            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16, MT ? (1 | 8) : 0));
         }
         float* dcur = d_ma;
         float* dnext = d_mb;

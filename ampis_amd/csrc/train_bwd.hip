@@ -452,7 +452,10 @@ __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K
 // p2), a mask pass and a conversion.  A thread owns 8 channels for all its rows: its 16 x 8 weights stay in registers, a row costs four
 // 16-B loads of dl (the same address for the 32 threads of the row), the mask halves, 120 FMAs and two 16-B stores.
 // 32 column groups x 8 row lanes per workgroup; partial [gridDim.x][C] for colsum_final.
+// ACT_SPLIT = false, LD4 = ld / 4 (the mask predictor behind the deconv: dl rows of Kp = 4 .. 16 floats, act = the deconv's fp32 output): the
+// same sums in the same order as small_k_dgrad_kernel, so dx is that kernel's value, scaled and split.
 typedef _Float16 sk_h8 __attribute__((ext_vector_type(8)));
+template <bool ACT_SPLIT, int LD4>
 __global__ __launch_bounds__(256) AMP_NO_PK void small_k_dgrad_split_kernel(const float* __restrict__ dl, int K, const float* __restrict__ w, int C,
                                                                    const float* __restrict__ act_split, float* __restrict__ dx_split, int npix,
                                                                    float* __restrict__ partial, float scale) {
@@ -463,30 +466,39 @@ __global__ __launch_bounds__(256) AMP_NO_PK void small_k_dgrad_split_kernel(cons
         const int ch = cbase + 8 * cg;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (ch < C) {
-            f32x4 wr[16][2];
+            f32x4 wr[4 * LD4][2];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < 4 * LD4; ++k) {
                 wr[k][0] = (k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
                 wr[k][1] = (k < K) ? *reinterpret_cast<const f32x4*>(w + (size_t)k * C + ch + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const size_t col_b = (size_t)(ch >> 5) * 128 + (size_t)(ch & 31) * 2;
             for (int r = r0 + rl; r < r1; r += 8) {
-                f32x4 d4[4];
+                f32x4 d4[LD4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) d4[q] = *reinterpret_cast<const f32x4*>(dl + (size_t)r * 16 + 4 * q);
+                for (int q = 0; q < LD4; ++q) d4[q] = *reinterpret_cast<const f32x4*>(dl + (size_t)r * (4 * LD4) + 4 * q);
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float d = d4[k >> 2][k & 3];
+                for (int k = 0; k < 4 * LD4; ++k) {
+                    const float d = (ACT_SPLIT || k < K) ? d4[k >> 2][k & 3] : 0.f;      // (the mask logits' pad columns are not written)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) v[q] = __fadd_rn(v[q], __fmul_rn(d, q < 4 ? wr[k][0][q] : wr[k][1][q - 4]));
                 }
-                const char* mb = reinterpret_cast<const char*>(act_split + (size_t)r * C) + col_b;
-                const sk_h8 mh = *reinterpret_cast<const sk_h8*>(mb), ml = *reinterpret_cast<const sk_h8*>(mb + 64);
+                float av[8];
+                if (ACT_SPLIT) {
+                    const char* mb = reinterpret_cast<const char*>(act_split + (size_t)r * C) + col_b;
+                    const sk_h8 mh = *reinterpret_cast<const sk_h8*>(mb), ml = *reinterpret_cast<const sk_h8*>(mb + 64);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) av[q] = (float)mh[q] + (float)ml[q] * (1.0f / 2048.0f);
+                } else {
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(act_split + (size_t)r * C + ch), m1 = *reinterpret_cast<const f32x4*>(act_split + (size_t)r * C + ch + 4);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) av[q] = q < 4 ? m0[q] : m1[q - 4];
+                }
                 sk_h8 hi, lo;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    const float g = ((float)mh[q] + (float)ml[q] * (1.0f / 2048.0f)) > 0.f ? v[q] : 0.f;
+                    const float g = av[q] > 0.f ? v[q] : 0.f;
                     acc[q] = __fadd_rn(acc[q], g);
                     const float x = g * scale;
                     const _Float16 h = (_Float16)x;
@@ -725,7 +737,23 @@ int amp_small_k_dgrad_split(amp_ctx* ctx, const float* dl, int K, const float* w
     AMP_REQUIRE(ctx && dl && w && act_split && dx_split && scratch && colsum_out && C % 32 == 0 && K >= 1 && K <= 16 && npix > 0 && shift >= 0 && shift <= 24,
                 "amp_small_k_dgrad_split: bad argument (dl rows are 16 floats, K <= 16)");
     const int parts = (npix + 511) / 512;
-    hipLaunchKernelGGL(small_k_dgrad_split_kernel, dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, ldexpf(1.0f, shift));
+    hipLaunchKernelGGL((small_k_dgrad_split_kernel<true, 4>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, ldexpf(1.0f, shift));
+    AMP_HIP_CHECK(hipGetLastError());
+    return amp_colsum_finish(ctx, scratch, parts, C, colsum_out, accumulate);
+}
+
+int amp_small_k_dgrad_split_f32act(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx_split, int npix,
+                                   int shift, float* scratch, float* colsum_out, int accumulate) {
+    AMP_REQUIRE(ctx && dl && w && act && dx_split && scratch && colsum_out && C % 32 == 0 && K >= 1 && K <= ld && ld % 4 == 0 && ld <= 16 && npix > 0 && shift >= 0 && shift <= 24,
+                "amp_small_k_dgrad_split_f32act: bad argument (dl rows are ld = 4, 8, 12 or 16 floats, K <= ld)");
+    const int parts = (npix + 511) / 512;
+    const float sc = ldexpf(1.0f, shift);
+    switch (ld / 4) {
+        case 1: hipLaunchKernelGGL((small_k_dgrad_split_kernel<false, 1>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act, dx_split, npix, scratch, sc); break;
+        case 2: hipLaunchKernelGGL((small_k_dgrad_split_kernel<false, 2>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act, dx_split, npix, scratch, sc); break;
+        case 3: hipLaunchKernelGGL((small_k_dgrad_split_kernel<false, 3>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act, dx_split, npix, scratch, sc); break;
+        default: hipLaunchKernelGGL((small_k_dgrad_split_kernel<false, 4>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act, dx_split, npix, scratch, sc); break;
+    }
     AMP_HIP_CHECK(hipGetLastError());
     return amp_colsum_finish(ctx, scratch, parts, C, colsum_out, accumulate);
 }

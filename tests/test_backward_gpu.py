@@ -271,3 +271,39 @@ def test_dgrad_weights_split_is_transpose_then_split(gpu_ctx, shape, scaled):
     one = ops.dgrad_weights_split(gpu_ctx, w, scale)
     torch.cuda.synchronize()
     assert torch.equal(one.view(torch.int32), two.view(torch.int32))
+
+
+def test_mask_tail_on_presplit_operands_agrees_with_the_fp32_storage_path():
+    """The mask head's tail of a training step with fcn4's output and d(deconv out) kept as split rows (deconv forward on the ring kernel, the
+    predictor's data gradient writing d * 2^16 as split rows with the deconv's bias sums on the side, the deconv's weight- and data-gradient
+    launches staging both operands as they are) against the same step with fp32 storage there (amp_debug_set_mask_tail_split(0)): identical
+    losses (the forward values do not depend on the storage), the same gradients up to summation order -- 512 foreground RoIs, so the path is live."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    K, B, S = 2, 4, 1024
+    imgs, gts = synth.batch(B, S, S, first_index=300)
+    gts = [dict(boxes=g["boxes"][:150], classes=g["classes"][:150], polygons=g["polygons"][:150]) for g in gts]
+    npp = P.init_params(K, seed=0, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 200, max_poly_doubles=B * 200 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    out = {}
+    try:
+        for on in (0, 1):
+            _lib.lib().amp_debug_set_mask_tail_split(on)
+            losses = m.forward_losses(imgs, gts, seed=11, backward=True)
+            out[on] = (losses, {k: m.get_tensor(k, grad=True) for k in names})
+    finally:
+        _lib.lib().amp_debug_set_mask_tail_split(-1)
+    assert not ctx.conv_range_flag()
+    assert out[0][0] == out[1][0]
+    changed = 0
+    for k in names:
+        r, g = out[0][1][k], out[1][1][k]
+        err = float(np.abs(g - r).max()) / max(float(np.abs(r).max()), 1e-8)
+        assert err < 2e-5, (k, err)
+        changed += int(not np.array_equal(r, g))
+    assert changed > 0, "the switch changed nothing: the split mask tail did not run"
+    m.close()
+    ctx.close()
