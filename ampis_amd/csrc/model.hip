@@ -1109,8 +1109,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
         // a big biased layer whose activation is already split (FPN output / RPN conv at p2, p3; the mask head): one pass over dy gives the bias
         // gradient AND dy * 2^16 in the split format, and the weight gradient runs on wgrad_split_kernel (+35-45 % on these shapes)
         static const bool no_conv = getenv("AMP_NO_DY_CONVERT") != nullptr;      // EXPERIMENT switch
+        static const long long dyc_min_rows = getenv("AMP_DY_CONVERT_MIN_ROWS") ? atoll(getenv("AMP_DY_CONVERT_MIN_ROWS")) : 200000;      // EXPERIMENT switch
         const long long Mo = (long long)B_ * ((H_ + 2 * pad - cw.kh) / stride + 1) * ((W_ + 2 * pad - cw.kw) / stride + 1);
-        if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && (Mo >= 200000 || (cw.kh * cw.kw * cw.cin >= 4096 && Mo >= 4096)) &&
+        if (bias && xfmt == 1 && GSW && !no_conv && cw.cout % 128 == 0 && cw.cin % 128 == 0 && cw.kh * cw.kw * cw.cin >= 256 && (Mo >= dyc_min_rows || (cw.kh * cw.kw * cw.cin >= 4096 && Mo >= 4096)) &&
             (size_t)Mo * cw.cout <= DYS_SCRATCH) {
             AMP_TRY(amp_colsum_split(ctx, dy, (int)Mo, cw.cout, cs_scratch, GB(cw), acc ? 1 : 0, dys_scratch, 16));
             dys_of = dy; dys_rows = Mo;                 // the data-gradient convolution of the same dy can stage this copy (dgrad below)

@@ -15,11 +15,14 @@ imgs, gts = synth.batch(B, S, S)
 print("gt per image", [len(g["boxes"]) for g in gts][:4], flush=True)
 for i in range(2):
     t = time.time(); L = model.forward_losses(imgs, gts, seed=i, backward=True); model.sgd_step(0.001); ctx.sync(); print("warm", time.time() - t, L, flush=True)
-n = 5
-t = time.time()
-for i in range(n):
-    L = model.forward_losses(imgs, gts, seed=10 + i, backward=True)
-    model.sgd_step(0.001)
-ctx.sync()
-dt = (time.time() - t) / n
+n = int(os.environ.get("BENCH_TRAIN_STEPS", "10"))
+dts = []
+for rep in range(3):          # three timed blocks, the fastest one reported (A/B runs of a few tenths of a millisecond need it)
+    t = time.time()
+    for i in range(n):
+        L = model.forward_losses(imgs, gts, seed=10 + i, backward=True)
+        model.sgd_step(0.001)
+    ctx.sync()
+    dts.append((time.time() - t) / n)
+dt = min(dts)
 print(json.dumps({"train_step_ms": dt * 1e3, "images_per_s": B / dt, "B": B, "losses": L}))
