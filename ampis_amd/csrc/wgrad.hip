@@ -435,6 +435,20 @@ __device__ __forceinline__ f16x8 tr_pair_p(const unsigned char* p) {        // t
     return __builtin_bit_cast(f16x8, v);
 }
 
+// The fragment reads as inline asm: behind the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of every step's reads (an LDS read
+// "may alias" the LDS-DMA still in flight -- it does not for the plain ds_read_b128 of conv_split_kernel), which drains the youngest tile's
+// requests and turns the ring's prefetch distance of two tiles into one.  The asm is opaque to that pass, so the data's arrival is
+// waited for by hand: tr_wait() -- `s_waitcnt lgkmcnt(0)` that names every fragment register as in/out, so no MFMA can be scheduled above it.
+template <int SECOND>
+__device__ __forceinline__ f16x8 tr_pair_asm(unsigned int addr) {
+    s16x4 a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(SECOND) : "memory");
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(f16x8, v);
+}
+
 __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, const float out_scale, int* range_flag) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * WS_TILE];
     const int tid = threadIdx.x;
@@ -486,13 +500,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
     ctab_t tab0 = (ctab_t)(a.rowtab + (size_t)min(tap0, ntaps - 1) * a.Mpad + m_begin + 4 * wave);
     ctab_t tab1 = (ctab_t)(a.rowtab + (size_t)min(tap0 + 1, ntaps - 1) * a.Mpad + m_begin + 4 * wave);
     const bool tap0_ok = kp0 < a.Kp, tap1_ok = two && tap0 + 1 < ntaps;
-    unsigned int qt0[4], qt1[4];
+    // Two sets: a step's stage() consumes `qt`, the scalar loads of the NEXT stage's rows go into `qn` and are issued at the START of a step, in
+    // front of the fragment reads -- lgkmcnt counts scalar loads and LDS reads alike and scalar loads return out of order, so every wait for
+    // the fragments is lgkmcnt(0): issued behind the staging (as they were until the end of round 3) their latency sat between the early
+    // half's barrier and its first MFMA in every K-step (SQ_WAIT_ANY 2.8 x conv_split_kernel's per flop, tools/pmc_wgrad_vs_conv.sh).
+    unsigned int qt0[4], qt1[4], qn0[4], qn1[4];
+    // (one 16-B scalar load per tap: the index is a multiple of 4 -- Mpad, m_begin and BKW are multiples of 32 -- and both pointers stay inside
+    //  the table whatever the tile, so the loads are unconditional and the OOB marker is a select: no branch per entry)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u32x4* ctab4_t;
     auto load_tab = [&](int st) {
+        const u32x4 t0 = *(ctab4_t)(tab0 + st * BKW);
+        const u32x4 t1 = *(ctab4_t)(tab1 + st * BKW);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            qt0[i] = tap0_ok ? tab0[st * BKW + i] : OOB;
-            qt1[i] = tap1_ok ? tab1[st * BKW + i] : OOB;
-        }
+        for (int i = 0; i < 4; ++i) { qn0[i] = t0[i]; qn1[i] = t1[i]; }      // raw: the first USE of a loaded value is where the wave waits for it
+    };
+    auto take_tab = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { qt0[i] = tap0_ok ? qn0[i] : OOB; qt1[i] = tap1_ok ? qn1[i] : OOB; }
     };
 
     int staged = 0;                                                  // next K-step to stage
@@ -510,7 +535,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
                                                      (int)(row + q_lane[i]), 0, 0, 0);      // 0x80000000 + lane part: zero fill
         }
         ++staged;
-        if (staged < nsteps) load_tab(staged);                       // for the next call
     };
 
     // ---- fragment addresses: row R = 8 lq + q (+ 4 for the second read); lane 4 q + p supplies row q, 8-B piece p of the block's 32 B ----
@@ -537,17 +561,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
             for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
     f16x8 xh[4], xl[4], yh[4], yl[4];
 
+    const unsigned int lds_base = (unsigned int)(size_t)lds;          // LDS byte address of the ring (low half of the generic address)
     auto load = [&](int buf) {
-        const unsigned char* T = lds + buf * WS_TILE;
+        const unsigned int T = lds_base + (unsigned int)(buf * WS_TILE);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            xh[b] = tr_pair(T + offQ[b][0]);
-            xl[b] = tr_pair(T + offQ[b][1]);
-            yh[b] = tr_pair_p(T + offP[b][0]);
-            yl[b] = tr_pair_p(T + offP[b][1]);
+            xh[b] = tr_pair_asm<4 * 1024>(T + (unsigned int)offQ[b][0]);
+            xl[b] = tr_pair_asm<4 * 1024>(T + (unsigned int)offQ[b][1]);
+            yh[b] = tr_pair_asm<4 * 512>(T + (unsigned int)offP[b][0]);
+            yl[b] = tr_pair_asm<4 * 512>(T + (unsigned int)offP[b][1]);
         }
     };
+    auto tr_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]),
+                       "+v"(yh[0]), "+v"(yh[1]), "+v"(yh[2]), "+v"(yh[3]), "+v"(yl[0]), "+v"(yl[1]), "+v"(yl[2]), "+v"(yl[3])
+                     :: "memory");
+    };
     auto mfma = [&]() {
+        tr_wait();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -560,9 +592,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
     };
 
     if (nsteps > 0) {
-        load_tab(0);
+        load_tab(0); take_tab();
         stage(0);
-        if (nsteps > 1) stage(1);
+        if (nsteps > 1) { load_tab(1); take_tab(); stage(1); }
+        if (nsteps > 2) { load_tab(2); take_tab(); }                 // qt: the rows of K-step 2, staged in step 0
         int cur = 0, nxt = 2;
         auto open_step = [&](int step) {
             if (step + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0070 | 6);     // all but the youngest tile's 6 requests; lgkmcnt(0)
@@ -575,6 +608,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
         if (wave < 4) {
             for (int step = 0; step < nsteps; ++step) {
                 open_step(step);
+                if (step + 3 < nsteps) load_tab(step + 3);           // scalar loads first: their latency passes under the fragment reads
+                __builtin_amdgcn_sched_barrier(0);
                 load(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if (step + 2 < nsteps) stage(nxt);
@@ -584,6 +619,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
                 mfma();
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (step + 3 < nsteps) take_tab();
                 advance();
             }
         } else {
@@ -594,10 +630,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_kernel(const WgradArgs a, 
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                if (step + 3 < nsteps) load_tab(step + 3);
+                __builtin_amdgcn_sched_barrier(0);
                 load(cur);
                 __builtin_amdgcn_sched_barrier(0);
                 if (step + 2 < nsteps) stage(nxt);
                 __builtin_amdgcn_sched_barrier(0);
+                if (step + 3 < nsteps) take_tab();
                 advance();
             }
             mfma();
