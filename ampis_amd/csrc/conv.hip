@@ -2030,6 +2030,12 @@ static void launch_split_short(const ConvArgs& a, int epi, hipStream_t st, unsig
     else AMP_TIMED_LAUNCH((conv_split_kernel<128, 128, 1, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
 }
 
+// Cout = 64 (res2's 3x3 and 1x1 layers): 256 x 64 tiles, four waves of 64 x 64 (one wave spans all 64 output channels: 2/3 of the LDS bytes per
+// MFMA of the 128 x 64 tiles' 64 x 32 wave tiles), two buffers, two workgroups per CU
+static void launch_split_tall64(const ConvArgs& a, hipStream_t st, unsigned int xb, unsigned int wb) {
+    AMP_TIMED_LAUNCH((conv_split_kernel<256, 64, 1, 2>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
+}
+
 void launch_f16x3_stem(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     if (epi == 1) AMP_TIMED_LAUNCH((conv_f16x3_kernel<64, 1, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
     else AMP_TIMED_LAUNCH((conv_f16x3_kernel<64, 0, true>), dim3(a.nblk), dim3(256), 0, st, a, xb, wb);
@@ -2070,6 +2076,8 @@ extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
 static int g_short_k_steps = getenv("AMP_SHORT_K_STEPS") ? atoi(getenv("AMP_SHORT_K_STEPS")) : 16;     // K <= 512 (2: K <= 64 only)
 static int g_short_k = getenv("AMP_NO_SHORT_K") ? 0 : 1;      // EXPERIMENT switch: K <= 64 layers on 128 x 128 tiles, two workgroups per CU (0: the 128 x 256 ring tiles)
 extern "C" void amp_debug_set_short_k(int v) { g_short_k = v; }
+static int g_tall64 = getenv("AMP_TALL64") ? atoi(getenv("AMP_TALL64")) : 1;      // Cout = 64 layers on 256 x 64 tiles of conv_split_kernel, two workgroups per CU (0: the 128 x 64 ring tiles of conv_glds_kernel): res2 3x3 160 -> 145 us, 1x1 256 -> 64 148 -> 140 us, bit-identical
+extern "C" void amp_debug_set_tall64(int v) { g_tall64 = v; }
 static int g_split_ring = getenv("AMP_SPLIT_RING") ? atoi(getenv("AMP_SPLIT_RING")) : 1;    // EXPERIMENT switch: the 3-buffer conv_split_kernel for pre-split inputs (0: the 2-buffer conv_glds_kernel<.., F16>)
 extern "C" void amp_debug_set_split_ring(int v) { g_split_ring = v; }
 #ifdef AMP_STAMP
@@ -2690,6 +2698,10 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         } else if (x_is_split && g_split_ring && epi != 0 && !a.grouped && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {
             a.ntn = a.Cout / 128; a.nblk = ntm256 * a.ntn;                  // Cout = 128 (or 384, ...): 256 x 128 tiles
             launch_split<256, 128>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (x_is_split && g_split_ring && g_tall64 && epi == 1 && !a.grouped && a.Cout == 64 && in_shift == 0 && amp::cdiv(a.M, 256) >= 1024) {
+            a.ntn = 1; a.nblk = amp::cdiv(a.M, 256);
+            a.stagger = 0;
+            launch_split_tall64(a, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split) {      // both operands by LDS-DMA
             if (wide256) {
                 a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;

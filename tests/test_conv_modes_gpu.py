@@ -597,3 +597,32 @@ def test_short_k_two_workgroup_tiles_are_bit_identical(gpu_ctx, shape):
     finally:
         lib().amp_debug_set_short_k(1)
     assert float(ops.unsplit_rows(gpu_ctx, ref).abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5, 240, 251, 64, 3, True, False), (5, 240, 251, 256, 1, True, True), (6, 219, 230, 64, 1, False, False), (4, 256, 256, 64, 3, True, True)])
+def test_tall_64_wide_tiles_are_bit_identical(gpu_ctx, shape):
+    """Cout = 64 layers on pre-split input (res2's 3x3 and 1x1 convolutions) run on 256 x 64 tiles of `conv_split_kernel` (four waves of 64 x 64,
+    two buffers, two workgroups per CU) instead of the 128 x 64 ring tiles of `conv_glds_kernel`: the same products in the same order through the
+    same epilogue -- bit for bit, with split and fp32 output, on pixel counts that are not multiples of 256; launches reproduce."""
+    from ampis_amd import ops
+    from ampis_amd._lib import lib
+    B, H, W, Cin, k, relu, y_split = shape
+    g = torch.Generator().manual_seed(B * H + W + Cin + k)
+    x = ops.split_rows(gpu_ctx, torch.randn(B, H, W, Cin, generator=g).cuda())
+    w = (torch.randn(64, k, k, Cin, generator=g) * 0.1).cuda()
+    sc = (torch.rand(64, generator=g) + 0.5).cuda()
+    sh = torch.randn(64, generator=g).cuda()
+    kw = dict(stride=1, pad=k // 2, relu=relu, fmt=ops.FMT_X_SPLIT | (ops.FMT_Y_SPLIT if y_split else 0))
+    assert (B * H * W + 255) // 256 >= 1024          # the dispatch takes the tall tiles from 1024 of them
+    try:
+        lib().amp_debug_set_tall64(0)
+        ref = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw).clone()
+        lib().amp_debug_set_tall64(1)
+        for _ in range(5):
+            y = ops.conv2d_nhwc(gpu_ctx, x, w, sc, sh, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int32), ref.view(torch.int32))
+    finally:
+        lib().amp_debug_set_tall64(1)
+    assert float((ops.unsplit_rows(gpu_ctx, ref) if y_split else ref).abs().max()) > 0
