@@ -189,6 +189,11 @@ WGRAD_SPLIT_CASES = [
     (2, 32, 32, 128, 128, 3, 1, 1, 1e-4),        # Cin = 128: a K' tile straddles two taps, nine taps = 4.5 tiles
     (2, 32, 32, 256, 512, 1, 2, 0, 1e-5),        # stride 2 (the first conv of a stage)
     (1, 1, 300, 1024, 128, 1, 1, 0, 1e-3),       # fc-like
+    (1, 1, 32, 256, 128, 1, 1, 0, 1e-3),         # one K-step: the table / staging prologue without a loop body
+    (1, 1, 64, 256, 128, 1, 1, 0, 1e-3),         # two K-steps
+    (1, 1, 96, 256, 128, 1, 1, 0, 1e-3),         # three: the first step that loads a table row set inside the loop's guard
+    (1, 1, 130, 256, 256, 1, 1, 0, 1e-3),        # five, the last one ragged
+    (1, 6, 7, 256, 128, 3, 1, 1, 1e-3),          # 42 pixels, nine taps: two K-steps per tap tile with out-of-image rows
 ]
 
 
