@@ -1206,15 +1206,36 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             if (!wsp) AMP_TRY(amp_dgrad_weights(ctx, cd.w, nullptr, 1024, 1, 1, 256, wt_scratch));
             amp_conv_desc g;
             g.B = N; g.H = 28; g.W = 28; g.Cin = 256; g.Cout = 256; g.KH = 2; g.KW = 2; g.stride = 2; g.pad = 0; g.relu = 0; g.res_mode = 0; g.out_mode = 0;
-            AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16, MT ? (1 | 8) : 0));
+            // MT: the data gradient leaves the mask head's chain in the scaled split domain (the 2^16 rides on): fcn4..fcn1 below take d * 2^16 as
+            // split rows straight from the producing convolution's epilogue -- no fp32 tensor, no conversion pass
+            if (MT) AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 0, 1 | 2 | 8));
+            else AMP_TRY(amp::conv_run(ctx, &g, 1, d_mtb, wsp ? cd.w : wt_scratch, wsp, 0, nullptr, nullptr, nullptr, macts[4], d_ma, 16, 0));
         }
         float* dcur = d_ma;
         float* dnext = d_mb;
         for (int i = 4; i >= 1; --i) {
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
             const ConvW& cf = CONV(key.c_str());
-            AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, true, m->mask_acts_split));
-            AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext, m->mask_acts_split));
+            if (MT) {
+                // bias gradient: column sums of the split rows (read-only: half the bytes of the converting pass); weight gradient on both split
+                // operands; data gradient split -> split with fcn(i-1)'s split rows as the ReLU mask, the last one (no mask) back to fp32 for RoIAlign
+                AMP_TRY(amp_colsum_of_split(ctx, dcur, N * 196, 256, cs_scratch, GB(cf), 0, 16));
+                AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, false, 3));
+                if (i > 1) {
+                    AMP_TRY(dgrad_s(cf, dcur, N, 14, 14, 1, nullptr, macts[i - 1], dnext));
+                } else {
+                    AMP_REQUIRE((size_t)cf.cout * cf.kh * cf.kw * cf.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
+                    const float* wsp1 = dgrad_wsplit(cf, N, 14, 14);
+                    if (!wsp1) AMP_TRY(amp_dgrad_weights(ctx, cf.w, cf.scale, cf.cout, cf.kh, cf.kw, cf.cin, wt_scratch));
+                    amp_conv_desc d1;
+                    d1.B = N; d1.H = 14; d1.W = 14; d1.Cin = cf.cout; d1.Cout = cf.cin; d1.KH = cf.kh; d1.KW = cf.kw; d1.stride = 1; d1.pad = cf.kh - 1 - 1;
+                    d1.relu = 0; d1.res_mode = 0; d1.out_mode = 0;
+                    AMP_TRY(amp::conv_run(ctx, &d1, 1, dcur, wsp1 ? cf.w : wt_scratch, wsp1, 0, nullptr, nullptr, nullptr, nullptr, dnext, 16, 1));
+                }
+            } else {
+                AMP_TRY(wgrad(cf, macts[i - 1], N, 14, 14, 1, 1, dcur, false, true, m->mask_acts_split));
+                AMP_TRY(dgrad(cf, dcur, N, 14, 14, 1, nullptr, i > 1 ? macts[i - 1] : nullptr, dnext, m->mask_acts_split));
+            }
             std::swap(dcur, dnext);
         }
         AMP_TRY(amp::roi_align_bwd_run(ctx, d_feat, T.fh, T.fw, fstr, 256, m_rois, m_batch, N, 14, dcur, B, dfeat_init));

@@ -818,6 +818,40 @@ __global__ __launch_bounds__(256) void colsum_split_kernel(const float* __restri
     }
 }
 
+// Column sums of a tensor that is ALREADY split rows of dy * 2^shift (a data-gradient convolution wrote it that way): read-only, half the
+// bytes of colsum_split_kernel's pass; partial sums of the decoded values (hi + lo' * 2^-11) * inv_scale, same tree as above.
+__global__ __launch_bounds__(256) void colsum_of_split_kernel(const float* __restrict__ dy_split, int M, int N, float* __restrict__ partial, float inv_scale) {
+    __shared__ float red[8][32][8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * COLSUM_ROWS, r1 = min(M, r0 + COLSUM_ROWS);
+    for (int cbase = 0; cbase < N; cbase += 256) {
+        const int ch = cbase + 8 * cg;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (ch < N) {
+            const size_t col_b = (size_t)(ch >> 5) * 128 + (size_t)(ch & 31) * 2;
+#pragma unroll 4
+            for (int r = r0 + rl; r < r1; r += 8) {
+                const char* ib = reinterpret_cast<const char*>(dy_split + (size_t)r * N) + col_b;
+                const cs_h8 hi = *reinterpret_cast<const cs_h8*>(ib), lo = *reinterpret_cast<const cs_h8*>(ib + 64);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(__fadd_rn((float)hi[q], __fmul_rn((float)lo[q], 1.0f / LO_SCALE)), inv_scale));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[rl][cg][q] = acc[q];
+        __syncthreads();
+        if (rl == 0 && ch < N) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float t = red[0][cg][q];
+                for (int k = 1; k < 8; ++k) t = __fadd_rn(t, red[k][cg][q]);
+                partial[(size_t)blockIdx.x * N + ch + q] = t;
+            }
+        }
+    }
+}
+
 // Pass 2: 32 columns x 8 part-lanes per workgroup; part-lane l adds parts l, l+8, ... in order (4 independent loads in flight),
 // the 8 lanes are combined in lane order: a fixed summation tree -> run-to-run reproducible.
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
@@ -1067,6 +1101,16 @@ int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch
     AMP_REQUIRE(ctx && dy && scratch && out && dy_split && M >= 0 && N > 0 && N % 32 == 0 && shift >= 0 && shift <= 24, "amp_colsum_split: bad argument (N %% 32 != 0?)");
     const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
     hipLaunchKernelGGL(colsum_split_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy, M, N, scratch, dy_split, ldexpf(1.0f, shift));
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, scratch, parts, N, out, accumulate);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+/* out[n] (= or +=) sum_m dy[m][n] for dy given as split rows of dy * 2^shift (N % 32 == 0); scratch: >= ceil(M/512)*N floats */
+int amp_colsum_of_split(amp_ctx* ctx, const float* dy_split, int M, int N, float* scratch, float* out, int accumulate, int shift) {
+    AMP_REQUIRE(ctx && dy_split && scratch && out && M >= 0 && N > 0 && N % 32 == 0 && shift >= 0 && shift <= 24, "amp_colsum_of_split: bad argument (N %% 32 != 0?)");
+    const int parts = std::max(1, amp::cdiv(M, COLSUM_ROWS));
+    hipLaunchKernelGGL(colsum_of_split_kernel, dim3(parts), dim3(256), 0, ctx->stream, dy_split, M, N, scratch, ldexpf(1.0f, -shift));
     hipLaunchKernelGGL(colsum_final_kernel, dim3(amp::cdiv(N, 32)), dim3(256), 0, ctx->stream, scratch, parts, N, out, accumulate);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;

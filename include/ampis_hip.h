@@ -177,6 +177,8 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
 int amp_colsum(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate);
 /* the same pass also writing dy * 2^shift in the split row format (N % 32 == 0): the dy operand of amp_conv2d_wgrad_fmt(x_split & 2) */
 int amp_colsum_split(amp_ctx* ctx, const float* dy, int M, int N, float* scratch, float* out, int accumulate, float* dy_split, int shift);
+/* the column sums alone of a dy that is already split rows of dy * 2^shift (read-only; the values summed are the 22-bit ones the split holds) */
+int amp_colsum_of_split(amp_ctx* ctx, const float* dy_split, int M, int N, float* scratch, float* out, int accumulate, int shift);
 /* wt[Cin][KH][KW][Cout] = flipped / transposed / scaled copy of w[Cout][KH][KW][Cin]: conv(dy, wt) is the data gradient */
 int amp_dgrad_weights(amp_ctx* ctx, const float* w, const float* scale, int Cout, int KH, int KW, int Cin, float* wt);
 /* the same tensor already in the AMP_CONV_F16X3 split row format (= amp_split_weights of amp_dgrad_weights' result, bit for bit, in one
