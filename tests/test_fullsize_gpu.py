@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-FULLSIZE_TIE_SHARE_CAP, FULLSIZE_TIE_PIXELS_CAP, FULLSIZE_BOX_REL_CAP, FULLSIZE_IOU_MIN = 0.40, 20, 6, 0.99      # a little above the measured level (see the test)
+# What the end-to-end gate may relax is bound to the reference arithmetic's own noise floor (tests/golden/oracle_noise_floor.json: the
+# fp32 oracle against its exact-convolution evaluation on the eight images of this very batch, tools/oracle_noise_floor.py), not to hand-set caps.
 
 
 # BASELINE configs[1] (R50-FPN, 1024^2, 200 detections) and configs[4] (X-101-32x8d-FPN, native 2048^2, dense: 500 detections)
@@ -112,32 +113,37 @@ def test_fullsize_batch_against_the_oracle(gpu_ctx, mode):
     finally:
         gpu_ctx.conv_mode = keep_mode
     tp = O.to_torch_params(p)
-    stats = []
+    from oracle import exact
+    floor = gate.load_floor("fullsize_1024")
+    # the relative box term of rule 2 is the floor's too: the fp32 oracle itself sits up to 4.2 ppm of the side from the exact evaluation
+    # on boxes above 333 px (one of its own boxes, 240 x 360 px on image 10, is 1.5e-3 px off -- it would FAIL the bare 1e-3 px against itself)
+    box_rel = gate.FLOOR_FACTOR * floor["worst_box_rel"]
+    decode = lambda mk: _decode(mk["counts"], S, S)
+    stats, stats_ex, floor_here = [], [], []
     for b in (0, 5):
-        ref = O.infer(imgs[b:b + 1], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]
+        cfg = O.Cfg(num_classes=K, detections_per_image=D)
+        ref = O.infer(imgs[b:b + 1], tp, cfg)[0]
         assert len(ref["boxes"]) == D
-        # fp32 MFMA sums two products per instruction, the split arithmetic 16: its re-association noise is the LARGER one (DESIGN §4.1,
-        # tests/test_conv_modes_gpu.py), measured 3.3 ppm of a 393-px side against 1.9 ppm -> its relative term is 4e-6, not 3e-6
-        stats.append(gate.check_image(out[b], ref, S, S, lambda mk: _decode(mk["counts"], S, S), box_rel=4e-6 if mode == "f32" else gate.BOX_REL))
-    st = gate.merge(stats)
+        stats.append(gate.check_image(out[b], ref, S, S, decode, box_rel=box_rel))
+        # the same two images against the EXACT-convolution oracle, in the gate's measuring mode: the HIP path on one side, the fp32 oracle
+        # on the other -- each then carries ONE arithmetic's noise, so the two columns compare like with like (no sqrt(2))
+        with exact.exact_convs():
+            rex = O.infer(imgs[b:b + 1], tp, cfg)[0]
+        stats_ex.append(gate.check_image(out[b], rex, S, S, decode, box_rel=box_rel, strict=False))
+        as_hip = dict(boxes=ref["boxes"].numpy(), scores=ref["scores"].numpy(), classes=ref["classes"].numpy(), masks=list(ref["masks"].numpy()))
+        floor_here.append(gate.check_image(as_hip, rex, S, S, lambda m: m, box_rel=box_rel, strict=False))
+    st, st_ex, fl_here = gate.merge(stats), gate.merge(stats_ex), gate.merge(floor_here)
     print(f"full-size gate [{mode}]:", gate.summary(st))
     assert st["instances"] == 2 * D and st["identical"] + st["tie_masks"] == st["instances"]
-    # caps a little above the measured level (round 3: f16x3 115 of 400 masks with ties, at most 8 pixels in one, 6 masks below IoU 0.999
-    # -- the largest 1158 px, lowest IoU 0.9969 -- and 2 boxes of ~740 px inside the relative term; f32 124 / 12 / 6 / 0.9974 / 5):
-    # a regression shows here even while the per-instance rule holds
-    gate.assert_bounds(st, tie_mask_share=FULLSIZE_TIE_SHARE_CAP, max_tie_pixels=FULLSIZE_TIE_PIXELS_CAP, iou_min=FULLSIZE_IOU_MIN, box_rel_used=FULLSIZE_BOX_REL_CAP)
-    if mode == "f32":
-        return
-    # where 1e-3 px is below the reference's own fp32 noise (boxes of several hundred px): against an exact-convolution evaluation
-    # of the same network (oracle/exact.py) the HIP path must be as close as the fp32 oracle is
-    from oracle import exact
-    with exact.exact_convs():
-        rex = O.infer(imgs[5:6], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]["boxes"].numpy()
-    r32 = O.infer(imgs[5:6], tp, O.Cfg(num_classes=K, detections_per_image=D))[0]["boxes"].numpy()
-    dist = lambda a: max(float(np.abs(a - rex[i]).max(axis=1).min()) for i in range(len(rex)))
-    d_hip, d_ref = dist(out[5]["boxes"]), dist(r32)
-    print(f"worst box distance from the exact-convolution oracle: HIP {d_hip:.2e} px, fp32 oracle {d_ref:.2e} px")
-    assert d_hip <= max(1e-3, 1.5 * d_ref), (d_hip, d_ref)
+    # (1) HIP vs the fp32 oracle, capped at FLOOR_FACTOR x the committed floor (a rate over the batch's eight images)
+    print(f"  [{mode}] HIP vs fp32 oracle |", gate.assert_floor(st, floor))
+    # (2) HIP vs the exact oracle against fp32 oracle vs the exact oracle ON THESE TWO IMAGES, recomputed here: the HIP arithmetic may not be
+    #     noisier than the reference's own (boxes, tie masks, tie pixels beyond the noise margin, masks below IoU 0.999)
+    print(f"  [{mode}] fp32 oracle vs exact oracle (these two images):", gate.summary(fl_here))
+    print(f"  [{mode}] HIP vs exact oracle |", gate.assert_floor(st_ex, fl_here))
+    assert st_ex["violations"] <= fl_here["violations"] + 1 and st_ex["count_diff"] == 0, (st_ex, fl_here)
+    # the committed floor is reproduced by this host's torch (another CPU / thread count re-associates differently: same level, not same bits)
+    assert abs(fl_here["tie_masks"] - 114) <= 40 and fl_here["iou_below"] <= 20, gate.summary(fl_here)
 
 
 def test_inference_repeats_bit_for_bit():
