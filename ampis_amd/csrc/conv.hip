@@ -65,6 +65,8 @@ struct ConvArgs {
     int* range_flag;        // f16x3 kernels: set to 1 when an accumulator is not finite (operand beyond fp16 range)
     int cin_win, grouped;   // K runs over KH*KW*cin_win input channels; grouped: the window of N-tile n0 starts at channel n0
     int nblk;
+    int korder;             // conv_split_kernel: 0 = K runs tap-major (ky, kx, then the 32-channel slices), 1 = channel-major (slice, then the KH*KW taps:
+                            // the nine taps of a slice re-read the same cache lines within nine K-steps, while they are still in the XCD's L2)
     unsigned int div_howo_mul, div_wo_mul;   // x / d == (x * mul) >> shr for every x < 2^29 (Granlund-Montgomery, mul = ceil(2^shr / d))
     int div_howo_shr, div_wo_shr;
 };
@@ -1257,7 +1259,7 @@ __device__ unsigned long long g_stamp[8 * 8];
 #define STAMP_T(var)
 #define STAMP_ADD(slot, t0, t1)
 #endif
-template <int BM, int BN, int EPI, int NSTAGE = 3>
+template <int BM, int BN, int EPI, int NSTAGE = 3, bool CHAN = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) void conv_split_kernel(const ConvArgs a, const unsigned int x_bytes,
                                                                                                      const unsigned int w_bytes) {
     constexpr int WTM = 64, WTN = 64;
@@ -1326,8 +1328,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
     const int csteps = a.Cin / BK;
     int ky = 0, kx = 0, cs = 0, kstep = 0;     // block-uniform state of the tile being STAGED
 
+    constexpr bool chan_major = CHAN;      // compile-time: a run-time flag here cost 12 B of scratch and a vmcnt(0) per step (250 VGPRs, 96 SGPRs in use)
     auto stage = [&](int buf) {
-        if (cs == 0) {
+        if (cs == 0 || chan_major) {           // the tap changed: new pixel offsets (channel-major: every step)
 #pragma unroll
             for (int g = 0; g < GA; ++g) {
                 const int iy = a_iy0[g] + ky, ix = a_ix0[g] + kx;
@@ -1338,7 +1341,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
         float* As = lds + buf * TILE_FLOATS;
         float* Bs = As + BM * BK;
         const int a_soff = cs * (BK * 4);
-        const int b_soff = kstep * (BK * 4);
+        int b_soff;
+        if constexpr (chan_major) b_soff = ((ky * a.KW + kx) * csteps + cs) * (BK * 4);
+        else b_soff = kstep * (BK * 4);
 #pragma unroll
         for (int g = 0; g < GA; ++g)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK),
@@ -1347,10 +1352,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
         for (int g = 0; g < GB; ++g)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK),
                                                      16, (int)b_voff[g], b_soff, 0, 0);
-        ++kstep;
-        if (++cs == csteps) {
-            cs = 0;
-            if (++kx == a.KW) { kx = 0; ++ky; }
+        if constexpr (chan_major) {
+            if (++kx == a.KW) {
+                kx = 0;
+                if (++ky == a.KH) { ky = 0; ++cs; }
+            }
+        } else {
+            ++kstep;
+            if (++cs == csteps) {
+                cs = 0;
+                if (++kx == a.KW) { kx = 0; ++ky; }
+            }
         }
     };
 
@@ -2019,6 +2031,12 @@ template <int BM, int BN>
 void launch_split(const ConvArgs& a, int epi, hipStream_t st, unsigned int xb, unsigned int wb) {
     constexpr int NT_ = (BM / 64) * (BN / 64) * 64;
     if constexpr (BM == 128 && BN == 256) {
+        if (a.korder) {      // EXPERIMENT (AMP_KORDER=1): channel-major K order
+            if (epi == 3) AMP_TIMED_LAUNCH((conv_split_kernel<128, 256, 3, 3, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+            else if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<128, 256, 2, 3, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+            else AMP_TIMED_LAUNCH((conv_split_kernel<128, 256, 1, 3, true>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
+            return;
+        }
         if (epi == 3) { AMP_TIMED_LAUNCH((conv_split_kernel<128, 256, 3>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb); return; }
     }
     if (epi == 2) AMP_TIMED_LAUNCH((conv_split_kernel<BM, BN, 2>), dim3(a.nblk), dim3(NT_), 0, st, a, xb, wb);
@@ -2089,6 +2107,8 @@ extern "C" int amp_debug_read_stamps(unsigned long long* out) {     // 64 values
 #endif
 static int g_direct_epi = getenv("AMP_DIRECT_EPI") ? atoi(getenv("AMP_DIRECT_EPI")) : 1;
 extern "C" void amp_debug_set_direct_epi(int v) { g_direct_epi = v; }
+static int g_korder = getenv("AMP_KORDER") ? atoi(getenv("AMP_KORDER")) : 0;     // EXPERIMENT switch: 1 = channel-major K order in conv_split_kernel (ConvArgs::korder)
+extern "C" void amp_debug_set_korder(int v) { g_korder = v; }
 static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
 extern "C" void amp_debug_set_stagger(int v) { g_stagger = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
@@ -2622,6 +2642,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     a.res_split = (fmt & 4) ? 1 : 0;
     a.mask_split = (fmt & 8) ? 1 : 0;
     a.stagger = g_stagger;
+    a.korder = (g_korder && a.KH * a.KW > 1) ? 1 : 0;
     a.direct_epi = g_direct_epi;
     a.pred_w = a.pred_b = nullptr; a.pred_cls = nullptr; a.pred_K = 0; a.prob = nullptr;
     if (fuse) {     // the mask head's deconv with ReLU + predictor + sigmoid in its epilogue (conv_epilogue_predict)

@@ -1,23 +1,15 @@
-"""ISA summary of one kernel family in a hipcc -S listing: registers, LDS, scratch, MFMA / LDS-DMA / barrier / waitcnt counts.
-usage: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S file.hip -o /tmp/x.s
-       python tools/isa_stats.py /tmp/x.s conv_split_kernel"""
-import re
-import sys
-
+"""VGPR / SGPR / scratch and instruction mix of the kernels in a `hipcc -S --cuda-device-only` listing whose mangled name contains a substring.
+python tools/isa_stats.py /tmp/conv.s conv_split_kernel      -- a kernel at 250 VGPRs spills on the smallest change: check before every GPU run."""
+import re, sys
+from collections import Counter
 s = open(sys.argv[1]).read()
-pat = sys.argv[2]
-for m in re.finditer(r'^(_Z\S*' + re.escape(pat) + r'\S*):', s, flags=re.M):
-    name = m.group(1)
-    end = s.find('s_endpgm', m.end())
-    code = s[m.end():end]
-    k = s.find('.amdhsa_kernel ' + name)
-    meta = s[k:s.find('.end_amdhsa_kernel', k)]
-    g = lambda key: (re.search(re.escape(key) + r'\s+(\S+)', meta) or [None, None])[1]
-    dem = re.search(r'; -- Begin function (\S+)', s[max(0, m.start() - 400):m.start()])
-    n_dma = len(re.findall(r'buffer_load_dwordx4[^\n]*lds', code))
-    n_vm0 = len(re.findall(r'vmcnt\(0\)', code))
-    print(name[:100])
-    print(f"   vgpr {g('.amdhsa_next_free_vgpr')} accum_offset {g('.amdhsa_accum_offset')} sgpr {g('.amdhsa_next_free_sgpr')} lds {g('.amdhsa_group_segment_fixed_size')} "
-          f"scratch {g('.amdhsa_private_segment_fixed_size')} | mfma {code.count('v_mfma')} lds-dma {n_dma} "
-          f"ds_read {code.count('ds_read')} barrier {code.count('s_barrier')} waitcnt {len(re.findall(r's_waitcnt', code))} "
-          f"vmcnt(0) {n_vm0} scratch-ops {code.count('scratch_')}")
+for m in re.finditer(r"^(\w+):\s*; @\1\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel", s, re.S | re.M):
+    name, body, meta = m.group(1), m.group(2), m.group(3)
+    if len(sys.argv) > 2 and sys.argv[2] not in name:
+        continue
+    ins = [l.split()[0] for l in body.split("\n") if l.startswith("\t") and l.strip() and not l.strip().startswith((".", ";"))]
+    c = Counter(ins)
+    g = lambda k: re.search(rf"\.amdhsa_{k} (\d+)", meta).group(1)
+    print(f"{name[:100]:100s} vgpr {g('next_free_vgpr'):>3} sgpr {g('next_free_sgpr'):>3} scratch {g('private_segment_fixed_size'):>4} B | {len(ins)} instr, "
+          f"waitcnt {c['s_waitcnt']} (vmcnt(0): {sum(1 for l in body.split(chr(10)) if 's_waitcnt vmcnt(0)' in l)}), mfma {sum(v for k, v in c.items() if 'mfma' in k)}, "
+          f"scratch ops {sum(v for k, v in c.items() if 'scratch' in k)}")
