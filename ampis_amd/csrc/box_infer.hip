@@ -21,7 +21,7 @@ struct CandArgs {
     int* overflow;            // set to 1 when an image has more than ccap candidates
 };
 
-__global__ AMP_NO_PK void box_candidates_kernel(const CandArgs a) {
+__global__ void box_candidates_kernel(const CandArgs a) {
     const int total = a.B * a.Rcap;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int b = t / a.Rcap, r = t - b * a.Rcap;

@@ -92,14 +92,15 @@ struct ProfLaunchScope {          // attaches a profile record's events to the t
 // kernel and is CALLED instead of inlined
 #define AMP_SYNCTHREADS() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); \
                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-// AMP_NO_PK: compile a kernel without packed-FP32 instructions (v_pk_mul / add / fma_f32).
-// Found in round 3 (tools/_probe_conc.py): with SEVERAL contexts running kernels on the card at once, box_candidates_kernel
-// occasionally wrote a box whose x1 (or y1) was the box CENTRE -- for 16 consecutive lanes, i.e. exp(dw) * w had come out as 0 there.  The
-// compiler keeps two wait states between a VALU instruction that writes VCC / an SGPR pair (v_cmp) and the VALU instruction that reads it as a
-// mask (v_cndmask: the range checks inside expf), and it had filled them with v_pk_* instructions; without packed instructions, or with
-// explicit s_nops, the same source never fails.  Single-context runs were never affected (every bitwise test of rounds 1-2 holds).
-// (paste_rle_kernel had one such window too: its compare / select became an xor.)
-// tools/scan_vcc_hazard.py finds these windows in a `hipcc -S` listing; tests/test_isa_hazard.py keeps every kernel file free of them.
+// Packed FP32 on this hardware (rounds 3-4; tools/pk_probe/pk_opsel_probe.hip, tools/_probe ISA variants): with kernels of OTHER queues
+// running on the card, v_pk_add / v_pk_mul / v_pk_fma_f32 whose op_sel picks src1's HIGH dword for the LOW result read that operand as 0 in
+// one quarter wave (~1e-4 of the executions; never alone; every other operand form, v_fma_mix_f32 and v_pk_mov_b32: 0 of 1.7e9).  Round 3
+// saw it as box coordinates replaced by the box centre (box_candidates_kernel: the SLP vectoriser's `x2 = cx + 0.5 w` was such an
+// instruction) and blamed VALU-mask wait states; hand-edited ISA refuted that.  The fence is at build level: files of scalar fp32 code are
+// compiled with -fno-slp-vectorize (csrc/Makefile NOSLP), hand-packed code never shuffles src1, and tests/test_isa_hazard.py scans the
+// listing of every file, built with the Makefile's own flags, for the form (tools/scan_pk_opsel.py).
+// AMP_NO_PK (a kernel without any packed-FP32 instruction) was round 3's fix; it made the HIP headers' inline functions CALLS inside the
+// kernel (other target features) and is no longer used.  Kept for experiments.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define AMP_NO_PK __attribute__((target("no-packed-fp32-ops")))
 #else

@@ -2294,7 +2294,7 @@ struct StemU8Args {
     const int* img_hw;        // optional device [B][2]: per-image valid size
     float m0, m1, m2, s0, s1, s2;
 };
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) AMP_NO_PK void stem_pool_u8_kernel(const ConvArgs a, const StemPoolArgs sp, const StemU8Args u,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void stem_pool_u8_kernel(const ConvArgs a, const StemPoolArgs sp, const StemU8Args u,
                                                                                                        const unsigned int w_bytes) {
     constexpr int BM = 256, BN = 64;
     constexpr int WTM = 64, WTN = 32, NWN = 2;      // 8 waves: 4 x 2 wave tiles

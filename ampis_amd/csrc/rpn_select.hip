@@ -144,7 +144,7 @@ struct DecodeArgs {
     int lvl_off[MAX_LEVELS];
 };
 
-__global__ AMP_NO_PK void rpn_decode_kernel(const DecodeArgs a, int B) {
+__global__ void rpn_decode_kernel(const DecodeArgs a, int B) {
     const int per_img = a.nlevels * a.k;
     const int total = B * a.cap;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {

@@ -375,7 +375,7 @@ __global__ void relu_mask_split_kernel(float* __restrict__ g, const float* __res
 // d * scale (scale = 2^16: loss gradients of 1e-9..1e-4 would sit in the f16 subnormals), so that data-gradient convolutions stage it by
 // LDS-DMA like an activation and the weight-gradient kernel passes its halves through.
 // out = split(scale * (act > 0 ? g : 0)): the entry of a stage's chain (g fp32 from the FPN lateral, act = the stage output, split rows)
-__global__ AMP_NO_PK void relu_mask_to_split_kernel(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out, size_t n4, int C4, float scale) {
+__global__ void relu_mask_to_split_kernel(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out, size_t n4, int C4, float scale) {
     const f32x4* gg = reinterpret_cast<const f32x4*>(g);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const size_t row = i / C4;
@@ -456,7 +456,7 @@ __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K
 // same sums in the same order as small_k_dgrad_kernel, so dx is that kernel's value, scaled and split.
 typedef _Float16 sk_h8 __attribute__((ext_vector_type(8)));
 template <bool ACT_SPLIT, int LD4>
-__global__ __launch_bounds__(256) AMP_NO_PK void small_k_dgrad_split_kernel(const float* __restrict__ dl, int K, const float* __restrict__ w, int C,
+__global__ __launch_bounds__(256) void small_k_dgrad_split_kernel(const float* __restrict__ dl, int K, const float* __restrict__ w, int C,
                                                                    const float* __restrict__ act_split, float* __restrict__ dx_split, int npix,
                                                                    float* __restrict__ partial, float scale) {
     __shared__ float red[8][32][8];

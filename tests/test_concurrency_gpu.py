@@ -48,3 +48,103 @@ def test_three_contexts_at_once_reproduce_the_single_context_results():
         m.close(); c.close()
     assert not errors, errors
     assert not bad, f"{len(bad)} of {3 * 25 * 7} concurrent batches differ from the single-context result: {bad[:8]}"
+
+
+def _sig(out):
+    return [(o["boxes"].tobytes(), o["scores"].tobytes(), o["classes"].tobytes(), tuple(mm["counts"] for mm in o["masks"])) for o in out]
+
+
+def test_two_contexts_at_the_bench_size_reproduce_the_single_context_results():
+    """The size at which round 3 SAW the fault (B = 8, 1024 x 1024, 1000 proposals, 200 detections per image): two contexts at once, every
+    batch bit for bit the single-context result.  (Cause, round 4: packed-FP32 instructions selecting src1's high half, tools/pk_probe; the
+    library no longer contains one, tests/test_isa_hazard.py.)"""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    K, B, S, D = 2, 8, 1024, 200
+    params = P.init_params(K, seed=0, style="spread")
+    batches = [synth.batch(B, S, S, first_index=20 * i)[0] for i in range(2)]
+    models = []
+    for _ in range(2):
+        c = _lib.Context(0)
+        m = MaskRCNN(c, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, detections_per_image=D)
+        m.load_params(params)
+        models.append((c, m))
+    want = [_sig(models[0][1].infer(b)) for b in batches]
+    assert all(len(w) == B for w in want)
+    bad, errors = [], []
+
+    def work(t):
+        try:
+            for rep in range(6):
+                for bi, b in enumerate(batches):
+                    if _sig(models[t][1].infer(b)) != want[bi]:
+                        bad.append((t, rep, bi))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for c, m in models:
+        m.close(); c.close()
+    assert not errors, errors
+    assert not bad, f"{len(bad)} of 24 concurrent full-size batches differ from the single-context result: {bad[:8]}"
+
+
+def test_a_training_step_beside_an_inference_context_is_bitwise_what_it_is_alone():
+    """What DefaultTrainer with an evaluation hook, or a serving process beside a fine-tuning one, puts on the card: training steps in one
+    context while another context runs inference.  The step's losses and its whole gradient arena, and the inference results, must be
+    bit for bit what each is alone (a training step is bitwise reproducible, tests/test_backward_gpu.py)."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    K, B, H, W, D = 2, 2, 384, 512, 60
+    npp = P.init_params(K, seed=2, style="spread")
+    ct, ci = _lib.Context(0), _lib.Context(0)
+    imgs, gts = synth.batch(B, H, W, seed=9)
+    gts = [dict(boxes=g["boxes"][:60], classes=g["classes"][:60], polygons=g["polygons"][:60]) for g in gts]
+    mt = MaskRCNN(ct, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=2048, max_poly_doubles=2048 * 64)
+    mt.load_params(npp)
+    mi = MaskRCNN(ci, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D)
+    mi.load_params(npp)
+    ibatches = [synth.batch(B, H, W, first_index=10 * i)[0] for i in range(4)]
+
+    def step():
+        L = mt.forward_losses(imgs, gts, seed=3, backward=True)
+        ptr, n = mt.grad_arena()
+        arena = np.empty(n, dtype=np.float32)
+        ct.sync()
+        ct.d2h(arena, ptr)
+        return L, arena
+
+    L0, g0 = step()
+    want = [_sig(mi.infer(b)) for b in ibatches]
+    stop, bad_i, bad_t, errors = [False], [], [], []
+
+    def infer_loop():
+        try:
+            rep = 0
+            while not stop[0]:
+                for bi, b in enumerate(ibatches):
+                    if _sig(mi.infer(b)) != want[bi]:
+                        bad_i.append((rep, bi))
+                rep += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    th = threading.Thread(target=infer_loop)
+    th.start()
+    try:
+        for rep in range(12):
+            L, g = step()
+            if L != L0 or not np.array_equal(g, g0):
+                bad_t.append((rep, int((g != g0).sum())))
+    finally:
+        stop[0] = True
+        th.join()
+    mt.close(); mi.close(); ct.close(); ci.close()
+    assert not errors, errors
+    assert np.abs(g0).max() > 0
+    assert not bad_t, f"training steps beside an inference context differ from the step alone (step, differing gradient values): {bad_t}"
+    assert not bad_i, f"inference batches beside a training context differ from the single-context result: {bad_i[:8]}"

@@ -1,5 +1,5 @@
 import sys, os, threading
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from ampis_amd import _lib, params as P, synth
 if os.environ.get('AMP_LIB'):
