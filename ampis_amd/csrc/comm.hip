@@ -41,6 +41,7 @@ int load_rccl() {
     if (forced && *forced) {
         h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
         if (!h) { amp::set_error("amp_comm: AMP_RCCL_LIB=%s could not be opened: %s", forced, dlerror()); return AMP_ERR_STATE; }
+        fprintf(stderr, "ampis_hip: AMP_RCCL_LIB=%s overrides librccl for this process (a test hook: the collectives are NOT RCCL's unless this is an RCCL build)\n", forced);
     }
     if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
     if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;

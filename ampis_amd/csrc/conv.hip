@@ -2623,7 +2623,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         if (ctx->prof_used < ctx->prof_pool.size()) {
             rec = &ctx->prof_pool[ctx->prof_used++];
             rec->flops = 2.0 * (double)a.M * (double)a.Cout * (double)d->KH * (double)d->KW * (double)cpg;   // useful work
-            rec->variant = (!a.grouped && a.Cout > 64 && (a.Cin % BK != 0 || ntm * amp::cdiv(a.Cout, 128) >= 512)) ? 0 : 1;
+            rec->variant = 1;      // 0 = a launch of the DOMINANT kernel (set where it is launched: conv_split_kernel<128x256>, fp32 mode conv_glds_kernel<128>)
         } else {
             ctx->prof_truncated = true;
         }
@@ -2700,9 +2700,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
                     "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
+            if (rec) rec->variant = 0;
             launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (a.out_mode == 4) {                                        // fused RPN tail: one N tile
             a.ntn = 1; a.nblk = ntm;
+            if (rec) rec->variant = 0;
             launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && g_short_k && epi != 0 && !a.grouped && a.nsteps <= g_short_k_steps && res && a.res_mode == 1 && a.res_split && a.y_split && !mask &&
                    a.Cout % 128 == 0 && ntm * (a.Cout / 128) >= 1024) {
@@ -2715,6 +2717,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             launch_split_short(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
+            if (rec) rec->variant = 0;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (x_is_split && g_split_ring && epi != 0 && !a.grouped && a.Cout % 128 == 0 && (ntm256 * (a.Cout / 128) >= 512 || (ntm256 * (a.Cout / 128) >= 192 && a.nsteps >= 64))) {
             a.ntn = a.Cout / 128; a.nblk = ntm256 * a.ntn;                  // Cout = 128 (or 384, ...): 256 x 128 tiles
@@ -2767,6 +2770,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         if (!a.grouped && a.Cout > 64 && nblk128 >= 512) {
             a.ntn = amp::cdiv(a.Cout, 128);
             a.nblk = ntm * a.ntn;
+            if (rec) rec->variant = 0;
             launch_glds<128, false>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else {
             a.ntn = amp::cdiv(a.Cout, 64);

@@ -298,6 +298,11 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
     el = ranks.max(el)
     buckets = model.grad_buckets()
     model.close()
+    if world > 1 or has_comm:     # per rank: what its gradient exchange cost (the JSON line carries rank 0's)
+        log(f"rank {rank}: grad exchange over {ctx.comm_info()[1] if has_comm else 0} RCCL ranks (version {ctx.comm_info()[2] if has_comm else None}): "
+            f"exposed_comm_ms {exposed / nstat if nstat else None}, comm_span_ms {span / nstat if nstat else None}, bucket_us "
+            f"{[round(v / nstat, 1) for v in bucket_us] if (nstat and bucket_us) else None} (mask head, box head, RPN, FPN, res5, res4, res3); "
+            f"step {el / steps * 1e3:.2f} ms (max over ranks)")
     f16 = ctx.conv_mode == ctx.CONV_F16X3
     peak = PEAK_F16X3_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
     wg_ms, wg_fl, wg_n = prof["ms"][2], prof["flops"][2], prof["launches"][2]
@@ -483,7 +488,12 @@ def main(args):
     if world > 1 and not staged:
         from ampis_amd.utils import comm
         rccl = comm.attach_rccl(ctx)
-        log(f"rank {rank}: RCCL communicator up (rank {rccl[0]} of {rccl[1]}, version {rccl[2]})")
+        # every rank says what it got, so that the first multi-GPU run explains itself from its log alone
+        log(f"rank {rank}: RCCL communicator up (rank {rccl[0]} of {rccl[1]}, version {rccl[2]}, device {local_rank}"
+            + (f", AMP_RCCL_LIB={os.environ['AMP_RCCL_LIB']} OVERRIDES librccl" if os.environ.get("AMP_RCCL_LIB") else "") + ")")
+        if rccl[1] != world or rccl[0] != rank:
+            log(f"rank {rank}: FATAL: the communicator has {rccl[1]} ranks (this is rank {rccl[0]}) but the job has {world} (this is rank {rank})")
+            sys.exit(4)
     ranks = Ranks(ctx, dev, world, staged)
     model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     params = P.init_params(K, seed=0, style="spread")
@@ -563,7 +573,8 @@ def main(args):
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"
                                       + (f"; barrier / max-over-ranks on RCCL {rccl[2]} through the C ABI" if rccl else "")},
             "roofline": {"bound": "mfma",
-                         "kernel": ("wide f16x3 tiles: conv_split_kernel<128x256 | 256x128> (+ conv_glds_kernel<128,F16>): implicit-GEMM conv on "
+                         "kernel": ("conv_split_kernel<128x256> -- every launch of it and nothing else (tagged where it is launched: the 3x3 256->256 layers "
+                                    "of FPN / RPN / mask head / res4, fc1, the fused RPN and mask-head tails): implicit-GEMM conv on "
                                     "v_mfma_f32_16x16x32_f16, 3 MFMAs per product, both operands pre-split and staged by LDS-DMA through a ring of "
                                     "three 48-KB tiles, the two waves of a SIMD ping-pong between loading and multiplying") if mode == "f16x3" else
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
@@ -645,12 +656,19 @@ def main(args):
                 extra["x101_2048"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         dog.cancel()
     emit(train_obj)
+    # a multi-GPU line whose gradient exchange did not run over all N ranks is not a scaling measurement: say so with the exit code
+    bad_ranks = (world > 1 and not staged and isinstance(train_obj, dict) and "grad_exchange" in train_obj
+                 and train_obj["grad_exchange"]["rccl_ranks"] != world)
+    if bad_ranks:
+        log(f"rank {rank}: FATAL: grad_exchange.rccl_ranks = {train_obj['grad_exchange']['rccl_ranks']} but --gpus {world}")
     if world > 1:
         ranks.barrier()
         if rccl:
             from ampis_amd.utils import comm
             comm.detach_rccl()
         torch.distributed.destroy_process_group()
+    if bad_ranks:
+        sys.exit(4)
 
 
 if __name__ == "__main__":

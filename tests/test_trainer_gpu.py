@@ -258,3 +258,140 @@ def test_momentum_survives_a_regrown_net(tmp_path):
     with pytest.raises(_lib.AmpError):
         a2.load_momentum_dict({"roi_heads.box_head.fc2.bias": np.zeros(7, np.float32)})
     a2.close(); b.close(); ctx.close()
+
+
+NOTEBOOK_GPU_CELLS = r'''
+import os, sys, types, json, pickle
+sys.path.insert(0, ROOT)
+import numpy as np
+import ampis_amd
+ampis_amd.install_as_detectron2()
+if "cv2" not in sys.modules:                      # this image has no OpenCV: cv2.imread is all the notebook needs of it
+    def _imread(p, *a):
+        from PIL import Image
+        return np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1].copy()
+    cv2 = types.ModuleType("cv2"); cv2.imread = _imread; sys.modules["cv2"] = cv2
+os.chdir(WORK)
+# ---- NB:c7 (imports; `from ampis import data_utils` is the product's mirror here: the reference tree is not on the GPU box) ----
+import cv2
+from pathlib import Path
+from detectron2 import model_zoo
+from detectron2.config import get_cfg
+from detectron2.data import DatasetCatalog, MetadataCatalog
+from detectron2.engine import DefaultTrainer, DefaultPredictor
+from ampis_amd import data_utils
+# ---- NB:c11 ----
+EXPERIMENT_NAME = 'particle'
+root = Path('AMPIS','examples','powder')
+json_path_train = Path(root,'data','via_2.0.8/', f'via_powder_{EXPERIMENT_NAME}_masks_training.json')
+json_path_val = Path(root,'data','via_2.0.8/', f'via_powder_{EXPERIMENT_NAME}_masks_validation.json')
+assert json_path_train.is_file(), 'training file not found!'
+assert json_path_val.is_file(), 'validation file not found!'
+# ---- NB:c13 ----
+DatasetCatalog.clear()
+dataset_train = f'{EXPERIMENT_NAME}_Train'
+dataset_valid = f'{EXPERIMENT_NAME}_Val'
+DatasetCatalog.register(dataset_train, lambda f = json_path_train: data_utils.get_ddicts(label_fmt='via2', im_root=f, dataset_class='Train'))
+DatasetCatalog.register(dataset_valid, lambda f = json_path_val: data_utils.get_ddicts(label_fmt='via2', im_root=f, dataset_class='Validation'))
+print(f'Registered Datasets: {list(DatasetCatalog.data.keys())}')
+for d in [dataset_train, dataset_valid]:
+    MetadataCatalog.get(d).set(**{'thing_classes': [EXPERIMENT_NAME]})
+# ---- NB:c20 ----
+cfg = get_cfg()
+cfg.merge_from_file(model_zoo.get_config_file('COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml'))
+cfg.INPUT.MASK_FORMAT = 'polygon'
+cfg.DATASETS.TRAIN = (dataset_train,)
+cfg.DATASETS.TEST = (dataset_train, dataset_valid)
+cfg.SOLVER.IMS_PER_BATCH = 1
+cfg.SOLVER.CHECKPOINT_PERIOD = 400
+cfg.MODEL.DEVICE='cuda'
+cfg.MODEL.ROI_HEADS.NUM_CLASSES = 1
+cfg.TEST.DETECTIONS_PER_IMAGE = 400 if EXPERIMENT_NAME == 'particle' else 150
+cfg.SOLVER.MAX_ITER = 2000
+weights_path = Path('AMPIS','models','model_final_f10217.pkl')
+if weights_path.is_file():
+    print('Using locally stored weights: {}'.format(weights_path))
+else:
+    weights_path = model_zoo.get_checkpoint_url("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml")
+    print('Weights not found, weights will be downloaded from source: {}'.format(weights_path))
+cfg.MODEL.WEIGHTs = str(weights_path)
+cfg.OUTPUT_DIR = str(Path(f'{EXPERIMENT_NAME}_output'))
+os.makedirs(Path(cfg.OUTPUT_DIR), exist_ok=True)
+# ---- the test's only edits: a run of 6 iterations instead of 2000, a checkpoint every 3 ----
+cfg.SOLVER.MAX_ITER = 6
+cfg.SOLVER.CHECKPOINT_PERIOD = 3
+# ---- NB:c22 ----
+trainer = DefaultTrainer(cfg)
+trainer.resume_or_load(resume=False)
+trainer.train()
+# ---- NB:c24 ----
+model_checkpoints = sorted(Path(cfg.OUTPUT_DIR).glob('*.pth'))
+cfg.DATASETS.TEST = (dataset_train, dataset_valid)
+cfg.MODEL.WEIGHTS = str(model_checkpoints[-1])
+predictor = DefaultPredictor(cfg)
+# ---- NB:c26 (without the plot) ----
+img_path = Path(root, 'data','images_png','Sc1Tile_001-001-000_0-000.png')
+img = cv2.imread(str(img_path))
+outs = predictor(img)
+data_utils.format_outputs(img_path, dataset='test', pred=outs)
+# ---- NB:c28 (without the plots) ----
+results = []
+for ds in cfg.DATASETS.TEST:
+    print(f'Dataset: {ds}')
+    for dd in DatasetCatalog.get(ds):
+        print(f'\tFile: {dd["file_name"]}')
+        img = cv2.imread(dd['file_name'])
+        outs = predictor(img)
+        results.append(data_utils.format_outputs(dd['file_name'], ds, outs))
+prediction_save_path = Path(f'{EXPERIMENT_NAME}-results.pickle')
+with open(prediction_save_path, 'wb') as f:
+    pickle.dump(results, f)
+# ---- what the analysis half (NB:c33 on) expects of that file ----
+with open(prediction_save_path, 'rb') as f:
+    back = pickle.load(f)
+assert len(back) == 3 and [r['dataset'] for r in back] == ['particle_Train', 'particle_Train', 'particle_Val']
+for r in back:
+    inst = r['pred']['instances']
+    assert inst.image_size == (1024, 1536) and isinstance(inst.pred_masks, list) and inst.pred_boxes.dtype == np.float32
+    assert len(inst.pred_masks) == len(inst.scores) == len(inst.pred_classes) <= 400 and inst.pred_classes.dtype == np.int64
+    assert all(m['size'] == [1024, 1536] and isinstance(m['counts'], bytes) for m in inst.pred_masks)
+print('CHECKPOINTS', [p.name for p in model_checkpoints], 'ITER', trainer.iter, 'DETECTIONS', [len(r['pred']['instances'].scores) for r in back])
+print('NOTEBOOK GPU CELLS OK')
+'''
+
+
+def test_notebook_training_and_prediction_cells_as_written(tmp_path):
+    """NB:c7-c28 of the reference's tutorial as a user runs them on a GPU box -- `DefaultTrainer(cfg)` -> `resume_or_load(resume=False)` ->
+    `train()` -> `sorted(glob('*.pth'))[-1]` -> `DefaultPredictor(cfg)` -> `predictor(cv2.imread(..))` -> `format_outputs` -> `pickle.dump` --
+    call for call (the plots left out; MAX_ITER 6 instead of 2000), under the module names the notebook imports (`install_as_detectron2`), on
+    the two-image cut of the reference's own VIA project with images drawn from its polygons.  cfg.MODEL.WEIGHTS stays the model-zoo URL
+    (the notebook's `cfg.MODEL.WEIGHTs = ...` sets nothing): no network, so the trainer starts from its seeded initialisation, with a warning.
+    tests/test_zero_edit.py runs c4-c20 and c33-c68 from the notebook file itself where the reference tree exists."""
+    import subprocess
+    import sys
+    from PIL import Image, ImageDraw
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    via = json.load(open(os.path.join(root, "tests", "golden", "via_subset.json")))["via"]
+    data = tmp_path / "AMPIS" / "examples" / "powder" / "data"
+    (data / "via_2.0.8").mkdir(parents=True)
+    (data / "images_png").mkdir()
+    meta = via["_via_img_metadata"]
+    keys = list(meta)
+    rng = np.random.RandomState(0)
+    for k in keys:                                   # a micrograph-like image under every file name: bright particles where the polygons are
+        im = Image.fromarray((40 + 10 * rng.rand(1024, 1536)).astype(np.uint8))
+        dr = ImageDraw.Draw(im)
+        for reg in meta[k]["regions"]:
+            sa = reg["shape_attributes"]
+            dr.polygon(list(zip(sa["all_points_x"], sa["all_points_y"])), fill=int(150 + 60 * rng.rand()))
+        im.save(data / "images_png" / meta[k]["filename"])
+    (data / "via_2.0.8" / "via_powder_particle_masks_training.json").write_text(json.dumps(via))
+    val = dict(via, _via_img_metadata={keys[1]: meta[keys[1]]})
+    (data / "via_2.0.8" / "via_powder_particle_masks_validation.json").write_text(json.dumps(val))
+    script = f"ROOT = {root!r}\nWORK = {str(tmp_path)!r}\n" + NOTEBOOK_GPU_CELLS
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0 and "NOTEBOOK GPU CELLS OK" in r.stdout, (r.stdout[-1500:] + r.stderr[-3000:])
+    assert "Registered Datasets: ['particle_Train', 'particle_Val']" in r.stdout
+    line = [l for l in r.stdout.splitlines() if l.startswith("CHECKPOINTS")][0]
+    assert "model_final.pth" in line and "ITER 6" in line, line
+    print(line)
