@@ -321,6 +321,12 @@ class Context:
         check(lib().amp_comm_stats(self._h, C.byref(e), C.byref(s)), "amp_comm_stats")
         return {"exposed_ms": e.value, "span_ms": s.value}
 
+    def rowtab_stats(self):
+        """Weight-gradient row-table cache of this context (wgrad.hip): hits, misses, generation switches, resident bytes."""
+        v = (C.c_ulonglong * 4)()
+        check(lib().amp_debug_rowtab_stats(self._h, v), "amp_debug_rowtab_stats")
+        return {"hits": int(v[0]), "misses": int(v[1]), "generation_switches": int(v[2]), "resident_bytes": int(v[3])}
+
     def comm_wait(self):
         """The context's stream waits for every collective issued so far (before reading the gradient arena after an exchange)."""
         check(lib().amp_comm_wait(self._h), "amp_comm_wait")

@@ -177,7 +177,16 @@ def checkpoint_momentum(path):
     """name -> ndarray of the SGD momentum buffers stored by save_checkpoint ({} when the file has none)."""
     try:
         d = torch.load(str(path), map_location="cpu", weights_only=False)
-        mb = d.get("optimizer", {}).get("momentum_buffers", {}) if isinstance(d, dict) else {}
+        opt = d.get("optimizer", {}) if isinstance(d, dict) else {}
+        if isinstance(opt, dict) and "momentum_buffers" not in opt and "state" in opt and "param_groups" in opt:
+            # a detectron2 / reference checkpoint: torch's SGD.state_dict() indexes the buffers by parameter POSITION in an optimizer this
+            # process never built, so they cannot be mapped to names reliably -- say so instead of dropping them silently (INTEGRATION.md §4)
+            import logging
+            logging.getLogger("ampis_amd").warning(
+                f"{path}: the optimizer state is torch's SGD.state_dict() ({len(opt['state'])} buffers by parameter index); momentum is NOT "
+                "restored from it (weights and iteration are) -- the first steps after this resume run with zero momentum")
+            return {}
+        mb = opt.get("momentum_buffers", {}) if isinstance(opt, dict) else {}
         return {k: _to_numpy(v).astype(np.float32) for k, v in mb.items()}
     except Exception:
         return {}

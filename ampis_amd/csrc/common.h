@@ -132,9 +132,17 @@ struct amp_ctx {
     int* roi_order = nullptr;              // roi_align.hip: XCD-major processing order of the RoIs of a call (8 x (R/8 + 64) + 8 ints)
     size_t roi_order_ints = 0;
     // wgrad row tables (wgrad.hip): they depend on the layer geometry only, so a training loop computes each once, not once per step
-    struct RowTab { int key[9]; unsigned int* tab; size_t n; };
+    // ONE arena per context, allocated at the first weight-gradient call (not inside a later step), in two generations: tables are bump-allocated
+    // in the current generation; when it is full the OTHER generation's tables are dropped and it becomes the current one -- what was used
+    // during the last generation survives, memory is bounded, no allocation or free ever happens in a training step (stream order makes the
+    // re-use safe: tables are written and read on `stream` only).  amp_debug_rowtab_stats reports hits / misses / resident bytes.
+    struct RowTab { int key[9]; unsigned int* tab; size_t n; int gen; };
     std::vector<RowTab> rowtabs;
-    size_t rowtab_bytes = 0;
+    unsigned int* rowtab_arena = nullptr;
+    size_t rowtab_gen_words = 0;           // capacity of one generation, in 4-byte words (AMP_ROWTAB_MB: total arena, default 512 MiB)
+    size_t rowtab_used[2] = {0, 0};        // words used in each generation
+    int rowtab_gen = 0;
+    unsigned long long rowtab_hits = 0, rowtab_misses = 0, rowtab_flushes = 0;
     // weight-gradient reductions on a second stream (wgrad.hip amp::wgrad_async_*): the MFMA kernel of a layer stays on `stream`, its
     // slab reduction runs on `side` behind an event, two scratch buffers alternate; the next layers' kernels do not wait for it
     bool reduce_async = false;

@@ -165,7 +165,7 @@ void amp_destroy(amp_ctx* ctx) {
     (void)hipFree(ctx->d_conv_flag);
     (void)hipFree(ctx->split_scratch);
     (void)hipFree(ctx->topk_scratch);
-    for (auto& t : ctx->rowtabs) (void)hipFree(t.tab);
+    if (ctx->rowtab_arena) (void)hipFree(ctx->rowtab_arena);
     (void)hipFree(ctx->roi_order);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -1003,25 +1003,44 @@ int amp_conv2d_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, c
     const size_t tab_n = (size_t)a.KH * a.KW * a.Mpad;
     a.bias_partial = bias_grad ? reinterpret_cast<float*>(rowtab + tab_n) : nullptr;
     // The table is a function of the geometry alone: a context keeps the tables of the shapes it has seen (a training loop asks for the same
-    // ~30 every step: 69 launches and 0.4 ms per step otherwise) up to 512 MiB / 128 shapes; beyond that, and on a miss, it is made in the
-    // call's scratch as before.
+    // ~30 every step: 69 launches and 0.4 ms per step otherwise) in a two-generation arena (common.h): bounded memory, no allocation inside
+    // a step, and a run whose frames change (multi-scale training) keeps the tables of its recent frames instead of the first four it saw.
+    // A table larger than a generation, or a failed arena allocation, falls back to the call's scratch as before.
     {
         const int key[9] = {a.B, a.H, a.W, a.Cin, a.KH, a.KW, a.stride, a.pad, a.Mpad};
         static const bool no_cache = getenv("AMP_NO_ROWTAB_CACHE") != nullptr;      // EXPERIMENT switch
         unsigned int* cached = nullptr;
         for (auto& t : ctx->rowtabs) if (memcmp(t.key, key, sizeof(key)) == 0) { cached = t.tab; break; }
-        if (!cached && !no_cache && ctx->rowtabs.size() < 128 && ctx->rowtab_bytes + tab_n * 4 <= ((size_t)512 << 20)) {
-            unsigned int* t = nullptr;
-            if (hipMalloc(&t, tab_n * 4) == hipSuccess) {
+        if (cached) ++ctx->rowtab_hits;
+        if (!cached && !no_cache) {
+            ++ctx->rowtab_misses;
+            if (!ctx->rowtab_arena && ctx->rowtab_gen_words == 0) {
+                const char* mb = getenv("AMP_ROWTAB_MB");
+                const size_t total = (size_t)std::max(64, mb ? atoi(mb) : 512) << 20;
+                AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (hipMalloc(&ctx->rowtab_arena, total) == hipSuccess) ctx->rowtab_gen_words = total / 8;      // two generations
+                else { (void)hipGetLastError(); ctx->rowtab_arena = nullptr; ctx->rowtab_gen_words = (size_t)-1; }      // do not try again
+            }
+            const size_t words = (tab_n + 63) & ~(size_t)63;
+            if (ctx->rowtab_arena && words <= ctx->rowtab_gen_words) {
+                if (ctx->rowtab_used[ctx->rowtab_gen] + words > ctx->rowtab_gen_words) {
+                    // the current generation is full: the other one's tables go (none of them was asked for since the last switch -- a hit
+                    // re-homes nothing, so a table in steady use is re-made once per two switches at worst) and it becomes the current one
+                    const int g = ctx->rowtab_gen ^ 1;
+                    ctx->rowtabs.erase(std::remove_if(ctx->rowtabs.begin(), ctx->rowtabs.end(), [g](const amp_ctx::RowTab& t) { return t.gen == g; }), ctx->rowtabs.end());
+                    ctx->rowtab_used[g] = 0;
+                    ctx->rowtab_gen = g;
+                    ++ctx->rowtab_flushes;
+                }
+                const int g = ctx->rowtab_gen;
+                unsigned int* t = ctx->rowtab_arena + (size_t)g * ctx->rowtab_gen_words + ctx->rowtab_used[g];
+                ctx->rowtab_used[g] += words;
                 WgradArgs ta = a;
                 hipLaunchKernelGGL(wgrad_rowtab_kernel, dim3((unsigned)std::min<size_t>((tab_n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, ta, t);
                 amp_ctx::RowTab e;
-                memcpy(e.key, key, sizeof(key)); e.tab = t; e.n = tab_n;
+                memcpy(e.key, key, sizeof(key)); e.tab = t; e.n = tab_n; e.gen = g;
                 ctx->rowtabs.push_back(e);
-                ctx->rowtab_bytes += tab_n * 4;
                 cached = t;
-            } else {
-                (void)hipGetLastError();
             }
         }
         if (cached) a.rowtab = cached;
@@ -1158,4 +1177,12 @@ int amp::wgrad_async_end(amp_ctx* ctx) {
     const int st = amp::wgrad_async_join(ctx);
     ctx->reduce_async = false;
     return st;
+}
+
+// hits / misses / generation switches of the weight-gradient row-table cache of a context, and the bytes its tables occupy (tools/bench_trainer.py)
+extern "C" int amp_debug_rowtab_stats(amp_ctx* ctx, unsigned long long* out4) {
+    if (!ctx || !out4) return AMP_ERR_ARG;
+    out4[0] = ctx->rowtab_hits; out4[1] = ctx->rowtab_misses; out4[2] = ctx->rowtab_flushes;
+    out4[3] = (unsigned long long)(ctx->rowtab_used[0] + ctx->rowtab_used[1]) * 4ull;
+    return AMP_OK;
 }

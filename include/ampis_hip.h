@@ -567,7 +567,11 @@ int amp_model_grads_exchanged(amp_model* m, int* exchanged);
  *
  * amp_model_forward_backward on a communicator of more than one rank is a collective: every rank must call it for every step; a
  * rank whose step fails still completes the step's RCCL sequence, and then EVERY rank returns an error for that step (the failing
- * rank its own status, the others AMP_ERR_STATE) with the gradients discarded. */
+ * rank its own status, the others AMP_ERR_STATE) with the gradients discarded.
+ * What that covers: failures that leave the HIP runtime usable -- bad arguments, capacity / out-of-memory refusals, the f16 range flag.
+ * A HIP error is sticky: the failing rank can then no longer issue its remaining buckets or join the agreement, and its peers would wait
+ * in a collective nobody joins.  RCCL has no timeout of its own, so on AMP_ERR_HIP the caller must end the job (the trainer does: it
+ * raises, the launcher tears the group down); the library does not try to continue on a dead device. */
 int amp_model_broadcast_params(amp_model* m, int root);
 
 #ifdef __cplusplus

@@ -145,3 +145,24 @@ def test_pth_round_trip_with_iteration_and_momentum(tmp_path):
 def test_urls_are_refused_without_a_network(tmp_path):
     with pytest.raises(FileNotFoundError):
         checkpoint.load_checkpoint("detectron2://COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x/137849600/model_final_f10217.pkl", 1)
+
+
+def test_a_torch_layout_optimizer_state_is_reported_not_silently_dropped(tmp_path, caplog):
+    """A detectron2 / reference checkpoint stores torch's SGD.state_dict() (`state` by parameter index + `param_groups`): its momentum cannot be
+    mapped to names here -- checkpoint_momentum returns nothing AND says so, while weights and iteration still load."""
+    import logging
+    import torch
+    from ampis_amd import checkpoint, params as P
+    p = P.init_params(1, seed=1, style="spread")
+    path = tmp_path / "d2_style.pth"
+    torch.save({"model": {k: torch.as_tensor(v) for k, v in p.items()}, "iteration": 41,
+                "optimizer": {"state": {0: {"momentum_buffer": torch.zeros(3)}, 1: {"momentum_buffer": torch.ones(2)}},
+                              "param_groups": [{"lr": 0.02, "momentum": 0.9, "params": [0, 1]}]}}, str(path))
+    with caplog.at_level(logging.WARNING, logger="ampis_amd"):
+        mom = checkpoint.checkpoint_momentum(str(path))
+    assert mom == {} and any("momentum is NOT" in r.getMessage() for r in caplog.records)
+    assert checkpoint.checkpoint_iteration(str(path)) == 41
+    # the format written here round-trips with its buffers
+    own = tmp_path / "own.pth"
+    checkpoint.save_checkpoint(str(own), p, iteration=7, optimizer={"roi_heads.box_head.fc1.weight": np.ones_like(p["roi_heads.box_head.fc1.weight"])})
+    assert set(checkpoint.checkpoint_momentum(str(own))) == {"roi_heads.box_head.fc1.weight"}

@@ -9,16 +9,22 @@ from ampis_amd.data import DatasetCatalog, MetadataCatalog
 from ampis_amd.engine import DefaultTrainer
 
 N, S, B, ITERS = 32, 1024, 16, 12
+# "multiscale": the model zoo's own training config (MIN_SIZE_TRAIN 640..800 sampled per image, MAX_SIZE_TRAIN 1333) on 1024 x 1536 micrographs:
+# the batch frame changes from iteration to iteration, so the weight-gradient row tables (wgrad.hip) are re-used only through the cache --
+# its hit rate is printed (the fixed 1024 x 1024 bench says nothing about that).  B = 8 there, 40 iterations.
+MULTI = len(sys.argv) > 1 and sys.argv[1] == "multiscale"
+if MULTI:
+    N, B, ITERS = 16, 8, 40
 dd = []
 for i in range(N):
-    img, gt = synth.micrograph(i, S, S)
+    img, gt = synth.micrograph(i, S, 1536 if MULTI else S)
     annos = [{"bbox": [float(v) for v in b], "bbox_mode": 0, "segmentation": [[float(v) for v in p]], "category_id": 0}
              for b, p in zip(gt["boxes"], gt["polygons"])]
-    dd.append({"file_name": f"synthetic_{i}.png", "image_bgr": img, "height": S, "width": S, "image_id": i, "annotations": annos})
+    dd.append({"file_name": f"synthetic_{i}.png", "image_bgr": img, "height": S, "width": img.shape[1], "image_id": i, "annotations": annos})
 tmp = tempfile.mkdtemp()
 checkpoint.save_checkpoint(os.path.join(tmp, "init.pth"), P.init_params(1, seed=4, style="spread"))
 out = {}
-for workers in (0, 4):
+for workers in ((4,) if MULTI else (0, 4)):
     DatasetCatalog.clear()
     DatasetCatalog.register("particle_Train", lambda: dd)
     MetadataCatalog.get("particle_Train").set(thing_classes=["particle"])
@@ -27,7 +33,8 @@ for workers in (0, 4):
     cfg.DATASETS.TRAIN, cfg.DATASETS.TEST = ("particle_Train",), ("particle_Train",)
     cfg.SOLVER.IMS_PER_BATCH, cfg.SOLVER.MAX_ITER, cfg.SOLVER.CHECKPOINT_PERIOD, cfg.SOLVER.BASE_LR = B, ITERS, 10 ** 6, 1e-4
     cfg.MODEL.WEIGHTS, cfg.MODEL.ROI_HEADS.NUM_CLASSES = os.path.join(tmp, "init.pth"), 1
-    cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (S,), S
+    if not MULTI:
+        cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (S,), S
     cfg.DATALOADER.NUM_WORKERS = workers
     cfg.OUTPUT_DIR = os.path.join(tmp, f"out{workers}")
     tr = DefaultTrainer(cfg)
@@ -42,5 +49,11 @@ for workers in (0, 4):
     tr.register_hooks([Clock()]) if hasattr(tr, "register_hooks") else tr._hooks.append(Clock())
     tr.train()
     out[f"NUM_WORKERS={workers}"] = {"ms_per_iter_median": round(float(np.median(times[3:])) * 1e3, 1), "images_per_s": round(B / float(np.median(times[3:])), 1)}
+    try:
+        st = tr.ctx.rowtab_stats()
+        st["hit_rate"] = round(st["hits"] / max(st["hits"] + st["misses"], 1), 4)
+        out[f"NUM_WORKERS={workers}"]["wgrad_rowtab_cache"] = st
+    except Exception as e:   # noqa: BLE001
+        out[f"NUM_WORKERS={workers}"]["wgrad_rowtab_cache"] = repr(e)
     del tr
 print(json.dumps(out))
