@@ -544,6 +544,10 @@ class DefaultTrainer:
                 for h in self._hooks:
                     h.after_step()
                 self.storage.step()
+            # detectron2 TrainerBase.train: "self.iter == max_iter can be used by `after_train` to tell whether the training successfully
+            # finished or failed due to exceptions" -- after a complete run trainer.iter is max_iter, not max_iter - 1
+            if self.max_iter > self.start_iter:
+                self.iter += 1
         finally:
             sys.setswitchinterval(switch)
             try:
