@@ -110,6 +110,7 @@ def _declare(L):
         "amp_group_expand_weights": ([vp, vp, i, i, i, i, vp], i),
         "amp_resize_scratch_bytes": ([i, i, i, i], C.c_size_t),
         "amp_resize_bilinear_u8": ([vp, vp, i, i, vp, i, i, vp], i),
+        "amp_resize_flip_u8": ([vp, vp, i, i, vp, i, i, i, i, vp], i),
         "amp_compact_dets": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_set_conv_mode": ([vp, i], i),
         "amp_get_conv_mode": ([vp], i),

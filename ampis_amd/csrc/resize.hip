@@ -52,8 +52,9 @@ __device__ __forceinline__ unsigned char clip8(int v) {
 }
 
 // out[y][xx][c] = clip8(round_half + sum_x in[y][xmin+x][c] * k[xx][x])
+// opitch: pixels per output row (>= w: the output may be the top-left part of a wider frame); flip: output column xx lands at w - 1 - xx
 __global__ void resample_h_kernel(const unsigned char* __restrict__ in, int H, int W, unsigned char* __restrict__ out, int w,
-                                  const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+                                  const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int opitch, int flip) {
     const size_t total = (size_t)H * w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int xx = (int)(i % w), y = (int)(i / w);
@@ -65,13 +66,13 @@ __global__ void resample_h_kernel(const unsigned char* __restrict__ in, int H, i
             const int c = k[x];
             s0 += p[3 * x] * c; s1 += p[3 * x + 1] * c; s2 += p[3 * x + 2] * c;
         }
-        unsigned char* o = out + i * 3;
+        unsigned char* o = out + ((size_t)y * opitch + (flip ? w - 1 - xx : xx)) * 3;
         o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
     }
 }
 
 __global__ void resample_v_kernel(const unsigned char* __restrict__ in, int H, int W, unsigned char* __restrict__ out, int h,
-                                  const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
+                                  const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int opitch, int flip) {
     const size_t total = (size_t)h * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % W), yy = (int)(i / W);
@@ -84,8 +85,19 @@ __global__ void resample_v_kernel(const unsigned char* __restrict__ in, int H, i
             const unsigned char* q = p + (size_t)y * W * 3;
             s0 += q[0] * c; s1 += q[1] * c; s2 += q[2] * c;
         }
-        unsigned char* o = out + i * 3;
+        unsigned char* o = out + ((size_t)yy * opitch + (flip ? W - 1 - x : x)) * 3;
         o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+    }
+}
+
+// no resize: rows copied into a pitched frame, optionally mirrored
+__global__ void copy_flip_kernel(const unsigned char* __restrict__ in, int H, int W, unsigned char* __restrict__ out, int opitch, int flip) {
+    const size_t total = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)(i / W);
+        const unsigned char* p = in + i * 3;
+        unsigned char* o = out + ((size_t)y * opitch + (flip ? W - 1 - x : x)) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
     }
 }
 
@@ -101,8 +113,19 @@ size_t amp_resize_scratch_bytes(int H, int W, int h, int w) {
     return (((size_t)H * w * 3 + 255) & ~(size_t)255) + 4 * ((size_t)2 * (h + w) + (size_t)h * ky + (size_t)w * kx) + 1024;
 }
 
-int amp_resize_bilinear_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int h, int w, void* tmp) {
-    AMP_REQUIRE(ctx && src && dst && tmp && H > 0 && W > 0 && h > 0 && w > 0, "amp_resize_bilinear_u8: bad argument");
+/* The same resize into the top-left h x w pixels of a frame whose rows are dst_pitch pixels apart (dst_pitch >= w), optionally mirrored
+ * left-right afterwards -- detectron2's ResizeShortestEdge + RandomFlip of a training image, written where ImageList.from_tensors would
+ * stack it (ampis/data_utils.py:171-175 DatasetMapper; round 4: the train loader does this on the device).  Pixels of the frame outside
+ * the h x w part are not touched. */
+int amp_resize_flip_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int dst_pitch, int h, int w, int flip, void* tmp) {
+    AMP_REQUIRE(ctx && src && dst && H > 0 && W > 0 && h > 0 && w > 0 && dst_pitch >= w, "amp_resize_flip_u8: bad argument");
+    AMP_REQUIRE(tmp || (h == H && w == W), "amp_resize_flip_u8: a resize needs scratch (amp_resize_scratch_bytes)");
+    if (h == H && w == W) {
+        if (!flip && dst_pitch == w) AMP_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)H * W * 3, hipMemcpyDeviceToDevice, ctx->stream));
+        else hipLaunchKernelGGL(copy_flip_kernel, dim3((unsigned)std::min<size_t>(((size_t)H * W + 255) / 256, 16384)), dim3(256), 0, ctx->stream, src, H, W, dst, dst_pitch, flip);
+        AMP_HIP_CHECK(hipGetLastError());
+        return AMP_OK;
+    }
     std::vector<int> xb, xk, yb, yk;
     int kx = 0, ky = 0;
     coeffs(W, w, xb, xk, kx);
@@ -117,19 +140,23 @@ int amp_resize_bilinear_u8(amp_ctx* ctx, const unsigned char* src, int H, int W,
     AMP_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // the host vectors go out of scope
     const unsigned char* vin = src;
     int vW = W;
-    if (w != W) {       // Pillow: horizontal pass first, into a temporary
+    const bool two = (w != W) && (h != H);
+    if (w != W) {       // Pillow: horizontal pass first, into a temporary when a vertical pass follows (then the flip belongs to the vertical pass)
         hipLaunchKernelGGL(resample_h_kernel, dim3((unsigned)std::min<size_t>(((size_t)H * w + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
-                           src, H, W, (h != H) ? mid : dst, w, d_xb, d_xk, kx);
+                           src, H, W, two ? mid : dst, w, d_xb, d_xk, kx, two ? w : dst_pitch, two ? 0 : flip);
         vin = mid; vW = w;
     }
     if (h != H) {
         hipLaunchKernelGGL(resample_v_kernel, dim3((unsigned)std::min<size_t>(((size_t)h * vW + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
-                           vin, H, vW, dst, h, d_yb, d_yk, ky);
-    } else if (w == W) {
-        AMP_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)H * W * 3, hipMemcpyDeviceToDevice, ctx->stream));
+                           vin, H, vW, dst, h, d_yb, d_yk, ky, dst_pitch, flip);
     }
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
+}
+
+int amp_resize_bilinear_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int h, int w, void* tmp) {
+    AMP_REQUIRE(ctx && src && dst && tmp && H > 0 && W > 0 && h > 0 && w > 0, "amp_resize_bilinear_u8: bad argument");
+    return amp_resize_flip_u8(ctx, src, H, W, dst, w, h, w, 0, tmp);
 }
 
 }  // extern "C"

@@ -230,24 +230,35 @@ class DatasetMapper:
         flip = str(c.INPUT.get("RANDOM_FLIP", "horizontal")) == "horizontal" and bool(self._rng.random() < 0.5)
         return min_size, flip
 
-    def apply(self, dataset_dict, min_size, flip):
-        """Image read + ResizeShortestEdge (+ flip, ground truth): no random state, safe to run in a worker thread."""
-        from .engine.defaults import read_image_bgr, resize_shortest_edge
+    def apply(self, dataset_dict, min_size, flip, defer=False):
+        """Image read + ResizeShortestEdge (+ flip, ground truth): no random state, safe to run in a worker thread.
+        defer=True (the train loader with a device uploader, round 4): the pixels are NOT resized or mirrored here -- d["image_bgr"] stays the
+        decoded image and d["device_plan"] = (new_h, new_w, flip) tells the uploader what amp_resize_flip_u8 has to do; the annotations are
+        transformed for the new size as always.  The frame the network sees is byte for byte the one the host path stacks
+        (tests/test_train_input_gpu.py)."""
+        from .engine.defaults import read_image_bgr, resize_shortest_edge, shortest_edge_size
         c = self.cfg
         img = dataset_dict["image_bgr"] if "image_bgr" in dataset_dict else read_image_bgr(dataset_dict["file_name"])
         h, w = img.shape[:2]
         max_size = int(c.INPUT.MAX_SIZE_TRAIN) if self.is_train else int(c.INPUT.MAX_SIZE_TEST)
-        out = resize_shortest_edge(np.ascontiguousarray(img), min_size, max_size)
-        nh, nw = out.shape[:2]
+        defer = bool(defer) and self.is_train
+        if defer:
+            out = img
+            nh, nw = shortest_edge_size(h, w, min_size, max_size)
+        else:
+            out = resize_shortest_edge(np.ascontiguousarray(img), min_size, max_size)
+            nh, nw = out.shape[:2]
         d = {k: v for k, v in dataset_dict.items() if k not in ("annotations", "image_bgr")}
         d["height"], d["width"] = h, w
+        if defer:
+            d["device_plan"] = (int(nh), int(nw), bool(flip))
         if self.is_train:
-            if flip:
+            if flip and not defer:
                 out = out[:, ::-1]
             annos = dataset_dict.get("annotations", [])
             if str(c.INPUT.get("MASK_FORMAT", "polygon")) == "bitmask":
                 d["gt"] = transform_annotations_bitmask(annos, h, w, nh, nw, flip)
-                d["image_bgr"] = np.ascontiguousarray(out)
+                d["image_bgr"] = out if defer else np.ascontiguousarray(out)
                 return d
             ent = self._parsed.get(id(annos))
             if ent is None or ent[0] is not annos:
@@ -255,7 +266,7 @@ class DatasetMapper:
                 self._parsed[id(annos)] = ent
             d["gt"] = (transform_parsed(ent[1], nw / w, nh / h, flip, nw, nh) if ent[1] is not None
                        else _transform_annotations_loop(annos, nw / w, nh / h, flip, nw, nh))
-        d["image_bgr"] = np.ascontiguousarray(out)
+        d["image_bgr"] = out if defer else np.ascontiguousarray(out)
         return d
 
     def __call__(self, dataset_dict):
@@ -324,13 +335,20 @@ class CollatedBatch(list):
     device = None      # (device pointer, (B, H, W)) of the stacked frame when the loader was given an `upload` callable
 
 
+def mapped_hw(d):
+    """(h, w) of a mapped image as the network will see it: the deferred plan's size, else the pixels' own."""
+    plan = d.get("device_plan")
+    return (plan[0], plan[1]) if plan else tuple(d["image_bgr"].shape[:2])
+
+
 def _collate(futures, upload=None):
     batch = CollatedBatch(f.result() for f in futures)
     if all("gt" in d for d in batch):
         from .engine.defaults import TrainModel
         batch.collated = TrainModel.collate(batch)
         if upload is not None:
-            batch.device = upload(batch.collated[0])
+            # deferred batches (device_plan): the uploader resizes / mirrors / stacks on the device; else it copies the host-stacked frame
+            batch.device = upload.frames(batch) if batch.collated[0] is None else upload(batch.collated[0])
     return batch
 
 
@@ -352,7 +370,8 @@ def _prefetched(plans, mapper, workers, depth=PREFETCH_DEPTH, upload=None):
     def produce():
         try:
             for plan in plans:
-                futs = collator.submit(_collate, [pool.submit(mapper.apply, *t) for t in plan], upload)
+                defer = upload is not None and getattr(upload, "device_resize", False)
+                futs = collator.submit(_collate, [pool.submit(mapper.apply, *t, defer) if defer else pool.submit(mapper.apply, *t) for t in plan], upload)
                 while not stop.is_set():
                     try:
                         q.put(futs, timeout=0.2)

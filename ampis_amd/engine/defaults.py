@@ -224,6 +224,12 @@ class TrainModel:
 
     @staticmethod
     def stack(batch):
+        from ..data import mapped_hw
+        if all("device_plan" in d for d in batch):      # deferred: the uploader builds the frame on the device (no host copy of 3 MB per image)
+            hw = [mapped_hw(d) for d in batch]
+            H, W = max(h for h, _ in hw), max(w for _, w in hw)
+            return None, (None if all(h == H and w == W for h, w in hw) else hw)
+        assert not any("device_plan" in d for d in batch), "a batch mixes deferred and host-resized images"
         hs = [d["image_bgr"].shape[0] for d in batch]
         ws = [d["image_bgr"].shape[1] for d in batch]
         H, W = max(hs), max(ws)
@@ -244,13 +250,14 @@ class TrainModel:
     def __call__(self, batch, backward=False, seed=None):
         assert self.training, "TrainModel is the training-mode surface; use DefaultPredictor for inference"
         imgs, sizes, gt = getattr(batch, "collated", None) or self.collate(batch)
+        dev = getattr(batch, "device", None)          # the loader's collating thread has put the frame into HBM already (_Uploader)
+        assert imgs is not None or dev is not None, "a deferred batch (device_plan) needs the loader's uploader"
         if self._ensure is not None:   # a validation batch (LossEvalHook, ampis/data_utils.py:116) may be larger than every training batch so far
-            self._ensure(imgs.shape[1], imgs.shape[2])
+            self._ensure(*(dev[1][1:] if imgs is None else imgs.shape[1:3]))
         self.net.set_image_sizes(sizes)
         if seed is None:
             self._seed += 1
             seed = 0x5EED0000 + self._seed
-        dev = getattr(batch, "device", None)          # the loader's collating thread has put the frame into HBM already (_Uploader)
         if dev is not None:
             return self.net.forward_losses(None, gt, seed=seed, backward=backward, device_ptr=dev[0], shape=dev[1])
         return self.net.forward_losses(imgs, gt, seed=seed, backward=backward)
@@ -262,12 +269,65 @@ class _Uploader:
     The copy is complete (stream-synchronised) when __call__ returns, so the compute stream needs no event.  A buffer is re-used after
     `nbuf` batches: the loader holds at most PREFETCH_DEPTH finished batches plus the one being collated, the trainer one."""
 
+    device_resize = True      # the train loader defers ResizeShortestEdge + flip + stacking to `frames` (AMP_HOST_TRAIN_INPUT=1: the host path)
+
     def __init__(self, device, nbuf):
         import threading
         self.ctx = _lib.Context(device)
         self.bufs = [(0, 0)] * nbuf       # (pointer, bytes)
         self.k = 0
         self._lock = threading.Lock()     # close() may come from the training thread while the collating thread is uploading
+        self._stage = {}                  # "src" / "tmp": device staging of one decoded image and the resize scratch
+        if os.environ.get("AMP_HOST_TRAIN_INPUT"):
+            self.device_resize = False
+
+    def _scratch(self, key, nbytes):
+        ptr, cap = self._stage.get(key, (0, 0))
+        if cap < nbytes:
+            if ptr:
+                self.ctx.free(ptr)
+            ptr, cap = self.ctx.malloc(nbytes), nbytes
+            self._stage[key] = (ptr, cap)
+        return ptr
+
+    def frames(self, batch):
+        """The stacked frame of a deferred batch, built in HBM: every decoded image goes up once as it is, amp_resize_flip_u8 (PIL-exact
+        resize + mirror) writes it into its slot of the zeroed frame -- what DatasetMapper + ImageList.from_tensors do on the host, byte for
+        byte (tests/test_train_input_gpu.py).  An image that needs neither resize nor flip and fills the frame is copied straight into it."""
+        import ctypes as C
+        from ..data import mapped_hw
+        hw = [mapped_hw(d) for d in batch]
+        B, H, W = len(batch), max(h for h, _ in hw), max(w for _, w in hw)
+        nbytes = B * H * W * 3
+        with self._lock:
+            if self.ctx is None:
+                return None
+            ptr, cap = self.bufs[self.k]
+            if cap < nbytes:
+                if ptr:
+                    self.ctx.free(ptr)
+                ptr, cap = self.ctx.malloc(nbytes), nbytes
+                self.bufs[self.k] = (ptr, cap)
+            L = _lib.lib()
+            if any((h, w) != (H, W) for h, w in hw):
+                _lib.check(L.amp_memset(self.ctx.handle, C.c_void_p(ptr), 0, nbytes), "amp_memset")       # the padding of the smaller images
+            for b, d in enumerate(batch):
+                img = np.ascontiguousarray(d["image_bgr"], dtype=np.uint8)
+                h0, w0 = img.shape[:2]
+                (h, w), flip = hw[b], bool(d["device_plan"][2])
+                slot = ptr + b * H * W * 3
+                if (h, w) == (h0, w0) and not flip and w == W:
+                    self.ctx.h2d(slot, img)                                   # rows contiguous in the slot: no kernel
+                    continue
+                src = self._scratch("src", img.nbytes)
+                self.ctx.h2d(src, img)
+                tmp = self._scratch("tmp", int(L.amp_resize_scratch_bytes(h0, w0, h, w))) if (h, w) != (h0, w0) else 0
+                _lib.check(L.amp_resize_flip_u8(self.ctx.handle, C.c_void_p(src), h0, w0, C.c_void_p(slot), W, h, w, int(flip), C.c_void_p(tmp) if tmp else None),
+                           "amp_resize_flip_u8")
+                self.ctx.sync()                                               # `src` is re-used by the next image
+            self.ctx.sync()
+            self.k = (self.k + 1) % len(self.bufs)
+            return ptr, (B, H, W)
 
     def __call__(self, imgs):
         imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
@@ -288,10 +348,10 @@ class _Uploader:
         with self._lock:
             if self.ctx is None:
                 return
-            for ptr, _ in self.bufs:
+            for ptr, _ in list(self.bufs) + list(self._stage.values()):
                 if ptr:
                     self.ctx.free(ptr)
-            self.bufs = []
+            self.bufs, self._stage = [], {}
             self.ctx.close()
             self.ctx = None
 
@@ -508,9 +568,10 @@ class DefaultTrainer:
         from ..utils import comm
         if self.data_loader is None:
             self._build_loader()
+        from ..data import mapped_hw
         batch = next(self.data_loader)
-        h = max(d["image_bgr"].shape[0] for d in batch)
-        w = max(d["image_bgr"].shape[1] for d in batch)
+        h = max(mapped_hw(d)[0] for d in batch)
+        w = max(mapped_hw(d)[1] for d in batch)
         self._ensure_net(h, w)
         losses = self.model(batch, backward=True, seed=(self.iter * 7919 + comm.get_rank()) & 0x7FFFFFFF)
         scale = comm.all_reduce_gradients(self._net, self.ctx)

@@ -109,6 +109,10 @@ int amp_split_weights(amp_ctx* ctx, const float* w, long long rows, int K, float
  * tmp (amp_resize_scratch_bytes) are device pointers. */
 size_t amp_resize_scratch_bytes(int H, int W, int h, int w);
 int amp_resize_bilinear_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int h, int w, void* tmp);
+/* Train-time input pipeline on the device (detectron2 DatasetMapper under ampis/data_utils.py:171-175: ResizeShortestEdge + RandomFlip, then
+ * ImageList.from_tensors): the same resize written into the top-left h x w pixels of a frame slot whose rows are dst_pitch pixels apart,
+ * mirrored left-right when flip != 0 (== numpy out[:, ::-1] of the resized image).  h == H and w == W: a (mirrored) copy, tmp may be null. */
+int amp_resize_flip_u8(amp_ctx* ctx, const unsigned char* src, int H, int W, unsigned char* dst, int dst_pitch, int h, int w, int flip, void* tmp);
 
 /* Stage a9/a10/a11/a14/a16: implicit-GEMM convolution on fp32 MFMA ------------------------- */
 typedef struct amp_conv_desc {

@@ -163,3 +163,40 @@ def test_gradient_all_reduce_world_size_2_gloo():
     assert [r[1] for r in res] == [3.0, 3.0]             # 1 + 2 on both ranks
     assert all(r[2] == 0.5 and r[3] == 2 for r in res)
     assert [r[4] for r in res] == [True, False]
+
+
+def test_deferred_mapping_plans_exactly_what_the_host_mapping_does():
+    """The device input path (round 4) leaves ResizeShortestEdge + flip + stacking to the uploader: the mapper's deferred form must hand over the
+    decoded pixels untouched, the size PIL would produce, the flip, and the SAME transformed annotations; collate then carries no host frame
+    but the same per-image sizes.  (The bytes of the device-built frame are compared on the GPU: tests/test_train_input_gpu.py.)"""
+    import numpy as np
+    from ampis_amd import model_zoo, synth
+    from ampis_amd.config import get_cfg
+    from ampis_amd.data import DatasetMapper, mapped_hw
+    from ampis_amd.engine.defaults import TrainModel
+    cfg = get_cfg()
+    cfg.merge_from_file(model_zoo.get_config_file("COCO-InstanceSegmentation/mask_rcnn_R_50_FPN_3x.yaml"))
+    cfg.INPUT.MIN_SIZE_TRAIN, cfg.INPUT.MAX_SIZE_TRAIN = (160, 192, 224, 300), 260
+    dicts = []
+    for i, (h, w) in enumerate([(200, 280), (280, 200), (192, 192)]):
+        img, gt = synth.micrograph(i, h, w, seed=5)
+        annos = [{"bbox": [float(v) for v in b], "bbox_mode": 0, "segmentation": [[float(v) for v in p]], "category_id": 0}
+                 for b, p in list(zip(gt["boxes"], gt["polygons"]))[:30]]
+        dicts.append({"file_name": f"s{i}.png", "image_bgr": img, "height": h, "width": w, "image_id": i, "annotations": annos})
+    m = DatasetMapper(cfg, True, seed=1)
+    flips = 0
+    for rep in range(12):
+        plans = [(d,) + tuple(m.draw()) for d in dicts]
+        host = [m.apply(*p) for p in plans]
+        dev = [m.apply(*p, True) for p in plans]
+        for p, a, b in zip(plans, host, dev):
+            assert b["image_bgr"] is p[0]["image_bgr"]                                     # untouched, not even copied
+            assert b["device_plan"] == (a["image_bgr"].shape[0], a["image_bgr"].shape[1], bool(p[2])) and mapped_hw(b) == mapped_hw(a)
+            assert set(a["gt"]) == set(b["gt"])
+            for k in ("boxes", "classes", "poly_flat", "poly_len"):
+                assert np.array_equal(a["gt"][k], b["gt"][k]), k
+            flips += int(p[2])
+        fh, sh, gh = TrainModel.collate(host)
+        fd, sd, gd = TrainModel.collate(dev)
+        assert fd is None and sd == sh and fh.shape[1:3] == (max(mapped_hw(b)[0] for b in dev), max(mapped_hw(b)[1] for b in dev))
+    assert 6 < flips < 30

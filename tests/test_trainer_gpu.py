@@ -135,7 +135,8 @@ def test_trainer_with_mixed_scales(tmp_path):
     orig = trainer.model.__call__
     import types
     def spy(self, batch, **kw):
-        seen.append(sorted({d["image_bgr"].shape[:2] for d in batch}))
+        from ampis_amd.data import mapped_hw          # the size the network sees (device input path: the resize is deferred to the uploader)
+        seen.append(sorted({mapped_hw(d) for d in batch}))
         return orig(batch, **kw)
     trainer.model.__class__ = type("Spy", (trainer.model.__class__,), {"__call__": spy})
     trainer.train()

@@ -47,8 +47,25 @@ for workers in ((4,) if MULTI else (0, 4)):
         def before_step(self): self.t = time.perf_counter()
         def after_step(self): times.append(time.perf_counter() - self.t)
     tr.register_hooks([Clock()]) if hasattr(tr, "register_hooks") else tr._hooks.append(Clock())
+    # where an iteration goes: waiting for the loader, the forward / backward call, everything else (SGD, scalars, hooks)
+    parts = {"loader_wait": [], "model_call": []}
+    if tr.data_loader is None: tr._build_loader()
+    _it = tr.data_loader
+    class TimedLoader:
+        def __iter__(self): return self
+        def __next__(self):
+            t = time.perf_counter(); b = next(_it); parts["loader_wait"].append(time.perf_counter() - t); return b
+    tr.data_loader = TimedLoader()
+    from ampis_amd.engine import defaults as _D
+    if not hasattr(_D.TrainModel, "_orig_call"):
+        _D.TrainModel._orig_call = _D.TrainModel.__call__
+    def _timed_call(self, *a, **kw):
+        t = time.perf_counter(); r = _D.TrainModel._orig_call(self, *a, **kw); parts["model_call"].append(time.perf_counter() - t); return r
+    _D.TrainModel.__call__ = _timed_call
     tr.train()
-    out[f"NUM_WORKERS={workers}"] = {"ms_per_iter_median": round(float(np.median(times[3:])) * 1e3, 1), "images_per_s": round(B / float(np.median(times[3:])), 1)}
+    out[f"NUM_WORKERS={workers}"] = {"ms_per_iter_median": round(float(np.median(times[3:])) * 1e3, 1), "images_per_s": round(B / float(np.median(times[3:])), 1),
+                                     "loader_wait_ms_median": round(float(np.median(parts["loader_wait"][3:])) * 1e3, 2),
+                                     "model_call_ms_median": round(float(np.median(parts["model_call"][3:])) * 1e3, 2)}
     try:
         st = tr.ctx.rowtab_stats()
         st["hit_rate"] = round(st["hits"] / max(st["hits"] + st["misses"], 1), 4)

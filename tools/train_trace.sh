@@ -5,6 +5,7 @@ OUT=$ROOT/gpurun_out/train_trace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-steps 6 --train-warmup 2 --x101-steps 0 --no-two-pipelines --no-host-inclusive --no-strict > $OUT/log.txt 2>&1
+python3 $ROOT/tools/train_timeline.py $(ls $OUT/*/*kernel_trace.csv | head -1) > $OUT/timeline.txt; cat $OUT/timeline.txt
 python3 - <<PY
 import csv, glob, re, collections
 f = glob.glob("$OUT/*/*kernel_trace.csv")[0]
