@@ -1096,13 +1096,40 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 1 : 2) void conv
 }
 
 
+// The predictor rows a wave tile can need, fetched ahead of the epilogue (conv_split_kernel issues this BEFORE its K loop): a wave tile is 64
+// consecutive GEMM rows = pixels of at most TWO RoIs (196 pixels each), so two class ids, two weight quads per lane and two biases cover it.
+// Before round 4 every one of the 16 row groups of the epilogue walked pred_cls[b] -> pred_w[cls] again -- two dependent global round trips
+// per group, and two more in the final reduction: ~8 us of a 19-us tile (K = 256: 8 K-steps) that nothing hid.
+struct PredictPrefetch {
+    unsigned int b0;
+    f32x4 wp0, wp1;
+    float pb0, pb1;
+};
+__device__ __forceinline__ PredictPrefetch predict_prefetch(const ConvArgs& a, int wave, int lane, int m0) {
+    const int wm = wave >> 2, wn = wave & 3, l15 = lane & 15;
+    const int mw0 = m0 + wm * 64;
+    const unsigned int mf = min((unsigned int)mw0, (unsigned int)(a.M - 1)), ml = min((unsigned int)(mw0 + 63), (unsigned int)(a.M - 1));
+    PredictPrefetch p;
+    p.b0 = fastdiv(mf, a.div_howo_mul, a.div_howo_shr);
+    const unsigned int b1 = fastdiv(ml, a.div_howo_mul, a.div_howo_shr);
+    int c0 = a.pred_cls[p.b0], c1 = a.pred_cls[b1];
+    c0 = (c0 >= 0 && c0 < a.pred_K) ? c0 : 0;
+    c1 = (c1 >= 0 && c1 < a.pred_K) ? c1 : 0;
+    const int co = wn * 64 + l15 * 4;
+    p.wp0 = *reinterpret_cast<const f32x4*>(a.pred_w + (size_t)c0 * 256 + co);
+    p.wp1 = *reinterpret_cast<const f32x4*>(a.pred_w + (size_t)c1 * 256 + co);
+    p.pb0 = a.pred_b[c0];
+    p.pb1 = a.pred_b[c1];
+    return p;
+}
+
 // Epilogue of the fused mask-head tail (out_mode 3).  The GEMM is the ConvTranspose2d 2x2 s2 as a 1x1 convolution to
 // Cout = 4 * 256 channels ordered (tap, co); a 128 x 256 tile is therefore 128 input pixels x ONE tap x all 256 output channels.
 // Per tile row (RoI b, input pixel (oy, ox), tap (ky, kx)): v[co] = relu(acc[co] + bias[co]) is the deconv output at output pixel
 // (2oy + ky, 2ox + kx); the predictor's logit for the RoI's class c is  sum_co v[co] * wp[c][co] + bp[c];  the mask probability its
 // sigmoid.  fp32 products and sums in a fixed order (4 columns per lane, xor tree over the 16 lanes of a row, the 4 N-waves in order):
 // deterministic.  Replaces a 1.28 GB write, its read-back, the 1x1 predictor GEMM and mask_prob_kernel (B = 8, 200 detections).
-__device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0) {
+__device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0, const PredictPrefetch& pf) {
     constexpr int WTM = 64, WTN = 64, SLD = WTN + 4;
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -1125,9 +1152,7 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
         const int rl = it * 4 + lq;                     // row of the wave tile
         const unsigned int m = min((unsigned int)(mw0 + rl), (unsigned int)(a.M - 1));
         const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
-        int cls = a.pred_cls[b];
-        cls = (cls >= 0 && cls < a.pred_K) ? cls : 0;
-        const f32x4 wp = *reinterpret_cast<const f32x4*>(a.pred_w + (size_t)cls * 256 + co);
+        const f32x4 wp = (b == pf.b0) ? pf.wp0 : pf.wp1;         // the RoI's class row, fetched ahead (same values as pred_w[pred_cls[b]])
         const f32x4 v = *reinterpret_cast<const f32x4*>(stage + rl * SLD + l15 * 4);
         float s = 0.f;
 #pragma unroll
@@ -1152,10 +1177,8 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
             const unsigned int rem = (unsigned int)m - b * (unsigned int)(a.Ho * a.Wo);
             const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
             const unsigned int ox = rem - oy * (unsigned int)a.Wo;
-            int cls = a.pred_cls[b];
-            cls = (cls >= 0 && cls < a.pred_K) ? cls : 0;
             float x = __fadd_rn(__fadd_rn(__fadd_rn(red[rl], red[128 + rl]), red[256 + rl]), red[384 + rl]);
-            x = __fadd_rn(x, a.pred_b[cls]);
+            x = __fadd_rn(x, (b == pf.b0) ? pf.pb0 : pf.pb1);
             const float p = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
             a.prob[((size_t)b * 2 * a.Ho + 2 * oy + (tap >> 1)) * (2 * a.Wo) + 2 * ox + (tap & 1)] = p;
         }
@@ -1378,6 +1401,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
 
     stage(0);
     if (a.nsteps > 1) stage(1);
+    // fused mask-head tail only: its predictor rows, requested here -- behind the first two tiles' DMA (the class-id load the row addresses
+    // wait for must not delay the staging; younger loads in the queue only make the ring's counted vmcnt waits stricter, never looser)
+    PredictPrefetch ppf;
+    if constexpr (BM == 128 && BN == 256 && EPI == 3) {
+        if (a.out_mode == 3) ppf = predict_prefetch(a, wave, lane, m0);
+    }
     int cur = 0, nxt = 2;                      // ring positions of the tile being computed / staged
     auto open_step = [&](int step) {
         // tile `step` has landed once all but the youngest tile's requests of this wave are done (LDS-DMA counts in vmcnt, in order);
@@ -1485,7 +1514,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
                 if (scaled_in) acc[i][j][e] *= a.out_scale;      // x arrived as split rows of x * 2^shift (a scaled loss gradient): exact power of two
             }
     if constexpr (BM == 128 && BN == 256 && EPI == 3) {          // the fused tails have an instantiation of their own: no row epilogue, no spills
-        if (a.out_mode == 3) conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0);
+        if (a.out_mode == 3) conv_epilogue_predict(a, acc, lds, wave, lane, m0, n0, ppf);
         else conv_epilogue_rpn(a, acc, lds, wave, lane, m0, n0);
         return;
     }

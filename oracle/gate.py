@@ -197,31 +197,54 @@ def floor_caps(st, floor, factor=FLOOR_FACTOR, sigmas=2.0):
     for k in _FLOOR_COUNTS:
         e = factor * floor[k] * n / nf
         caps[k] = e + sigmas * math.sqrt(max(e, 1.0))
-    caps["max_tie_pixels"] = math.ceil(factor * max(floor["max_tie_pixels"], 1))
-    caps["iou_min"] = 1.0 - factor * (1.0 - floor["iou_min"])
+    # extreme values (most tie pixels in one mask, lowest IoU) cannot be estimated from a floor that itself rests on a handful of tie masks
+    # (the small-image tests measure theirs on 40-120 instances): there the count caps above carry the bound, the maximum gets two pixels
+    # of allowance and the lowest IoU is not compared
+    small = floor["tie_masks"] < 10
+    caps["max_tie_pixels"] = math.ceil(factor * max(floor["max_tie_pixels"], 1)) + (2 if small else 0)
+    caps["iou_min"] = 0.0 if small else 1.0 - factor * (1.0 - floor["iou_min"])
     caps["worst_box_rel"] = factor * floor["worst_box_rel"]
     caps["worst_box"] = max(BOX_TOL, factor * floor["worst_box"])
     return caps
 
 
-def floor_summary(st, floor, factor=FLOOR_FACTOR):
+def as_hip(r):
+    """an oracle result in the shape check_image expects of the product path (masks dense: decode = identity)"""
+    return dict(boxes=r["boxes"].numpy(), scores=r["scores"].numpy(), classes=r["classes"].numpy(), masks=list(r["masks"].numpy()))
+
+
+def floor_of(run, hw, **check_kw):
+    """The floor of a test's OWN inputs: run() is the test's oracle call (returns oracle.maskrcnn.infer's list); it is run as it is and once
+    more with every convolution exact (oracle/exact.py), and the fp32 result is measured against the exact one with the gate itself.
+    Returns (the fp32 results -- so the test does not run the oracle twice --, the merged floor statistics).  hw: (h, w) of the output
+    frame, or a list of them."""
+    from . import exact
+    ref = run()
+    with exact.exact_convs():
+        rex = run()
+    hws = hw if isinstance(hw, list) else [hw] * len(ref)
+    per = [check_image(as_hip(a), b, h, w, lambda m: m, strict=False, **check_kw) for a, b, (h, w) in zip(ref, rex, hws)]
+    return ref, merge(per)
+
+
+def floor_summary(st, floor, factor=FLOOR_FACTOR, sigmas=2.0):
     """both floors side by side: what this run measured against the oracle | what the oracle itself measures against its exact evaluation"""
     n, nf = max(st["instances"], 1), max(floor["instances"], 1)
-    caps = floor_caps(st, floor, factor)
+    caps = floor_caps(st, floor, factor, sigmas)
     cell = lambda k: f"{st[k]} vs {floor[k] * n / nf:.1f} (cap {caps[k]:.1f})"
-    return (f"run vs reference-arithmetic floor scaled to {n} instances [cap = {factor} x floor + 2 sigma]: masks with ties {cell('tie_masks')}, tie px {cell('tie_pixels')}, "
+    return (f"run vs reference-arithmetic floor scaled to {n} instances [cap = {factor} x floor + {sigmas:g} sigma]: masks with ties {cell('tie_masks')}, tie px {cell('tie_pixels')}, "
             f"tie px beyond {PROB_NOISE:.0e} {cell('tie_pixels_beyond_noise')}, masks IoU<0.999 {cell('iou_below')}, boxes >= 1e-3 px {cell('box_rel_used')}, "
             f"most tie px in a mask {st['max_tie_pixels']} vs {floor['max_tie_pixels']} (cap {caps['max_tie_pixels']}), lowest IoU {st['iou_min']:.4f} vs {floor['iou_min']:.4f} "
             f"(cap {caps['iou_min']:.4f}), worst box {st['worst_box']:.2e} vs {floor['worst_box']:.2e} px (cap {caps['worst_box']:.2e}), "
             f"boxes > 333 px {1e6 * st['worst_box_rel']:.2f} vs {1e6 * floor['worst_box_rel']:.2f} ppm (cap {1e6 * caps['worst_box_rel']:.2f})")
 
 
-def assert_floor(st, floor, factor=FLOOR_FACTOR):
+def assert_floor(st, floor, factor=FLOOR_FACTOR, sigmas=2.0):
     """A path noisier than the reference's own arithmetic fails: every relaxation the gate granted (masks with tie pixels, tie pixels beyond the
     fixed probability-noise margin, masks below IoU 0.999 and the lowest IoU, boxes beyond the bare 1e-3 px and their worst relative error)
     must stay within `factor` x what the fp32 oracle itself shows against its exact-convolution evaluation (load_floor)."""
-    caps = floor_caps(st, floor, factor)
-    msg = floor_summary(st, floor, factor)
+    caps = floor_caps(st, floor, factor, sigmas)
+    msg = floor_summary(st, floor, factor, sigmas)
     for k in _FLOOR_COUNTS:
         assert st[k] <= caps[k], f"{k}: {st[k]} > cap {caps[k]:.1f} | {msg}"
     assert st["max_tie_pixels"] <= caps["max_tie_pixels"], msg

@@ -50,7 +50,7 @@ def setup(gpu_ctx):
     model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D)
     model.load_params(np_params)
     out = model.infer(imgs)
-    return dict(model=model, out=out, ref=ref, stages=stages, cfg=cfg, B=B, H=H, W=W, K=K, D=D, imgs=imgs)
+    return dict(model=model, out=out, ref=ref, stages=stages, cfg=cfg, B=B, H=H, W=W, K=K, D=D, imgs=imgs, np_params=np_params)
 
 
 def test_backbone_fpn_taps(setup):
@@ -126,7 +126,10 @@ def test_final_outputs_match_oracle(setup):
     st = gate.merge([gate.check_image(o, r, H, W, lambda m: _decode(m["counts"], H, W)) for o, r in zip(out, ref)])
     print("e2e gate:", gate.summary(st))
     assert st["instances"] > 20 and st["identical"] + st["tie_masks"] == st["instances"]
-    gate.assert_bounds(st, tie_mask_share=0.06, max_tie_pixels=3)
+    # what the gate relaxed, bound to the reference arithmetic's own noise on THESE images (fp32 oracle against its exact-convolution evaluation)
+    from oracle import maskrcnn as O
+    _, floor = gate.floor_of(lambda: O.infer(setup["imgs"], O.to_torch_params(setup["np_params"]), setup["cfg"]), (H, W))
+    print("e2e gate |", gate.assert_floor(st, floor, sigmas=3.0))
 
 
 def test_mask_prob_tap(setup):

