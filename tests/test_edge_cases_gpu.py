@@ -32,7 +32,7 @@ def _match(out, ref, h, w, floor=None):
     print("edge-case gate:", gate.summary(st))
     assert st["instances"] > 5, st
     if floor is not None:
-        print("edge-case gate |", gate.assert_floor(st, floor, sigmas=3.0))
+        print("edge-case gate |", gate.assert_floor(st, floor, sigmas=3.0, floor_sigmas=2.5))
     else:
         gate.assert_bounds(st, tie_mask_share=0.12, max_tie_pixels=4)
     return st

@@ -46,7 +46,7 @@ def test_predictor_matches_oracle_with_resize(tmp_path):
     st = gate.check_image(hip, ref, 240, 300, lambda m: rle.decode(m).astype(bool))
     print("predictor gate:", gate.summary(st))
     assert st["instances"] > 5
-    print("predictor gate |", gate.assert_floor(st, floor, sigmas=3.0))      # (30 instances pasted into an upscaled frame: many single-pixel ties, in the oracle's own noise too)
+    print("predictor gate |", gate.assert_floor(st, floor, sigmas=3.0, floor_sigmas=2.5))      # (30 instances pasted into an upscaled frame: many single-pixel ties, in the oracle's own noise too)
 
 
 def test_predictor_refuses_cpu_device():

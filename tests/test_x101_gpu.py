@@ -26,7 +26,7 @@ def setup(gpu_ctx):
     model = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=D, pixel_std=std, arch="X101")
     model.load_params(np_params)
     out = model.infer(imgs)
-    yield dict(model=model, out=out, ref=ref, stages=stages, H=H, W=W, params=np_params)
+    yield dict(model=model, out=out, ref=ref, stages=stages, H=H, W=W, params=np_params, np_params=np_params, imgs=imgs, cfg=cfg)
     model.close()
 
 
@@ -177,7 +177,7 @@ def test_r101_inference_and_training_step(gpu_ctx):
     st = gate.merge([gate.check_image(o, r, H, W, lambda mk: _decode(mk["counts"], H, W)) for o, r in zip(out, ref)])
     print("R101 gate:", gate.summary(st))
     assert st["instances"] > 60
-    print("R101 gate |", gate.assert_floor(st, floor, sigmas=3.0))      # bound to the oracle's own noise on these images (33 blocks amplify it)
+    print("R101 gate |", gate.assert_floor(st, floor, sigmas=3.0, floor_sigmas=2.5))      # bound to the oracle's own noise on these images (33 blocks amplify it)
     # one training step runs and produces finite, sensible losses and gradients for a res4.22 weight
     timgs, gts = synth.batch(B, H, W, first_index=40)
     L = m.forward_losses(timgs, gts, seed=1, backward=True)
