@@ -174,6 +174,7 @@ def _declare(L):
         "amp_mask_target_loss": ([vp, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp], i),
         "amp_grouped_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),
         "amp_conv2d_grouped_wgrad": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp], i),
+        "amp_conv2d_grouped_wgrad_fmt": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, i, i], i),
         "amp_group_dgrad_weights": ([vp, vp, vp, i, i, i, vp], i),
         "amp_sigmoid_focal_loss": ([vp, C.c_longlong, i, vp, vp, f, f, f, vp, vp, i, vp], i),
         "amp_mask_targets_bitmask": ([vp, i, vp, vp, vp, vp, vp, vp, C.c_size_t, i, vp, vp], i),

@@ -21,7 +21,17 @@ struct GWArgs {
     int rows_per_slice;   // output rows (b, oy) per slice
     int nslices;
     int diag_only;        // <= 32 channels per group: the two off-diagonal 32 x 32 quadrants of a tile hold no in-group pair -- two waves, not four
+    int x_split;          // x rows are in the split hi|lo' row format (the native trunk of a training step): decoded on the load, hi + lo' * 2^-11 (exact)
+    int dy_split;         // dy rows likewise, holding dy * 2^dy_shift (the scaled split gradient chain): decoded and scaled back (exact)
+    float dy_unscale;     // 2^-dy_shift
 };
+
+typedef _Float16 f16;
+// value of channel c of a split row (per 32 channels: 64 B of hi halves, then 64 B of lo' halves)
+__device__ __forceinline__ float split_at(const float* row, int c) {
+    const f16* h = reinterpret_cast<const f16*>(row) + ((c >> 5) << 6) + (c & 31);
+    return __fadd_rn((float)h[0], __fmul_rn((float)h[32], 1.0f / 2048.0f));
+}
 
 // grid: (C/64) * KH*KW * nslices workgroups of 256 (128 with diag_only) threads; wave w computes the 32 x 32 quadrant (co half w & 1, ci half
 // w >> 1), or the diagonal quadrant w when the groups are at most 32 channels wide (the reduce pass never reads the other two)
@@ -53,8 +63,11 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
                 const int ox = ox0 + 2 * u + k;
                 const int ix = ox * a.stride + kx - a.pad;
                 const bool ok = ox < a.Wo;
-                av[u] = ok ? dyr[(size_t)ox * a.C] : 0.f;
-                bv[u] = (ok && ix >= 0 && ix < a.W) ? xr[(size_t)ix * a.C] : 0.f;
+                const bool okx = ok && ix >= 0 && ix < a.W;
+                if (a.dy_split) av[u] = ok ? __fmul_rn(split_at(a.dy + ((size_t)row * a.Wo + ox) * a.C, co), a.dy_unscale) : 0.f;
+                else av[u] = ok ? dyr[(size_t)ox * a.C] : 0.f;
+                if (a.x_split) bv[u] = okx ? split_at(a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.C, ci) : 0.f;
+                else bv[u] = okx ? xr[(size_t)ix * a.C] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
@@ -114,12 +127,18 @@ size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d) {
 
 int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
                              float* scratch, float* grad_win) {
-    AMP_REQUIRE(ctx && d && x && dy && scratch && grad_win && groups > 1, "amp_conv2d_grouped_wgrad: bad argument");
+    return amp_conv2d_grouped_wgrad_fmt(ctx, d, groups, x, dy, scale, scratch, grad_win, 0, 0);
+}
+
+int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
+                                 float* scratch, float* grad_win, int fmt, int dy_shift) {
+    AMP_REQUIRE(ctx && d && x && dy && scratch && grad_win && groups > 1 && fmt >= 0 && fmt <= 3 && dy_shift >= 0 && dy_shift <= 24, "amp_conv2d_grouped_wgrad: bad argument");
     AMP_REQUIRE(d->Cin == d->Cout && d->Cin % 64 == 0 && d->Cin % groups == 0, "amp_conv2d_grouped_wgrad: needs Cin == Cout, a multiple of 64 and of groups");
     const int cpg = d->Cin / groups;
     AMP_REQUIRE(cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64, "amp_conv2d_grouped_wgrad: %d channels per group (8/16/32/64 supported)", cpg);
     GWArgs a;
     a.x = x; a.dy = dy; a.partial = scratch;
+    a.x_split = fmt & 1; a.dy_split = (fmt >> 1) & 1; a.dy_unscale = ldexpf(1.0f, -dy_shift);
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->Cin; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
     a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;

@@ -102,6 +102,7 @@ struct amp_model {
     float* varena = nullptr;            // SGD momentum buffers, same offsets
     bool saving = false;                // run_trunk keeps every activation the backward pass needs
     bool acts_split = false;            // ... and kept them in the split row format (training on the native trunk, AMP_CONV_F16X3)
+    bool gs_chain_ok = false;           // ... and the backbone's backward chain can run on scaled split gradients (dense 3x3, stride in conv1: R50 / R101)
     bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
     bool mask_tail_split = false;       // ... and fcn4's output (the deconv's input): the deconv and its three gradient launches on pre-split operands
     struct BlockAct { std::string key; float *x_in, *t1, *t2, *sc, *out; int in_h, in_w, oh, ow, cin, mid, cout, stride, stage; bool has_sc; };
@@ -311,18 +312,25 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         if (!native) return false;
         auto it = m->conv.find(key);
         static const bool no_grouped_split = getenv("AMP_NO_GROUPED_SPLIT") != nullptr;      // EXPERIMENT switch: ResNeXt conv2 takes fp32 input
-        return it != m->conv.end() && it->second.w_split != nullptr && (it->second.groups == 1 || (!m->saving && !no_grouped_split)) && it->second.cin % 32 == 0;
+        // (round 4: a training step of a grouped backbone keeps the split format through conv2 too -- grouped_wgrad_kernel decodes split x)
+        static const bool no_grouped_train_split = getenv("AMP_NO_GROUPED_TRAIN_SPLIT") != nullptr;      // EXPERIMENT switch: round 3's fp32 trunk for ResNeXt training
+        const bool grouped_ok = m->saving ? !no_grouped_train_split : !no_grouped_split;
+        return it != m->conv.end() && it->second.w_split != nullptr && (it->second.groups == 1 || grouped_ok) && it->second.cin % 32 == 0;
     };
     bool native_all = native;          // every dense conv of backbone / FPN / RPN can read the format
     if (native)
         for (auto& kv : m->conv) {
             const std::string& k = kv.first;
             const bool trunk = k.rfind("backbone.", 0) == 0 || k.rfind("proposal_generator.", 0) == 0;
-            if (trunk && k != "backbone.bottom_up.stem.conv1" && (kv.second.groups != 1 ? m->saving : !reads_split(k))) native_all = false;
+            if (trunk && k != "backbone.bottom_up.stem.conv1" && !reads_split(k)) native_all = false;
         }
-    if (m->saving && !c.stride_in_1x1) native_all = false;   // the split-gradient chain of the backward pass assumes the stride in conv1
     if (m->saving && !native_all) native = false;     // (reads_split follows: everything fp32)
     m->acts_split = m->saving && native_all;
+    // the split-GRADIENT chain of the backward pass assumes dense 3x3 layers with the block's stride in conv1; a ResNeXt trunk keeps its saved
+    // activations split all the same (forward on the ring kernels, weight gradients with split x, FPN / RPN / heads as for R50) and runs
+    // the blocks' backward on fp32 gradients
+    m->gs_chain_ok = m->acts_split && c.stride_in_1x1;
+    for (auto& kv : m->conv) if (kv.second.groups != 1) m->gs_chain_ok = false;
     const int SPL = 5;                 // tap dtype of a split tensor
     auto FMT = [](bool x_split, bool y_split, bool res_split) { return (x_split ? 1 : 0) | (y_split ? 2 : 0) | (res_split ? 4 : 0); };
 
@@ -1155,7 +1163,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // convolution stages both operands by LDS-DMA on the ring kernel (no split, no scaling: the scale rides through the linear chain),
     // residual and ReLU mask come in the split format, and the weight-gradient kernel passes the halves through (xfmt 3).
     static const bool no_gs = getenv("AMP_NO_SPLIT_GRADS") != nullptr;      // EXPERIMENT switch
-    const bool GS = AS && !no_gs && ctx->conv_mode == AMP_CONV_F16X3;
+    const bool GS = AS && !no_gs && ctx->conv_mode == AMP_CONV_F16X3 && m->gs_chain_ok;
     auto dgrad_s = [&](const ConvW& cw, const float* dy_s, int B_, int Hy, int Wy, int fwd_pad, const float* res_s, const float* mask_s, float* dx_s) -> int {
         AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
         const float* wsp = dgrad_wsplit(cw, B_, Hy, Wy);
@@ -1340,6 +1348,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                 AMP_ALLOC(r3, float, (size_t)B * hh * ww * kOut[s_]);
                 AMP_ALLOC(r4, float, (size_t)B * hh * ww * kOut[s_]);
                 (void)r1; (void)r2; (void)r3; (void)r4;
+                if (m->cfg.num_groups > 1) {     // ResNeXt on the split trunk: conv2's input decoded to fp32 for the grouped weight gradient (at the block's INPUT resolution in its first block)
+                    const int up = (b_ == 0 && !c.stride_in_1x1) ? 2 : 1;
+                    AMP_ALLOC(r5, float, (size_t)B * (hh * up) * (ww * up) * m->mid[s_]);
+                    (void)r5;
+                }
             }
         }
     }
@@ -1378,12 +1391,21 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                 dw.B = B; dw.H = h1; dw.W = w1; dw.Cin = ba.mid; dw.Cout = ba.mid; dw.KH = 3; dw.KW = 3; dw.stride = st2; dw.pad = 1; dw.relu = 0; dw.res_mode = 0; dw.out_mode = 0;
                 AMP_REQUIRE(amp_grouped_wgrad_scratch_floats(&dw) <= WG_SCRATCH && (size_t)ba.mid * 9 * 64 <= WT_SCRATCH, "backward: grouped scratch too small");
                 AMP_TRY(amp::wgrad_async_join(ctx));      // the grouped kernels use wg_scratch on the main stream: no reduction may still be reading it
-                AMP_TRY(amp_conv2d_grouped_wgrad(ctx, &dw, c2.groups, ba.t1, d_t2, c2.scale, wg_scratch, GW(c2)));
+                // t1 is split on the native trunk.  grouped_wgrad_kernel can decode it on the load (amp_conv2d_grouped_wgrad_fmt, fmt 1), but its
+                // loop is bound by load issue and the two 2-byte loads + converts per value DOUBLE its time (6.6 -> 13.0 ms per X-101 step at
+                // B = 4 / 1024^2, measured); one decoding pass into a scratch (read 4 B, write 4 B per value: ~0.05 ms per layer) and the fp32 form is cheaper
+                const float* t1f = ba.t1;
+                if (AS) {
+                    AMP_ALLOC(t1_dec, float, (size_t)B * h1 * w1 * ba.mid);
+                    AMP_TRY(amp_unsplit_rows(ctx, ba.t1, (long long)B * h1 * w1, ba.mid, t1_dec));
+                    t1f = t1_dec;
+                }
+                AMP_TRY(amp_conv2d_grouped_wgrad(ctx, &dw, c2.groups, t1f, d_t2, c2.scale, wg_scratch, GW(c2)));
                 AMP_TRY(amp_group_dgrad_weights(ctx, c2.w, c2.scale, ba.mid, 3, 3, wt_scratch));
                 amp_conv_desc dd = dw;
                 dd.stride = 1;
                 dys_of = nullptr;
-                return amp::conv_run(ctx, &dd, c2.groups, dy2, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, ba.t1, d_t1, 16, 0);
+                return amp::conv_run(ctx, &dd, c2.groups, dy2, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, ba.t1, d_t1, 16, AS ? 8 : 0);      // (the ReLU mask t1 likewise)
             }
             AMP_TRY(wgrad(c2, ba.t1, B, h1, w1, st2, 1, d_t2, false, false, AS));
             return dgrad(c2, dy2, B, h1, w1, 1, nullptr, ba.t1, d_t1, AS);

@@ -144,6 +144,10 @@ int amp_conv2d_grouped_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups
 size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d);
 int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
                              float* scratch, float* grad_win);
+/* The same with operands in the split hi|lo' row format (same bytes as fp32): fmt bit 0: x, bit 1: dy holding dy * 2^dy_shift (the scaled split
+ * gradient chain of a training step).  Decoded on the load (exact); same sums in the same order as the fp32 form on the decoded tensors. */
+int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
+                                 float* scratch, float* grad_win, int fmt, int dy_shift);
 int amp_group_dgrad_weights(amp_ctx* ctx, const float* w_win, const float* scale, int C, int KH, int KW, float* wt_win);
 /* same, with an optional mask tensor indexed like y: y = mask > 0 ? y : 0 (applied last; the ReLU backward of a data gradient) */
 int amp_conv2d_nhwc_ex(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
