@@ -22,8 +22,7 @@ struct GWArgs {
     int nslices;
     int diag_only;        // <= 32 channels per group: the two off-diagonal 32 x 32 quadrants of a tile hold no in-group pair -- two waves, not four
     int x_split;          // x rows are in the split hi|lo' row format (the native trunk of a training step): decoded on the load, hi + lo' * 2^-11 (exact)
-    int dy_split;         // dy rows likewise, holding dy * 2^dy_shift (the scaled split gradient chain): decoded and scaled back (exact)
-    float dy_unscale;     // 2^-dy_shift
+    int dy_split;         // dy rows likewise (a 2^dy_shift riding on dy, split or fp32, is undone by the reduce pass: exact, one multiply per weight)
 };
 
 typedef _Float16 f16;
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
                 const int ix = ox * a.stride + kx - a.pad;
                 const bool ok = ox < a.Wo;
                 const bool okx = ok && ix >= 0 && ix < a.W;
-                if (a.dy_split) av[u] = ok ? __fmul_rn(split_at(a.dy + ((size_t)row * a.Wo + ox) * a.C, co), a.dy_unscale) : 0.f;
+                if (a.dy_split) av[u] = ok ? split_at(a.dy + ((size_t)row * a.Wo + ox) * a.C, co) : 0.f;
                 else av[u] = ok ? dyr[(size_t)ox * a.C] : 0.f;
                 if (a.x_split) bv[u] = okx ? split_at(a.x + (((size_t)b * a.H + iy) * a.W + ix) * a.C, ci) : 0.f;
                 else bv[u] = okx ? xr[(size_t)ix * a.C] : 0.f;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
 }
 
 // grad[co][ky][kx][slot] = scale[co] * sum over slices (in slice order) of the partials, zero outside the group of co
-__global__ void grouped_wgrad_reduce_kernel(const float* partial, const float* scale, float* grad, int C, int ntaps, int nslices, int cpg) {
+__global__ void grouped_wgrad_reduce_kernel(const float* partial, const float* scale, float* grad, int C, int ntaps, int nslices, int cpg, float out_scale) {
     const size_t total = (size_t)C * ntaps * 64;
     const int ntiles = C >> 6;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -94,6 +93,7 @@ __global__ void grouped_wgrad_reduce_kernel(const float* partial, const float* s
         float s = 0.f;
         if (cl / cpg == slot / cpg) {
             for (int sl = 0; sl < nslices; ++sl) s = __fadd_rn(s, partial[((((size_t)sl * ntiles + tile) * ntaps + tap) << 12) + (cl << 6) + slot]);
+            s = __fmul_rn(s, out_scale);                 // 2^-dy_shift: exact
             if (scale) s = __fmul_rn(s, scale[co]);
         }
         grad[idx] = s;
@@ -138,7 +138,7 @@ int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int group
     AMP_REQUIRE(cpg == 8 || cpg == 16 || cpg == 32 || cpg == 64, "amp_conv2d_grouped_wgrad: %d channels per group (8/16/32/64 supported)", cpg);
     GWArgs a;
     a.x = x; a.dy = dy; a.partial = scratch;
-    a.x_split = fmt & 1; a.dy_split = (fmt >> 1) & 1; a.dy_unscale = ldexpf(1.0f, -dy_shift);
+    a.x_split = fmt & 1; a.dy_split = (fmt >> 1) & 1;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->Cin; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
     a.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
     a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
@@ -153,7 +153,7 @@ int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int group
     hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(a.diag_only ? 128 : 256), 0, ctx->stream, a);
     const size_t total = (size_t)a.C * a.KH * a.KW * 64;
     hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
-                       scratch, scale, grad_win, a.C, a.KH * a.KW, nslices, cpg);
+                       scratch, scale, grad_win, a.C, a.KH * a.KW, nslices, cpg, ldexpf(1.0f, -dy_shift));
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -102,6 +102,7 @@ struct amp_model {
     float* varena = nullptr;            // SGD momentum buffers, same offsets
     bool saving = false;                // run_trunk keeps every activation the backward pass needs
     bool acts_split = false;            // ... and kept them in the split row format (training on the native trunk, AMP_CONV_F16X3)
+    int last_chain = -1;                // the last backward pass's backbone chain: 0 fp32 storage, 1 split activations + fp32 gradients, 2 scaled split gradients (R50 / R101), 3 the same for ResNeXt blocks
     bool gs_chain_ok = false;           // ... and the backbone's backward chain can run on scaled split gradients (dense 3x3, stride in conv1: R50 / R101)
     bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
     bool mask_tail_split = false;       // ... and fcn4's output (the deconv's input): the deconv and its three gradient launches on pre-split operands
@@ -140,6 +141,9 @@ static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN
 extern "C" void amp_debug_set_split_chain(int on) { g_split_chain = on; }
 static int g_mask_tail_split = -1;   // -1: from the environment (AMP_NO_MASK_TAIL_SPLIT), 0 / 1: set by amp_debug_set_mask_tail_split (tests)
 extern "C" void amp_debug_set_mask_tail_split(int on) { g_mask_tail_split = on; }
+static int g_gx = -1;                // -1: from the environment (AMP_NO_GX), 0 / 1: ResNeXt blocks on fp32 gradients / on the scaled split chain (tests)
+extern "C" void amp_debug_set_gx(int on) { g_gx = on; }
+extern "C" int amp_debug_last_backward_chain(amp_model* m) { return m ? m->last_chain : -1; }
 
 namespace {
 
@@ -1164,6 +1168,9 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     // residual and ReLU mask come in the split format, and the weight-gradient kernel passes the halves through (xfmt 3).
     static const bool no_gs = getenv("AMP_NO_SPLIT_GRADS") != nullptr;      // EXPERIMENT switch
     const bool GS = AS && !no_gs && ctx->conv_mode == AMP_CONV_F16X3 && m->gs_chain_ok;
+    static const bool no_gx = getenv("AMP_NO_GX") != nullptr;      // EXPERIMENT switch: ResNeXt blocks on fp32 gradients (split activations only)
+    const bool GX = AS && !GS && !no_gs && (g_gx < 0 ? !no_gx : g_gx != 0) && ctx->conv_mode == AMP_CONV_F16X3 && c.num_groups > 1 && !c.stride_in_1x1;
+    if (!dry) m->last_chain = !AS ? 0 : (GS ? 2 : (GX ? 3 : 1));      // which backbone chain ran (amp_debug_last_backward_chain)
     auto dgrad_s = [&](const ConvW& cw, const float* dy_s, int B_, int Hy, int Wy, int fwd_pad, const float* res_s, const float* mask_s, float* dx_s) -> int {
         AMP_REQUIRE((size_t)cw.cout * cw.kh * cw.kw * cw.cin <= WT_SCRATCH, "backward: weight-transform scratch too small");
         const float* wsp = dgrad_wsplit(cw, B_, Hy, Wy);
@@ -1351,7 +1358,8 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                 if (m->cfg.num_groups > 1) {     // ResNeXt on the split trunk: conv2's input decoded to fp32 for the grouped weight gradient (at the block's INPUT resolution in its first block)
                     const int up = (b_ == 0 && !c.stride_in_1x1) ? 2 : 1;
                     AMP_ALLOC(r5, float, (size_t)B * (hh * up) * (ww * up) * m->mid[s_]);
-                    (void)r5;
+                    AMP_ALLOC(r6, float, (size_t)B * hh * ww * m->mid[s_]);          // ... and its output gradient (the scaled split chain)
+                    (void)r5; (void)r6;
                 }
             }
         }
@@ -1438,6 +1446,62 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                     float* dprev = d_res[ba.stage - 1];             // fp32: already holds the FPN lateral's share
                     if (ba.stride == 2) AMP_TRY(amp_subsample2_bwd_split(ctx, tmp_in, dprev, B, ba.in_h, ba.in_w, ba.cin, 16));
                     else { amp::set_error("backward: stride-1 projection block is not expected here"); return AMP_ERR_STATE; }
+                }
+            } else {
+                AMP_ALLOC(d_in, float, out_elems);
+                const bool fuse = bi > 0 && m->blocks[bi - 1].out == ba.x_in;
+                AMP_TRY(dgrad_s(c1, d_t1, B, ba.oh, ba.ow, 0, dcur, fuse ? ba.x_in : nullptr, d_in));
+                dcur = d_in;
+                dcur_masked = fuse;
+            }
+        } else if (GX) {
+            // ResNeXt (grouped conv2, the block's stride in it) on the scaled split gradient chain: conv3 / conv1 / shortcut exactly as above;
+            // conv2's weight gradient on decoded operands (the 2^16 undone by its reduce pass), its data gradient = the grouped FORWARD kernel on
+            // transposed windows, split in / split out with t1 as the ReLU mask (a stride-2 layer: dy's rows scattered into a zeroed map first);
+            // in a stage's first block conv1's data gradient lives at the INPUT resolution and joins the fp32 stage-exit map there
+            if (last_of_stage) {
+                AMP_ALLOC(dcur_s, float, out_elems);
+                AMP_TRY(amp_relu_mask_to_split(ctx, dcur, ba.out, dcur_s, out_elems, ba.cout, 16));
+                dcur = dcur_s;
+            } else if (!dcur_masked) {
+                amp::set_error("backward: a block whose input is not the previous block's output is not expected inside a stage");
+                return AMP_ERR_STATE;
+            }
+            dcur_masked = false;
+            AMP_TRY(wgrad(c3, ba.t2, B, ba.oh, ba.ow, 1, 0, dcur, false, false, 3));
+            AMP_TRY(dgrad_s(c3, dcur, B, ba.oh, ba.ow, 0, nullptr, ba.t2, d_t2));
+            {
+                amp_conv_desc dw;
+                dw.B = B; dw.H = h1; dw.W = w1; dw.Cin = ba.mid; dw.Cout = ba.mid; dw.KH = 3; dw.KW = 3; dw.stride = st2; dw.pad = 1; dw.relu = 0; dw.res_mode = 0; dw.out_mode = 0;
+                AMP_REQUIRE(amp_grouped_wgrad_scratch_floats(&dw) <= WG_SCRATCH && (size_t)ba.mid * 9 * 64 <= WT_SCRATCH, "backward: grouped scratch too small");
+                AMP_REQUIRE(st2 == 1 || st2 == 2, "backward: conv2 with stride %d", st2);
+                AMP_ALLOC(t1_dec, float, (size_t)B * h1 * w1 * ba.mid);
+                AMP_ALLOC(dt2_dec, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+                AMP_TRY(amp_unsplit_rows(ctx, ba.t1, (long long)B * h1 * w1, ba.mid, t1_dec));
+                AMP_TRY(amp_unsplit_rows(ctx, d_t2, (long long)B * ba.oh * ba.ow, ba.mid, dt2_dec));          // = d(t2) * 2^16 in fp32
+                AMP_TRY(amp::wgrad_async_join(ctx));      // the grouped kernels use wg_scratch on the main stream
+                AMP_TRY(amp_conv2d_grouped_wgrad_fmt(ctx, &dw, c2.groups, t1_dec, dt2_dec, c2.scale, wg_scratch, GW(c2), 0, 16));
+                AMP_TRY(amp_group_dgrad_weights(ctx, c2.w, c2.scale, ba.mid, 3, 3, wt_scratch));
+                const float* dy2 = d_t2;
+                if (st2 == 2) { AMP_TRY(amp_scatter2_rows(ctx, d_t2, d_t2_up, B, h1, w1, ba.mid)); dy2 = d_t2_up; }
+                amp_conv_desc dd = dw;
+                dd.stride = 1;
+                dys_of = nullptr;
+                AMP_TRY(amp::conv_run(ctx, &dd, c2.groups, dy2, wt_scratch, nullptr, 0, nullptr, nullptr, nullptr, ba.t1, d_t1, 0, 1 | 2 | 8));
+            }
+            AMP_TRY(wgrad(c1, ba.x_in, B, ba.in_h, ba.in_w, st1, 0, d_t1, false, false, 3));
+            if (ba.has_sc) {
+                const ConvW& cs = CONV((ba.key + ".shortcut").c_str());
+                AMP_TRY(wgrad(cs, ba.x_in, B, ba.in_h, ba.in_w, ba.stride, 0, dcur, false, false, 3));
+                if (need_dx) {
+                    if (ba.stride != 2 || st1 != 1) { amp::set_error("backward: a ResNeXt projection block with stride %d / %d is not expected here", ba.stride, st1); return AMP_ERR_STATE; }
+                    float* dprev = d_res[ba.stage - 1];             // fp32, input resolution: already holds the FPN lateral's share
+                    AMP_ALLOC(tmp_sc, float, (size_t)B * ba.oh * ba.ow * ba.cin);
+                    AMP_ALLOC(tmp_full, float, (size_t)B * ba.in_h * ba.in_w * ba.cin);
+                    AMP_TRY(dgrad_s(cs, dcur, B, ba.oh, ba.ow, 0, nullptr, nullptr, tmp_sc));
+                    AMP_TRY(dgrad_s(c1, d_t1, B, h1, w1, 0, nullptr, nullptr, tmp_full));
+                    AMP_TRY(amp_accumulate_split(ctx, tmp_full, dprev, (long long)B * ba.in_h * ba.in_w, ba.cin, 16));
+                    AMP_TRY(amp_subsample2_bwd_split(ctx, tmp_sc, dprev, B, ba.in_h, ba.in_w, ba.cin, 16));
                 }
             } else {
                 AMP_ALLOC(d_in, float, out_elems);

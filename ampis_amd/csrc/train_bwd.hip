@@ -422,6 +422,38 @@ __global__ void subsample2_bwd_split_kernel(const float* __restrict__ dy, float*
     }
 }
 
+// dx[row][:] += unscale(dy[row][:]) with dy in scaled split rows, same resolution
+__global__ void accumulate_split_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t rows, int C4, float inv_scale) {
+    const size_t total = rows * C4;
+    f32x4* o = reinterpret_cast<f32x4*>(dx);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const size_t row = i / C4;
+        const char* sb = reinterpret_cast<const char*>(dy + row * (size_t)C4 * 4) + (size_t)(c >> 5) * 128 + (size_t)(c & 31) * 2;
+        const rm_f16x4 sh = *reinterpret_cast<const rm_f16x4*>(sb);
+        const rm_f16x4 sl = *reinterpret_cast<const rm_f16x4*>(sb + 64);
+        f32x4 v = o[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = __fadd_rn(v[q], ((float)sh[q] + (float)sl[q] * (1.0f / 2048.0f)) * inv_scale);
+        o[i] = v;
+    }
+}
+
+// up[b, 2y, 2x, :] = src[b, y, x, :], raw 16-byte chunks (the rest of `up` was zeroed by the caller)
+__global__ void scatter2_rows_kernel(const float* __restrict__ src, float* __restrict__ up, int B, int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    const f32x4* s = reinterpret_cast<const f32x4*>(src);
+    f32x4* o = reinterpret_cast<f32x4*>(up);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t t = i / C4;
+        const int x = (int)(t % Wo); t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        o[((size_t)(b * H + 2 * y) * W + 2 * x) * C4 + c4] = s[i];
+    }
+}
+
 // dx[p][c] = (sum_k dl[p][k] * w[k][c]) * (act[p][c] > 0)     (mask predictor 1x1 conv, K <= 8 classes padded to ld)
 __global__ void small_k_dgrad_kernel(const float* __restrict__ dl, int ld, int K, const float* __restrict__ w, int C,
                                      const float* __restrict__ act, float* __restrict__ dx, size_t npix) {
@@ -719,6 +751,22 @@ int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     hipLaunchKernelGGL(subsample2_bwd_split_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, ctx->stream, dy_split, dx, B, H, W, C / 4, Ho, Wo,
                        ldexpf(1.0f, -shift));
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_accumulate_split(amp_ctx* ctx, const float* dy_split, float* dx, long long rows, int C, int shift) {
+    AMP_REQUIRE(ctx && dy_split && dx && rows > 0 && C % 32 == 0 && shift >= 0 && shift <= 24, "amp_accumulate_split: bad argument");
+    hipLaunchKernelGGL(accumulate_split_kernel, dim3(grid_for((size_t)rows * (C / 4))), dim3(256), 0, ctx->stream, dy_split, dx, (size_t)rows, C / 4, ldexpf(1.0f, -shift));
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+int amp_scatter2_rows(amp_ctx* ctx, const float* src, float* up, int B, int H, int W, int C) {
+    AMP_REQUIRE(ctx && src && up && B > 0 && H > 0 && W > 0 && C % 4 == 0, "amp_scatter2_rows: bad argument");
+    AMP_HIP_CHECK(hipMemsetAsync(up, 0, (size_t)B * H * W * C * 4, ctx->stream));
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(scatter2_rows_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, ctx->stream, src, up, B, H, W, C / 4, Ho, Wo);
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
 }

@@ -144,8 +144,8 @@ int amp_conv2d_grouped_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups
 size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d);
 int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
                              float* scratch, float* grad_win);
-/* The same with operands in the split hi|lo' row format (same bytes as fp32): fmt bit 0: x, bit 1: dy holding dy * 2^dy_shift (the scaled split
- * gradient chain of a training step).  Decoded on the load (exact); same sums in the same order as the fp32 form on the decoded tensors. */
+/* The same with operands in the split hi|lo' row format (same bytes as fp32): fmt bit 0: x, bit 1: dy; decoded on the load (exact).  dy -- split
+ * or fp32 -- may hold dy * 2^dy_shift (the scaled gradient chain of a training step): the reduce pass multiplies the sums by 2^-dy_shift. */
 int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
                                  float* scratch, float* grad_win, int fmt, int dy_shift);
 int amp_group_dgrad_weights(amp_ctx* ctx, const float* w_win, const float* scale, int C, int KH, int KW, float* wt_win);
@@ -207,7 +207,13 @@ int amp_relu_mask_split(amp_ctx* ctx, float* g, const float* act_split, size_t n
 /* Scaled split gradients (the backbone's backward pass on the ring kernel): out = split(2^shift * (act > 0 ? g : 0)), and the
  * stride-2 scatter-add back into an fp32 gradient: dx[b,2y,2x,:] += 2^-shift * decode(dy_split[b,y,x,:]). */
 int amp_relu_mask_to_split(amp_ctx* ctx, const float* g, const float* act_split, float* out_split, size_t n, int C, int shift);
-int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int B, int H, int W, int C, int shift);                                  /* g *= (act > 0) */
+int amp_subsample2_bwd_split(amp_ctx* ctx, const float* dy_split, float* dx, int B, int H, int W, int C, int shift);
+/* dx (fp32, same resolution) += decode(dy_split) * 2^-shift: a scaled split gradient joins an fp32 gradient map (ResNeXt first blocks, where
+ * conv1's data gradient lives at the block's INPUT resolution). */
+int amp_accumulate_split(amp_ctx* ctx, const float* dy_split, float* dx, long long rows, int C, int shift);
+/* up[b, 2y, 2x, :] = src[b, y, x, :] as raw 16-byte chunks (split rows stay split rows), every other pixel of `up` zero: the input of the stride-1
+ * data gradient of a stride-2 convolution whose gradient arrives in the split format.  up: [B, H, W, C], src: [B, ceil(H/2), ceil(W/2), C]. */
+int amp_scatter2_rows(amp_ctx* ctx, const float* src, float* up, int B, int H, int W, int C);                                  /* g *= (act > 0) */
 int amp_small_k_dgrad(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx, size_t npix);
 /* The same product for dl rows of 16 floats (K <= 16), C % 32 == 0 and act in the split row format, leaving dx * 2^shift as split rows (the
  * dy operand of the ring kernels) and colsum_out[c] (= or +=) the sum over the pixels of dx[.][c] (the bias gradient of the layer that

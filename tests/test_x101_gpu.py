@@ -130,16 +130,29 @@ def test_x101_training_step_against_autograd(gpu_ctx):
     sum(ref.values()).backward()
     m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), arch="X101", train=True, max_gt=512, max_poly_doubles=512 * 64)
     m.load_params(npp)
-    got = m.forward_losses(imgs, gts, seed=3, backward=True)
-    for k, v in ref.items():
-        assert got[k] == pytest.approx(float(v), rel=3e-4, abs=1e-6), (k, got[k], float(v))
-    bad = []
-    for name in names:
-        g, r = m.get_tensor(name, grad=True), tp[name].grad.numpy()
-        err = float(np.abs(g - r).max()) / max(float(np.abs(r).max()), 1e-8)
-        if err > 3e-3:
-            bad.append((round(err, 5), name))
-    assert not bad, f"{len(bad)} of {len(names)} tensors off: {sorted(bad, reverse=True)[:8]}"
+    from ampis_amd import _lib
+    # round 4: the default is the scaled split gradient chain for ResNeXt blocks (chain 3); the fp32-gradient chain on split activations (1)
+    # is held to the same bar, and the two agree with each other far closer than either does with autograd
+    grads = {}
+    for gx, chain in ((1, 3), (0, 1)):
+        _lib.lib().amp_debug_set_gx(gx)
+        try:
+            got = m.forward_losses(imgs, gts, seed=3, backward=True)
+        finally:
+            _lib.lib().amp_debug_set_gx(-1)
+        assert _lib.lib().amp_debug_last_backward_chain(m._h) == chain, (gx, _lib.lib().amp_debug_last_backward_chain(m._h))
+        for k, v in ref.items():
+            assert got[k] == pytest.approx(float(v), rel=3e-4, abs=1e-6), (k, got[k], float(v))
+        bad = []
+        for name in names:
+            g, r = m.get_tensor(name, grad=True), tp[name].grad.numpy()
+            grads.setdefault(name, []).append(g)
+            err = float(np.abs(g - r).max()) / max(float(np.abs(r).max()), 1e-8)
+            if err > 3e-3:
+                bad.append((round(err, 5), name))
+        assert not bad, f"chain {chain}: {len(bad)} of {len(names)} tensors off: {sorted(bad, reverse=True)[:8]}"
+    worst = max(float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-12) for a, b in grads.values())
+    assert worst < 5e-4, worst
     grouped = [n for n in names if n.endswith(".conv2.weight")]
     assert len(grouped) == 4 + 23 + 3 and all(np.abs(m.get_tensor(n, grad=True)).max() > 0 for n in grouped[:3])
     # an SGD step moves the grouped weights and leaves the structural zeros of their windows zero (weight decay on 0 is 0)
