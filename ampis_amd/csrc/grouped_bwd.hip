@@ -81,6 +81,92 @@ __global__ __launch_bounds__(256) void grouped_wgrad_kernel(const GWArgs a) {
     }
 }
 
+// Round 4: all nine taps in ONE workgroup.  The per-tap kernel above reads dY and the three shifted X rows once per tap -- nine workgroups fetch the
+// same operands, 2.4 GB of loads per res3 layer for 9.7 GFLOP -- and was 7.4 ms of a 51-ms X-101 step.  Here a wave keeps nine 32 x 32 accumulators
+// (144 registers), loads its dY values once per pixel pair and walks the 3 x 3 taps over the three input rows (the shifted X loads hit the cache: the
+// same workgroup touched those lines microseconds ago): one dY load and nine X loads per nine MFMAs instead of eighteen loads, and the operands
+// leave HBM about once.  Same partial layout, same slice order in the reduce pass: bitwise reproducible; the sums differ from the per-tap kernel's
+// only through the slice boundaries.  3 x 3 windows only (KH = KW = 3: the ResNeXt conv2); dy may be a split row tensor (decoded on the load).
+__global__ __launch_bounds__(256, 2) void grouped_wgrad9_kernel(const GWArgs a) {      // stride 1 only (the three stride-2 layers of a ResNeXt keep the per-tap kernel)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntiles = a.C >> 6;
+    const int slice = blockIdx.x % a.nslices;
+    const int tile = blockIdx.x / a.nslices;
+    const int i = lane & 31, k = lane >> 5;
+    // <= 32 channels per group: only the two diagonal quadrants matter; the four waves then work as two PAIRS that take alternate trips of the
+    // slice (sub-slice 0 / 1: twice the waves per CU for the same grid; the reduce pass adds 2 x nslices partials in order)
+    const int sub = a.diag_only ? (wave >> 1) : 0, nsub = a.diag_only ? 2 : 1, q = a.diag_only ? (wave & 1) : wave;
+    const int cob = a.diag_only ? (q << 5) : ((q & 1) << 5), cib = a.diag_only ? (q << 5) : ((q >> 1) << 5);
+    const int co = (tile << 6) + cob + i;
+    const int ci = (tile << 6) + cib + i;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int row0 = slice * a.rows_per_slice, row1 = min(row0 + a.rows_per_slice, a.B * a.Ho);
+    // A trip = 8 output pixels of one output row: 4 dY values and 3 x 5 input pixel pairs per lane (the ten input pixels ox0 - 1 .. ox0 + 8 under
+    // the eight outputs, loaded ONCE per input row: half k of the wave holds pixel ox0 - 1 + 2 j + k; the three kx taps are views of them --
+    // kx = 0 takes pair u as it is, kx = 2 pair u + 1, kx = 1 the two halves crossed, one cross-half shuffle per pair).  The loads of trip
+    // t + 1 are issued before the 36 MFMAs of trip t (two register sets): with two or three waves per SIMD nothing else hides their latency.
+    const int tpr = (a.Wo + 7) >> 3, ntrips = (row1 - row0) * tpr;
+    auto load = [&](int t, float (&av)[4], float (&P)[3][5]) {
+        const int row = row0 + t / tpr, ox0 = (t % tpr) << 3;
+        const int b = row / a.Ho, oy = row - b * a.Ho;
+        const float* dyr = a.dy + ((size_t)row * a.Wo) * a.C;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ox = ox0 + 2 * u + k;
+            av[u] = (ox < a.Wo) ? (a.dy_split ? split_at(dyr + (size_t)ox * a.C, co) : dyr[(size_t)ox * a.C + co]) : 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy + ky - 1;
+            const bool rv = iy >= 0 && iy < a.H;
+            const float* xr = a.x + (((size_t)b * a.H + (rv ? iy : 0)) * a.W) * a.C + ci;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int px = ox0 - 1 + 2 * j + k;
+                P[ky][j] = (rv && px >= 0 && px < a.W) ? xr[(size_t)px * a.C] : 0.f;
+            }
+        }
+    };
+    auto compute = [&](const float (&av)[4], const float (&P)[3][5]) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float S[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) S[j] = __shfl_xor(P[ky][j], 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float m1 = k ? S[u + 1] : S[u];
+                acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], P[ky][u], acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], m1, acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], P[ky][u + 1], acc[ky * 3 + 2], 0, 0, 0);
+            }
+        }
+    };
+    float av0[4], av1[4], P0[3][5], P1[3][5];
+    if (sub < ntrips) load(sub, av0, P0);
+    for (int t = sub; t < ntrips; t += 2 * nsub) {
+        if (t + nsub < ntrips) load(t + nsub, av1, P1);
+        compute(av0, P0);
+        if (t + nsub < ntrips) {
+            if (t + 2 * nsub < ntrips) load(t + 2 * nsub, av0, P0);
+            compute(av1, P1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* out = a.partial + ((((size_t)(slice * nsub + sub) * ntiles + tile) * 9 + t) << 12);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rco = cob + (r >> 2) * 8 + k * 4 + (r & 3);
+            out[(rco << 6) + cib + i] = acc[t][r];
+        }
+    }
+}
+
 // grad[co][ky][kx][slot] = scale[co] * sum over slices (in slice order) of the partials, zero outside the group of co
 __global__ void grouped_wgrad_reduce_kernel(const float* partial, const float* scale, float* grad, int C, int ntaps, int nslices, int cpg, float out_scale) {
     const size_t total = (size_t)C * ntaps * 64;
@@ -122,7 +208,8 @@ extern "C" {
 
 size_t amp_grouped_wgrad_scratch_floats(const amp_conv_desc* d) {
     if (!d || d->Cin <= 0) return 0;
-    return (size_t)16 * d->Cin * d->KH * d->KW * 64;          // at most 16 slices
+    const size_t per_slice = (size_t)d->Cin * d->KH * d->KW * 64;
+    return std::min<size_t>(64, std::max<size_t>(16, ((size_t)48 << 20) / per_slice)) * per_slice;          // 16 .. 64 slices, at most 48 Mi floats beyond 16
 }
 
 int amp_conv2d_grouped_wgrad(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* dy, const float* scale,
@@ -144,13 +231,27 @@ int amp_conv2d_grouped_wgrad_fmt(amp_ctx* ctx, const amp_conv_desc* d, int group
     a.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     AMP_REQUIRE(a.Ho > 0 && a.Wo > 0, "amp_conv2d_grouped_wgrad: empty output");
     const int rows = a.B * a.Ho, pairs = (a.C >> 6) * a.KH * a.KW;
-    const int target = (cpg <= 32) ? 3072 : 1024;                                        // ~four (two-wave: twelve) workgroups per CU
-    int nslices = std::max(1, std::min({16, rows, (target + pairs - 1) / pairs}));
-    a.rows_per_slice = (rows + nslices - 1) / nslices;
-    nslices = (rows + a.rows_per_slice - 1) / a.rows_per_slice;
-    a.nslices = nslices;
     a.diag_only = cpg <= 32 ? 1 : 0;
-    hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(a.diag_only ? 128 : 256), 0, ctx->stream, a);
+    static const bool v1 = getenv("AMP_GROUPED_WGRAD_V1") != nullptr;      // EXPERIMENT switch: the per-tap kernel of round 3
+    if (!v1 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.x_split) {      // (a split x is decoded by the per-tap kernel only: the model decodes it in one pass instead)
+        // nine taps per workgroup: (tile, slice) workgroups -- enough slices to fill the chip (~3 workgroups per CU), within the scratch
+        const int ntiles = a.C >> 6;
+        const int cap = (int)(amp_grouped_wgrad_scratch_floats(d) / ((size_t)a.C * 9 * 64)) / (a.diag_only ? 2 : 1);
+        int nslices = std::max(1, std::min({cap, rows, (768 + ntiles - 1) / ntiles}));
+        a.rows_per_slice = (rows + nslices - 1) / nslices;
+        nslices = (rows + a.rows_per_slice - 1) / a.rows_per_slice;
+        a.nslices = nslices;
+        hipLaunchKernelGGL(grouped_wgrad9_kernel, dim3(ntiles * nslices), dim3(256), 0, ctx->stream, a);
+        if (a.diag_only) a.nslices = 2 * nslices;          // two sub-slices per workgroup (the reduce pass below)
+    } else {
+        const int target = (cpg <= 32) ? 3072 : 1024;                                        // ~four (two-wave: twelve) workgroups per CU
+        int nslices = std::max(1, std::min({16, rows, (target + pairs - 1) / pairs}));
+        a.rows_per_slice = (rows + nslices - 1) / nslices;
+        nslices = (rows + a.rows_per_slice - 1) / a.rows_per_slice;
+        a.nslices = nslices;
+        hipLaunchKernelGGL(grouped_wgrad_kernel, dim3(pairs * nslices), dim3(a.diag_only ? 128 : 256), 0, ctx->stream, a);
+    }
+    const int nslices = a.nslices;
     const size_t total = (size_t)a.C * a.KH * a.KW * 64;
     hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, ctx->stream,
                        scratch, scale, grad_win, a.C, a.KH * a.KW, nslices, cpg, ldexpf(1.0f, -dy_shift));

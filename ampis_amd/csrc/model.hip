@@ -1476,11 +1476,17 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
                 AMP_REQUIRE(amp_grouped_wgrad_scratch_floats(&dw) <= WG_SCRATCH && (size_t)ba.mid * 9 * 64 <= WT_SCRATCH, "backward: grouped scratch too small");
                 AMP_REQUIRE(st2 == 1 || st2 == 2, "backward: conv2 with stride %d", st2);
                 AMP_ALLOC(t1_dec, float, (size_t)B * h1 * w1 * ba.mid);
-                AMP_ALLOC(dt2_dec, float, (size_t)B * ba.oh * ba.ow * ba.mid);
-                AMP_TRY(amp_unsplit_rows(ctx, ba.t1, (long long)B * h1 * w1, ba.mid, t1_dec));
-                AMP_TRY(amp_unsplit_rows(ctx, d_t2, (long long)B * ba.oh * ba.ow, ba.mid, dt2_dec));          // = d(t2) * 2^16 in fp32
+                AMP_TRY(amp_unsplit_rows(ctx, ba.t1, (long long)B * h1 * w1, ba.mid, t1_dec));      // x is read nine times per pixel: decoded once; dy once: decoded on the load
                 AMP_TRY(amp::wgrad_async_join(ctx));      // the grouped kernels use wg_scratch on the main stream
-                AMP_TRY(amp_conv2d_grouped_wgrad_fmt(ctx, &dw, c2.groups, t1_dec, dt2_dec, c2.scale, wg_scratch, GW(c2), 0, 16));
+                // dy too is decoded by a pass of its own: decoding it on the load (fmt 2) costs the kernel more than the pass (55.1 against 52.8 ms
+                // per X-101 step, A/B in one call; AMP_GX_DY_INKERNEL=1 for the other)
+                static const bool dy_pass = getenv("AMP_GX_DY_INKERNEL") == nullptr;
+                if (dy_pass) {
+                    AMP_ALLOC(dt2_dec, float, (size_t)B * ba.oh * ba.ow * ba.mid);
+                    AMP_TRY(amp_unsplit_rows(ctx, d_t2, (long long)B * ba.oh * ba.ow, ba.mid, dt2_dec));
+                    AMP_TRY(amp_conv2d_grouped_wgrad_fmt(ctx, &dw, c2.groups, t1_dec, dt2_dec, c2.scale, wg_scratch, GW(c2), 0, 16));
+                } else
+                AMP_TRY(amp_conv2d_grouped_wgrad_fmt(ctx, &dw, c2.groups, t1_dec, d_t2, c2.scale, wg_scratch, GW(c2), 2, 16));
                 AMP_TRY(amp_group_dgrad_weights(ctx, c2.w, c2.scale, ba.mid, 3, 3, wt_scratch));
                 const float* dy2 = d_t2;
                 if (st2 == 2) { AMP_TRY(amp_scatter2_rows(ctx, d_t2, d_t2_up, B, h1, w1, ba.mid)); dy2 = d_t2_up; }
