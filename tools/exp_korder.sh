@@ -1,4 +1,6 @@
 #!/bin/bash
+# Round-4 experiment: channel-major against tap-major K order of conv_split_kernel in ONE gpurun call -- correctness, three
+# alternations of the bench, the per-launch table of both, per-dispatch traffic of the variant, then the full-size gate and smoke.
 set -o pipefail
 O=gpurun_out/c2; mkdir -p $O
 BQ="--steps 30 --warmup 5 --no-cpu-baseline --train-steps 0 --x101-steps 0 --no-strict --no-two-pipelines --no-host-inclusive"
