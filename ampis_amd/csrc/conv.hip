@@ -451,16 +451,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // where the unfused one did not round at all.  Range check: s = fma(v, 0, s) stays 0 unless an accumulator is inf or NaN.
 // out_mode 0, split output; residual none or in the split format (res_mode 1: same row; 2: the coarser level's row); ReLU mask
 // (training: the data gradient gated by the forward activation) none or in the split format.
+// out_mode 1 (SPATIAL instantiation; round 4): the ConvTranspose 2x2 s2 of the mask head as a 1x1 conv to (tap, co) = 4 x C2 channels -- a wave's
+// 64 columns lie inside ONE tap (C2 % 64 == 0), tile row m = input pixel (b, oy, ox) goes to output pixel (b, 2 oy + ky, 2 ox + kx), a row of C2
+// channels: the same 16-B stores at another row address, so the 1.6-GB tensor of a training step no longer takes the staged epilogue's trip
+// through LDS (1048 us at 1.96 TB/s before).
 template <bool SPATIAL, bool CHECK>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[4][4], int lane, int mw0, int nw0) {
     const int l15 = lane & 15, lq = lane >> 4;
     const bool has_res = a.res_mode != 0, has_mask = a.mask != nullptr;
+    const bool deconv = SPATIAL && a.out_mode == 1;
+    const int C2 = a.Cout >> 2;
+    const int tap = deconv ? nw0 / C2 : 0, ncol0 = deconv ? nw0 - tap * C2 : nw0;      // column of this wave inside an output row
+    const int yld = deconv ? C2 : a.Cout;                                              // floats per output row
     f32x2 sc[2][4], sh[2][4];
     size_t colb[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int n = nw0 + 32 * g + 8 * lq;
-        colb[g] = (size_t)(n >> 5) * 128 + (size_t)(n & 31) * 2;
+        const int nc = ncol0 + 32 * g + 8 * lq;
+        colb[g] = (size_t)(nc >> 5) * 128 + (size_t)(nc & 31) * 2;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             sc[g][p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
@@ -520,7 +529,14 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
         const int mrow = mw0 + i * 16 + l15;
         const bool mv = mrow < a.M;
         const unsigned int m = min((unsigned int)mrow, (unsigned int)(a.M - 1));
-        const size_t yrow = (size_t)m * a.Cout;
+        size_t yrow = (size_t)m * a.Cout;
+        if (deconv) {
+            const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            yrow = (((size_t)b * 2 * a.Ho + 2 * oy + (tap >> 1)) * (2 * a.Wo) + 2 * ox + (tap & 1)) * (size_t)yld;
+        }
         f16x8 rh[2], rl[2], mh[2], ml[2];
         if (has_res) {
             if (!HOIST) load_res(i);
@@ -1518,7 +1534,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
         else conv_epilogue_rpn(a, acc, lds, wave, lane, m0, n0);
         return;
     }
-    if (a.y_split && (!a.mask || a.mask_split) && a.out_mode == 0 && (a.res_mode == 0 || a.res_split) && a.direct_epi)
+    if (a.y_split && (!a.mask || a.mask_split) && (a.out_mode == 0 || (EPI == 2 && a.out_mode == 1 && !a.mask && a.res_mode == 0)) && (a.res_mode == 0 || a.res_split) && a.direct_epi)
         conv_epilogue_direct<EPI == 2, true>(a, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
     else
         conv_epilogue_swapped<WTM, WTN, EPI == 2, true>(a, acc, lds, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
@@ -2699,7 +2715,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     }
     AMP_REQUIRE(!a.mask_split || (mask != nullptr && epi != 0 && a.Cout % 32 == 0 && a.out_mode == 0), "conv: a split-format mask needs mask, Cout %% 32 == 0, out_mode 0 and a fast epilogue");
     AMP_REQUIRE(!a.res_split || (res != nullptr && epi != 0 && a.Cout % 32 == 0), "conv: a split-format residual needs res, Cout %% 32 == 0 and a fast epilogue");
-    AMP_REQUIRE(!a.y_split || (a.out_mode == 0 && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 and Cout %% 32 == 0");
+    // split output: out_mode 0; or the 2x2 deconv scatter (out_mode 1) straight from the ring kernel's accumulators -- checked again where the kernel is chosen
+    const bool deconv_split = a.y_split && a.out_mode == 1;
+    AMP_REQUIRE(!a.y_split || ((a.out_mode == 0 || a.out_mode == 1) && a.Cout % 32 == 0 && epi != 0), "conv: split output needs out_mode 0 (or the deconv scatter) and Cout %% 32 == 0");
+    AMP_REQUIRE(!deconv_split || ((a.Cout / 4) % 64 == 0 && !res && !mask && x_is_split && g_split_ring && g_direct_epi && a.Cout % 256 == 0),
+                "conv: a split deconv output needs Cout / 4 %% 64 == 0, a split input, no residual / mask and the ring kernel's direct epilogue");
     AMP_REQUIRE(!x_is_split || (ctx->conv_mode == AMP_CONV_F16X3 && !force_f32 && a.Cin % 32 == 0 && glds),
                 "conv: a split-format input needs AMP_CONV_F16X3, Cin %% 32 == 0 and operands below 2 GiB");
     a.in_scale = (in_shift != 0) ? ldexpf(1.0f, in_shift) : 1.0f;
@@ -2744,7 +2764,8 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             a.ntn = a.Cout / 128; a.nblk = ntm * a.ntn;
             a.stagger = 0;
             launch_split_short(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
-        } else if (x_is_split && g_split_ring && epi != 0 && wide256) {            // 128 x 256 tiles, 3-buffer ring
+        } else if (x_is_split && g_split_ring && epi != 0 && (wide256 || deconv_split)) {            // 128 x 256 tiles, 3-buffer ring
+            // (the K = 256 deconv with its scatter epilogue on two-buffer 128 x 128 tiles, two workgroups per CU: 1009 against 931 us -- measured, not kept)
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;
             if (rec) rec->variant = 0;
             launch_split<128, 256>(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -105,6 +105,7 @@ struct amp_model {
     int last_chain = -1;                // the last backward pass's backbone chain: 0 fp32 storage, 1 split activations + fp32 gradients, 2 scaled split gradients (R50 / R101), 3 the same for ResNeXt blocks
     bool gs_chain_ok = false;           // ... and the backbone's backward chain can run on scaled split gradients (dense 3x3, stride in conv1: R50 / R101)
     bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
+    bool deconv_out_split = false;      // ... and the deconv's [N,28,28,256] output (round 4)
     bool mask_tail_split = false;       // ... and fcn4's output (the deconv's input): the deconv and its three gradient launches on pre-split operands
     struct BlockAct { std::string key; float *x_in, *t1, *t2, *sc, *out; int in_h, in_w, oh, ow, cin, mid, cout, stride, stage; bool has_sc; };
     std::vector<BlockAct> blocks;
@@ -1028,8 +1029,14 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             const std::string key = "roi_heads.mask_head.mask_fcn" + std::to_string(i);
             AMP_TRY(launch_conv(m, CONV(key.c_str()), macts[i - 1], N, 14, 14, 1, 1, true, 0, nullptr, 0, macts[i], MS ? ((i < 4 || MT) ? 3 : 1) : 0));
         }
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, MT ? 1 : 0));
-        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits));
+        // MT: the deconv's OUTPUT stays in the split row format too (round 4): the ring kernel scatters split rows straight from its accumulators
+        // (conv_epilogue_direct, out_mode 1) instead of sending 1.6 GB of fp32 through the staged epilogue; the predictor reads it as a split
+        // operand, its weight gradient takes x split, its data gradient the split activation as the ReLU mask (AMP_NO_DECONV_SPLIT: fp32 as before)
+        static const bool no_ds = getenv("AMP_NO_DECONV_SPLIT") != nullptr;      // EXPERIMENT switch
+        const bool DS = MT && !no_ds && split_chain(m, {"roi_heads.mask_head.predictor"});
+        m->deconv_out_split = DS;
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.deconv"), macts[4], N, 14, 14, 1, 0, true, 0, nullptr, 1, mt_b, MT ? (DS ? 3 : 1) : 0));
+        AMP_TRY(launch_conv(m, CONV("roi_heads.mask_head.predictor"), mt_b, N, 28, 28, 1, 0, false, 0, nullptr, 0, mlogits, DS ? 1 : 0));
         if (n_runs) {
             // bitmask ground truth: BitMasks.crop_and_resize from the run lengths.  The runs travel in a buffer of their own (their
             // size is data-dependent: not part of the workspace plan), the window bit maps in a scratch of <= 256 frame-sized slots.
@@ -1200,9 +1207,11 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(dbd_t, float, 256);
     if (!dry && N > 0) {
         const ConvW& cp = CONV("roi_heads.mask_head.predictor");
-        AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false, true));
         const bool MT = m->mask_tail_split && ctx->conv_mode == AMP_CONV_F16X3;
-        if (MT) AMP_TRY(amp_small_k_dgrad_split_f32act(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, N * 784, 16, cs_scratch, dbd_t, 0));    // + the deconv's bias sums
+        const bool DS = MT && m->deconv_out_split;
+        AMP_TRY(wgrad(cp, mt_b, N, 28, 28, 1, 0, d_mlogits, false, true, DS ? 1 : 0));
+        if (DS) AMP_TRY(amp_small_k_dgrad_split_ld(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, N * 784, 16, cs_scratch, dbd_t, 0));    // + the deconv's bias sums
+        else if (MT) AMP_TRY(amp_small_k_dgrad_split_f32act(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, N * 784, 16, cs_scratch, dbd_t, 0));
         else AMP_TRY(amp_small_k_dgrad(ctx, d_mlogits, Kp, K, cp.w, 256, mt_b, d_mtb, (size_t)N * 784));
         const ConvW& cd = CONV("roi_heads.mask_head.deconv");
         {   // weight gradient in [ci][tap][co] form, then transposed into the forward layout [(tap,co)][ci]

@@ -790,6 +790,23 @@ int amp_small_k_dgrad_split(amp_ctx* ctx, const float* dl, int K, const float* w
     return amp_colsum_finish(ctx, scratch, parts, C, colsum_out, accumulate);
 }
 
+// act in the split row format and dl rows of ld = 4, 8, 12 or 16 floats (the mask predictor behind a deconv whose output is kept split, round 4)
+int amp_small_k_dgrad_split_ld(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act_split, float* dx_split, int npix,
+                               int shift, float* scratch, float* colsum_out, int accumulate) {
+    AMP_REQUIRE(ctx && dl && w && act_split && dx_split && scratch && colsum_out && C % 32 == 0 && K >= 1 && K <= ld && ld % 4 == 0 && ld <= 16 && npix > 0 && shift >= 0 && shift <= 24,
+                "amp_small_k_dgrad_split_ld: bad argument (dl rows are ld = 4, 8, 12 or 16 floats, K <= ld)");
+    const int parts = (npix + 511) / 512;
+    const float sc = ldexpf(1.0f, shift);
+    switch (ld / 4) {
+        case 1: hipLaunchKernelGGL((small_k_dgrad_split_kernel<true, 1>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, sc); break;
+        case 2: hipLaunchKernelGGL((small_k_dgrad_split_kernel<true, 2>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, sc); break;
+        case 3: hipLaunchKernelGGL((small_k_dgrad_split_kernel<true, 3>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, sc); break;
+        default: hipLaunchKernelGGL((small_k_dgrad_split_kernel<true, 4>), dim3(parts), dim3(256), 0, ctx->stream, dl, K, w, C, act_split, dx_split, npix, scratch, sc); break;
+    }
+    AMP_HIP_CHECK(hipGetLastError());
+    return amp_colsum_finish(ctx, scratch, parts, C, colsum_out, accumulate);
+}
+
 int amp_small_k_dgrad_split_f32act(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx_split, int npix,
                                    int shift, float* scratch, float* colsum_out, int accumulate) {
     AMP_REQUIRE(ctx && dl && w && act && dx_split && scratch && colsum_out && C % 32 == 0 && K >= 1 && K <= ld && ld % 4 == 0 && ld <= 16 && npix > 0 && shift >= 0 && shift <= 24,

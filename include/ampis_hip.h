@@ -224,6 +224,9 @@ int amp_small_k_dgrad_split(amp_ctx* ctx, const float* dl, int K, const float* w
  * is fp32): dx is amp_small_k_dgrad's value, * 2^shift, as split rows; colsum_out = the deconv's bias gradient. */
 int amp_small_k_dgrad_split_f32act(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act, float* dx_split, int npix,
                                    int shift, float* scratch, float* colsum_out, int accumulate);
+/* ... and with act in the split row format again (a deconv output kept split: amp_conv2d_nhwc_fmt with out_mode 1 and AMP_FMT y split) */
+int amp_small_k_dgrad_split_ld(amp_ctx* ctx, const float* dl, int ld, int K, const float* w, int C, const float* act_split, float* dx_split, int npix,
+                               int shift, float* scratch, float* colsum_out, int accumulate);
 int amp_colsum_finish(amp_ctx* ctx, const float* partial, int parts, int N, float* out, int accumulate);
 int amp_deconv_grad_transpose(amp_ctx* ctx, const float* in, float* out, int Cin, int T, int C2, int accumulate);
 /* torch.optim.SGD: g' = grad_scale*g + wd*p; v = mu*v + g'; p -= lr*v */

@@ -273,6 +273,29 @@ def test_dgrad_weights_split_is_transpose_then_split(gpu_ctx, shape, scaled):
     assert torch.equal(one.view(torch.int32), two.view(torch.int32))
 
 
+def test_deconv_scatter_written_as_split_rows_is_the_fp32_scatter_split(gpu_ctx):
+    """conv_epilogue_direct with out_mode 1 (round 4): the ConvTranspose 2x2 s2 of the mask head (a 1x1 conv to 4 x 256 channels whose rows are
+    scattered to the doubled resolution) written as split rows straight from the ring kernel's accumulators == the same deconv's fp32 output,
+    split afterwards, bit for bit (bias, ReLU; 1568 RoIs so that the ring kernel takes it, a row count that is not a multiple of the tile)."""
+    import torch
+    from ampis_amd import ops
+    torch.manual_seed(3)
+    N = 1568 + 3
+    x = torch.randn(N, 14, 14, 256, device="cuda")
+    w = torch.randn(1024, 1, 1, 256, device="cuda") * 0.05
+    b = torch.randn(1024, device="cuda")
+    xs = ops.split_rows(gpu_ctx, x)
+    y32 = ops.conv2d_nhwc(gpu_ctx, xs, w, None, b, relu=True, deconv2x2=True, fmt=ops.FMT_X_SPLIT)                       # fp32 [N,28,28,256], staged epilogue
+    ysp = ops.conv2d_nhwc(gpu_ctx, xs, w, None, b, relu=True, deconv2x2=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)     # split rows, direct epilogue
+    torch.cuda.synchronize()
+    assert y32.shape == ysp.shape == (N, 28, 28, 256)
+    want = ops.split_rows(gpu_ctx, y32)
+    assert torch.equal(ysp.view(torch.int32), want.view(torch.int32))
+    ref = torch.relu(torch.einsum("nhwc,oc->nhwo", ops.unsplit_rows(gpu_ctx, xs).double(), w.view(1024, 256).double()) + b.double())
+    ref = ref.view(N, 14, 14, 2, 2, 256).permute(0, 1, 3, 2, 4, 5).reshape(N, 28, 28, 256)
+    assert float((y32.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
 def test_mask_tail_on_presplit_operands_agrees_with_the_fp32_storage_path():
     """The mask head's tail of a training step with fcn4's output and d(deconv out) kept as split rows (deconv forward on the ring kernel, the
     predictor's data gradient writing d * 2^16 as split rows with the deconv's bias sums on the side, the deconv's weight- and data-gradient
@@ -297,7 +320,14 @@ def test_mask_tail_on_presplit_operands_agrees_with_the_fp32_storage_path():
     finally:
         _lib.lib().amp_debug_set_mask_tail_split(-1)
     assert not ctx.conv_range_flag()
-    assert out[0][0] == out[1][0]
+    # round 4: with the tail on, the deconv's OUTPUT is stored as split rows as well (22-23 significant bits instead of 24), so the mask
+    # predictor -- and with it loss_mask -- sees values rounded once more: equal to a few 1e-7, no longer bit for bit; the other four losses
+    # do not depend on the mask head's storage at all
+    for k in out[0][0]:
+        if k == "loss_mask":
+            assert out[1][0][k] == pytest.approx(out[0][0][k], rel=2e-6), (out[0][0], out[1][0])
+        else:
+            assert out[1][0][k] == out[0][0][k], (k, out[0][0], out[1][0])
     changed = 0
     for k in names:
         r, g = out[0][1][k], out[1][1][k]
