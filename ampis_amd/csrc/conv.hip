@@ -455,8 +455,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 64 columns lie inside ONE tap (C2 % 64 == 0), tile row m = input pixel (b, oy, ox) goes to output pixel (b, 2 oy + ky, 2 ox + kx), a row of C2
 // channels: the same 16-B stores at another row address, so the 1.6-GB tensor of a training step no longer takes the staged epilogue's trip
 // through LDS (1048 us at 1.96 TB/s before).
-template <bool SPATIAL, bool CHECK>
-__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[4][4], int lane, int mw0, int nw0) {
+// MBR row blocks of 16 per wave tile (4: the 64 x 64 wave tiles of conv_split_kernel; 2: conv3x3_c64_kernel); mrow_in[i] + (nothing): the GEMM row of
+// this lane in row block i (any value >= a.M: not stored) -- consecutive rows for the GEMM tiles, rows of a 2-D pixel patch for the patch kernel
+template <bool SPATIAL, bool CHECK, int MBR>
+__device__ __forceinline__ void conv_epilogue_direct_rows(const ConvArgs& a, f32x4 (&acc)[MBR][4], int lane, const int (&mrow_in)[MBR], int nw0) {
     const int l15 = lane & 15, lq = lane >> 4;
     const bool has_res = a.res_mode != 0, has_mask = a.mask != nullptr;
     const bool deconv = SPATIAL && a.out_mode == 1;
@@ -480,7 +482,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
     // The residual rows of ALL four row groups are requested before the first store: y and res may alias as far as the compiler knows, so
     // it keeps a group's loads behind the previous group's stores -- and loads return in order BEHIND older stores (one vmcnt queue), so
     // every group paid a store round trip plus a load round trip.  The 64 registers are the cross-term accumulators', dead since the fold.
-    f16x8 rha[4][2], rla[4][2];
+    f16x8 rha[MBR][2], rla[MBR][2];
 #ifdef AMP_NO_HOIST
     constexpr bool HOIST = false;
 #else
@@ -488,7 +490,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
 #endif
     auto load_res = [&](int i) {
         {
-            const unsigned int m = min((unsigned int)(mw0 + i * 16 + l15), (unsigned int)(a.M - 1));
+            const unsigned int m = min((unsigned int)mrow_in[i], (unsigned int)(a.M - 1));
             size_t rrow = (size_t)m * a.Cout;
             if (SPATIAL && a.res_mode == 2) {
                 const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
@@ -507,12 +509,12 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
     };
     if (has_res && HOIST) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_res(i);
+        for (int i = 0; i < MBR; ++i) load_res(i);
     }
     // the same for the gating activation (training: data gradients): all four row groups up front
-    f16x8 mha[4][2], mla[4][2];
+    f16x8 mha[MBR][2], mla[MBR][2];
     auto load_mask = [&](int i) {
-        const unsigned int m = min((unsigned int)(mw0 + i * 16 + l15), (unsigned int)(a.M - 1));
+        const unsigned int m = min((unsigned int)mrow_in[i], (unsigned int)(a.M - 1));
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const char* mb = reinterpret_cast<const char*>(a.mask + (size_t)m * a.Cout) + colb[g];
@@ -522,11 +524,11 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
     };
     if (has_mask && HOIST) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_mask(i);
+        for (int i = 0; i < MBR; ++i) load_mask(i);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mrow = mw0 + i * 16 + l15;
+    for (int i = 0; i < MBR; ++i) {
+        const int mrow = mrow_in[i];
         const bool mv = mrow < a.M;
         const unsigned int m = min((unsigned int)mrow, (unsigned int)(a.M - 1));
         size_t yrow = (size_t)m * a.Cout;
@@ -583,6 +585,13 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&
         }
     }
     if (CHECK && (!(chk[0] == 0.f) || !(chk[1] == 0.f))) atomicOr(a.range_flag, 1);
+}
+
+template <bool SPATIAL, bool CHECK>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvArgs& a, f32x4 (&acc)[4][4], int lane, int mw0, int nw0) {
+    const int l15 = lane & 15;
+    const int mrows[4] = {mw0 + l15, mw0 + 16 + l15, mw0 + 32 + l15, mw0 + 48 + l15};
+    conv_epilogue_direct_rows<SPATIAL, CHECK, 4>(a, acc, lane, mrows, nw0);
 }
 
 // The staged epilogues (fp32 output, mask, scatter modes) behind the role-swapped MFMA: only the staging indices differ.
@@ -1547,6 +1556,129 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// conv3x3_c64_kernel (round 4): the 3x3 stride-1 convolution over a 64-channel WINDOW -- res2's dense 64 -> 64 layers and the grouped conv2
+// of a ResNeXt (every 64-wide N tile reads its own 64 input channels) -- with both operands in the split row format.
+// The implicit-GEMM kernels stage, per tap and K-step, the tile's (shifted) input pixels again: 18 K-steps re-read a 256-pixel tile's
+// 64 channels nine times over, 1.2 GB of L2 -> LDS traffic per res2 layer for 134 MB of input, and that DMA stream, not the matrix pipe
+// (0.31 of its peak), is their bound.  Here a workgroup stages the (8 + 2) x (16 + 2) pixel PATCH under its 8 x 16 output pixels once (180 pixels
+// x 256 B = 46 KB, out-of-image pixels zero-filled by the buffer load) and all nine taps read their MFMA operands out of it: a 16 x 16
+// MFMA block is one tile row of 16 pixels, so tap (ky, kx) is the same fragment read at patch pixel (row + ky) * 18 + kx + column.  Only the
+// weights travel per tap (64 rows x 256 B, two buffers).  4 waves x (2 tile rows x 64 channels), two workgroups per CU (78 KB of LDS each).
+// LDS rows are 256 B = 16 chunks of 16 B ([hi 0-31 | lo' 0-31 | hi 32-63 | lo' 32-63]); chunk c of row r sits at position c ^ (r & 15), applied
+// to the SOURCE chunk of the LDS-DMA, so the 16 consecutive pixels (or weight rows) a lane group reads hit 16 different positions: conflict-free.
+// Same products as every other AMP_CONV_F16X3 kernel (f16x3_mfma16), summed tap by tap (ky, kx, then the two 32-channel halves: the K order of
+// the implicit-GEMM kernels), epilogue = conv_epilogue_direct_rows (FrozenBN / bias, ReLU, split ReLU mask for data gradients, split rows out).
+// ------------------------------------------------------------------------------------------------------------------
+// DIAG (groups of at most 32 channels): the 64 x 64 weight window is two 32 x 32 diagonal blocks -- LDS row blocks 0, 1 (channels 0-31 under swap_channel)
+// see only the first 32-channel half of the window, blocks 2, 3 only the second: the other half of the products is exactly zero and is not computed
+// (half the MFMAs and weight fragment reads; adding exact zeros changes no sum, so the result is the full product's bit for bit).
+template <bool DIAG>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes, const int tiles_x, const int tiles_y) {
+    constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;      // 180 patch pixels
+    constexpr int ROWF = 64;                                                        // floats per LDS row (256 B)
+    constexpr int NINST = NPIX / 4;                                                 // 45 DMA instructions of 4 pixels x 16 chunks
+    static_assert(NPIX % 4 == 0, "patch pixels per DMA instruction");
+    __shared__ __attribute__((aligned(16))) float lds[NPIX * ROWF + 2 * 64 * ROWF];
+    float* patch = lds;
+    float* wbuf = lds + NPIX * ROWF;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    int t = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = t % a.ntn; t /= a.ntn;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * 64;
+    const int cwin = a.grouped ? n0 : 0;                                            // first input channel of the window
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+    const int sub = lane >> 4, chunk = lane & 15;                                   // DMA: lane = (row sub of 4, 16-B chunk)
+    // ---- the patch, once ----
+    for (int it = wave; it < NINST; it += 4) {
+        const int q = it * 4 + sub;
+        const int py = q / PW, px = q - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned int voff = v ? (unsigned int)((((size_t)(b * a.H + iy) * a.W + ix) * a.Cin + cwin) * 4 + (size_t)((chunk ^ (q & 15)) * 16)) : OOB_VOFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(patch + it * 4 * ROWF), 16, (int)voff, 0, 0, 0);
+    }
+    // ---- weights of one tap: 64 rows (LDS row r = output channel n0 + swap_channel(r)) x 256 B ----
+    auto stage_w = [&](int tap, int buf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = (wave * 4 + g) * 4 + sub;
+            const int n = n0 + swap_channel(r);
+            const unsigned int voff = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + (size_t)tap * 64) * 4 + (size_t)((chunk ^ (r & 15)) * 16)) : OOB_VOFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(wbuf + buf * 64 * ROWF + (wave * 4 + g) * 4 * ROWF), 16, (int)voff, 0, 0, 0);
+        }
+    };
+    stage_w(0, 0);
+    f32x4 acc[2][4], acx[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    for (int tap = 0; tap < 9; ++tap) {
+        __syncthreads();                        // (vmcnt(0) + barrier) the patch and this tap's weights have landed; everyone is done with the other weight buffer
+        if (tap + 1 < 9) stage_w(tap + 1, (tap + 1) & 1);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const float* wb = wbuf + (tap & 1) * 64 * ROWF;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {           // the two 32-channel halves of the window
+            F16x3Frags<2, 4> f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = (2 * wave + i + ky) * PW + kx + l15;
+                const float* row = patch + q * ROWF;
+                f.ah[i] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + lq) ^ (q & 15)));
+                f.al[i] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + 4 + lq) ^ (q & 15)));
+            }
+            if constexpr (DIAG) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float* row = wb + ((2 * g + jj) * 16 + l15) * ROWF;
+                    f.bh[jj] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + lq) ^ l15));
+                    f.bl[jj] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + 4 + lq) ^ l15));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {     // f16x3_mfma16<.., SWAP>'s order per accumulator: lo'*hi, hi*lo', hi*hi
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acx[i][2 * g + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bh[jj], f.al[i], acx[i][2 * g + jj], 0, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acx[i][2 * g + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bl[jj], f.ah[i], acx[i][2 * g + jj], 0, 0, 0);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acc[i][2 * g + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.bh[jj], f.ah[i], acc[i][2 * g + jj], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* row = wb + (j * 16 + l15) * ROWF;
+                    f.bh[j] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + lq) ^ l15));
+                    f.bl[j] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + 4 + lq) ^ l15));
+                }
+                f16x3_mfma16<2, 4, true>(f, acc, acx);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+    int mrows[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * wave + i, ox = ox0 + l15;
+        mrows[i] = (oy < a.Ho && ox < a.Wo) ? (b * a.Ho + oy) * a.Wo + ox : a.M;
+    }
+    conv_epilogue_direct_rows<false, true, 2>(a, acc, lane, mrows, n0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // conv_f16x3_kernel (amp_set_conv_mode(ctx, AMP_CONV_F16X3)): the same implicit GEMM on the f16 matrix pipe, fp32 in / fp32 out.
 // Every operand x is split as x = hi + lo with hi = f16(x) and lo = x - hi (exact in fp32); the low half is stored as
 // lo' = f16(lo * 2^11), which has the magnitude of hi, so it stays a normal f16 number however small x is (22 significant bits
@@ -2154,6 +2286,8 @@ static int g_direct_epi = getenv("AMP_DIRECT_EPI") ? atoi(getenv("AMP_DIRECT_EPI
 extern "C" void amp_debug_set_direct_epi(int v) { g_direct_epi = v; }
 static int g_korder = getenv("AMP_KORDER") ? atoi(getenv("AMP_KORDER")) : 0;     // EXPERIMENT switch: 1 = channel-major K order in conv_split_kernel (ConvArgs::korder)
 extern "C" void amp_debug_set_korder(int v) { g_korder = v; }
+static int g_patch_conv = getenv("AMP_NO_PATCH_CONV") ? 0 : 1;      // EXPERIMENT switch: 0 = the implicit-GEMM kernels for the 64-channel-window 3x3 layers; 2 = conv3x3_c64_kernel whatever the grid size (tests)
+extern "C" void amp_debug_set_patch_conv(int v) { g_patch_conv = v; }
 static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
 extern "C" void amp_debug_set_stagger(int v) { g_stagger = v; }
 static int g_conv_generic_epi = 0;   // tests: force the generic epilogue
@@ -2747,6 +2881,15 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         // a split input that carries a 2^in_shift (scaled loss gradients): only the ring kernel undoes it (a.out_scale in its fold)
         AMP_REQUIRE(!(x_is_split && in_shift != 0) || (g_split_ring && epi != 0 && wide256 && a.out_mode != 3),
                     "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
+        if (g_patch_conv != 0 && x_is_split && a.y_split && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.cin_win == 64 && (a.grouped || (a.Cin == 64 && a.Cout == 64)) &&
+            a.out_mode == 0 && a.res_mode == 0 && epi != 0 && g_direct_epi && (!mask || a.mask_split) && a.in_scale == 1.0f && a.Cout % 64 == 0 &&
+            (g_patch_conv == 2 || (long long)a.B * amp::cdiv(a.Ho, 8) * amp::cdiv(a.Wo, 16) * (a.Cout / 64) >= 512)) {
+            // res2's dense 64 -> 64 layers and the ResNeXt conv2: a pixel patch staged once, nine taps read out of it (conv3x3_c64_kernel)
+            const int tiles_x = amp::cdiv(a.Wo, 16), tiles_y = amp::cdiv(a.Ho, 8);
+            a.ntn = a.Cout / 64; a.nblk = a.B * tiles_x * tiles_y * a.ntn;
+            if (a.grouped && cpg <= 32) AMP_TIMED_LAUNCH(conv3x3_c64_kernel<true>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
+            else AMP_TIMED_LAUNCH(conv3x3_c64_kernel<false>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
+        } else
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
             if (rec) rec->variant = 0;

@@ -631,3 +631,40 @@ def test_tall_64_wide_tiles_are_bit_identical(gpu_ctx, shape):
     finally:
         lib().amp_debug_set_tall64(1)
     assert float((ops.unsplit_rows(gpu_ctx, ref) if y_split else ref).abs().max()) > 0
+
+
+@pytest.mark.parametrize("case", ["dense64", "grouped32x8", "grouped_cpg32", "ragged"])
+def test_patch_staged_3x3_over_a_64_channel_window_equals_the_implicit_gemm_kernels(gpu_ctx, case):
+    """conv3x3_c64_kernel (round 4: res2's dense 64 -> 64 layers and the ResNeXt conv2: the pixel patch under an 8 x 16 output tile staged once,
+    nine taps read out of it) against the implicit-GEMM kernels it replaces on the same split operands: the same exact products summed in the
+    same K order (tap by tap, then the two 32-channel halves) -- bit for bit, with FrozenBN affine + ReLU, with a split ReLU mask (the data
+    gradient of a training step), on image sizes that are not multiples of the 8 x 16 tile, and against an fp64 reference."""
+    import torch
+    from ampis_amd import _lib, ops
+    torch.manual_seed(5)
+    B, H, W = (2, 40, 64) if case != "ragged" else (3, 37, 51)
+    C, groups = {"dense64": (64, 1), "grouped32x8": (256, 32), "grouped_cpg32": (128, 4), "ragged": (64, 1)}[case]
+    cpg = C // groups
+    x = torch.randn(B, H, W, C, device="cuda")
+    wg = torch.randn(C, 3, 3, cpg, device="cuda") * 0.1                  # grouped OHWI
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    xs = ops.split_rows(gpu_ctx, x)
+    L = _lib.lib()
+    outs = []
+    for mode in (0, 2):
+        L.amp_debug_set_patch_conv(mode)
+        try:
+            if groups == 1:
+                y = ops.conv2d_nhwc(gpu_ctx, xs, wg, sc, sh, stride=1, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+            else:
+                y = ops.conv2d_grouped_nhwc(gpu_ctx, xs, wg, groups, sc, sh, stride=1, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+            torch.cuda.synchronize()
+        finally:
+            L.amp_debug_set_patch_conv(1)
+        outs.append(y)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32)), f"{int((outs[0].view(torch.int32) != outs[1].view(torch.int32)).sum())} words differ"
+    xd = ops.unsplit_rows(gpu_ctx, xs).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xd, wg.double().permute(0, 3, 1, 2), stride=1, padding=1, groups=groups)
+    ref = torch.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
+    got = ops.unsplit_rows(gpu_ctx, outs[1]).double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6

@@ -134,12 +134,16 @@ def test_x101_training_step_against_autograd(gpu_ctx):
     # round 4: the default is the scaled split gradient chain for ResNeXt blocks (chain 3); the fp32-gradient chain on split activations (1)
     # is held to the same bar, and the two agree with each other far closer than either does with autograd
     grads = {}
-    for gx, chain in ((1, 3), (0, 1)):
+    # third pass: the patch-staged grouped 3x3 (conv3x3_c64_kernel) forced on at this small size -- forward conv2 AND its data gradient with the
+    # split ReLU mask run through it (at bench sizes it is the default; its grid rule would leave it out here)
+    for gx, chain, patch in ((1, 3, 1), (0, 1, 1), (1, 3, 2)):
         _lib.lib().amp_debug_set_gx(gx)
+        _lib.lib().amp_debug_set_patch_conv(patch)
         try:
             got = m.forward_losses(imgs, gts, seed=3, backward=True)
         finally:
             _lib.lib().amp_debug_set_gx(-1)
+            _lib.lib().amp_debug_set_patch_conv(1)
         assert _lib.lib().amp_debug_last_backward_chain(m._h) == chain, (gx, _lib.lib().amp_debug_last_backward_chain(m._h))
         for k, v in ref.items():
             assert got[k] == pytest.approx(float(v), rel=3e-4, abs=1e-6), (k, got[k], float(v))
@@ -151,8 +155,9 @@ def test_x101_training_step_against_autograd(gpu_ctx):
             if err > 3e-3:
                 bad.append((round(err, 5), name))
         assert not bad, f"chain {chain}: {len(bad)} of {len(names)} tensors off: {sorted(bad, reverse=True)[:8]}"
-    worst = max(float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-12) for a, b in grads.values())
+    worst = max(float(np.abs(a - b).max()) / max(float(np.abs(b).max()), 1e-12) for a, b, _ in grads.values())
     assert worst < 5e-4, worst
+    assert all(np.array_equal(a, c) for a, _, c in grads.values()), "the patch-staged grouped 3x3 must give the implicit-GEMM kernels' gradients bit for bit"
     grouped = [n for n in names if n.endswith(".conv2.weight")]
     assert len(grouped) == 4 + 23 + 3 and all(np.abs(m.get_tensor(n, grad=True)).max() > 0 for n in grouped[:3])
     # an SGD step moves the grouped weights and leaves the structural zeros of their windows zero (weight decay on 0 is 0)
