@@ -13,7 +13,7 @@ per = len(rows)
 
 
 def is_conv(name):
-    return any(t in name for t in ("conv_split_kernel", "conv_glds_kernel", "conv_f16x3_kernel", "conv_mfma_kernel", "stem_pool"))
+    return any(t in name for t in ("conv_split_kernel", "conv_glds_kernel", "conv_f16x3_kernel", "conv_mfma_kernel", "conv3x3_c64_kernel", "stem_pool"))
 
 
 def per_dispatch(sub, counter):
@@ -32,7 +32,7 @@ def per_dispatch(sub, counter):
 
 def short(n):
     import re
-    m = re.search(r"(conv_\w+_kernel|stem_pool\w+)<?([^>(]*)", n)
+    m = re.search(r"(conv\w*_kernel|stem_pool\w+)<?([^>(]*)", n)
     if not m:
         return n[:30]
     a = [t.strip() for t in m.group(2).split(",")] if m.group(2) else []
