@@ -35,6 +35,28 @@ def test_no_packed_fp32_instruction_selects_the_high_half_of_src1(tmp_path):
             elif "s_swappc_b64" in line and name:
                 calls[name] = calls.get(name, 0) + 1
     assert not calls, calls
+    # Codegen guard of the hot kernels (round 4: a run-time flag in conv_split_kernel's staging lambda spilled 12 B of scratch at 250 VGPRs and put a
+    # vmcnt(0) into every K-step -- 35 % slower on every launch, and every test stayed green): no scratch, and the ring kernels' K loops keep
+    # their counted waits (the full drains that exist are in prologue / epilogue: 15 in the plain instantiations).
+    import re
+    def kernels(path):
+        txt = open(path).read()
+        for m in re.finditer(r"^(\w+):\s*; @\1\n(.*?)s_endpgm(.*?)\.end_amdhsa_kernel", txt, re.S | re.M):
+            yield m.group(1), m.group(2), m.group(3)
+    hot = {"conv.s": ("conv_split_kernel", "conv3x3_c64_kernel", "conv_glds_kernel", "conv_f16x3_kernel", "stem_pool"), "wgrad.s": ("wgrad_split_kernel", "wgrad_f16x3_kernel"),
+           "grouped_bwd.s": ("grouped_wgrad9_kernel",), "roi_align.s": ("roi_align_split",)}
+    seen = 0
+    for fname, keys in hot.items():
+        for name, body, meta in kernels(os.path.join(lst, fname)):
+            if not any(k in name for k in keys):
+                continue
+            seen += 1
+            scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+            assert scratch == 0 and "scratch_" not in body, f"{name}: {scratch} B of scratch in a hot kernel"
+            if "conv_split_kernel" in name and "ELi3ELi3E" not in name:      # plain instantiations (EPI 1 / 2); the fused tails (EPI 3) drain more in their epilogues
+                drains = sum(1 for l in body.split("\n") if "s_waitcnt vmcnt(0)" in l)
+                assert drains <= 16, f"{name}: {drains} full vmcnt drains (15 before: one inside the K loop would serialise the LDS-DMA ring)"
+    assert seen >= 40, seen
     # the scanner does find the form where it is known to be: box_infer.hip built WITH the SLP vectoriser (round 3's failing kernel)
     out = tmp_path / "box_infer_slp.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
