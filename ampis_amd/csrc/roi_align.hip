@@ -776,6 +776,10 @@ __global__ __launch_bounds__(256) void roi_align_split_tab_kernel(const RoiArgs 
 }
 
 
+// (Round 4, measured and removed: a ROW CACHE -- each lane keeps the decoded values of the last lower cell row it fetched, its own 8 channels of up to 4 or 5
+//  cells, in LDS (per-lane storage, no barrier) and takes the upper row of the next sample row from there instead of through the L1.  Bit-identical, and
+//  SLOWER: 780 against 682-777 us at P = 7 and 365 against 321 us at P = 14 with 4 cells (40 KB of LDS, four workgroups per CU still), 920-975 / 430 us with
+//  5 cells (three per CU): the two LDS round trips and the select per cell cost more than the L1 line they save.)
 // (A variant with a whole BIN ROW per half-wave -- box arithmetic and column tables shared by the P bins of a row, 28 % fewer VALU
 //  instructions -- was measured in round 3 and removed: faster when every tap is a cache hit (429 against 482 us at P = 7, 183 against 249 us
 //  at P = 14) but SLOWER on proposal-like boxes over the p2 / p3 maps (1020 against 767 us), and touching the next bin's cache lines ahead made
