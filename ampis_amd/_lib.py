@@ -116,6 +116,7 @@ def _declare(L):
         "amp_get_conv_mode": ([vp], i),
         "amp_conv_range_flag": ([vp, i, C.POINTER(C.c_int)], i),
         "amp_split_weights": ([vp, vp, C.c_longlong, i, vp], i),
+        "amp_bottleneck64_tail": ([vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, i, vp, vp], i),
         "amp_conv2d_grouped_nhwc": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, vp], i),
         "amp_conv2d_grouped_nhwc_fmt": ([vp, C.POINTER(ConvDesc), i, vp, vp, vp, vp, vp, vp, i], i),
         "amp_conv_wgrad_scratch_floats": ([C.POINTER(ConvDesc)], C.c_size_t),

@@ -215,6 +215,9 @@ int compact_dets_run(amp_ctx* ctx, int B, int D, const int* det_count, const flo
 // x_split: the input pixels are in preprocess_run's split form (16 B = 4 hi halves | 4 lo' halves)
 int stem_pool_run(amp_ctx* ctx, int B, int H, int W, const float* x, int x_split, const float* w_split, const float* scale, const float* shift,
                   float* pool, int pool_split);
+// conv.hip: conv2 + conv3 of a res2 bottleneck in one launch (conv3x3_c64_kernel<false, true>); 1 = does not apply (caller: two convolutions)
+int conv_c64_fused3_run(amp_ctx* ctx, int B, int H, int W, const float* x_split, const float* w2_split, const float* scale2, const float* shift2,
+                        const float* w3_split, const float* scale3, const float* shift3, int C3, const float* res_split, float* y_split);
 bool stem_pool_applies(amp_ctx* ctx, const float* w_split);     // would stem_pool_run launch the fused kernel (mode, switches)?
 bool stem_u8_applies(amp_ctx* ctx, const float* w_split);       // ... and straight from the uint8 image (stem_pool_u8_kernel: no preprocess pass)?
 int stem_pool_u8_run(amp_ctx* ctx, const uint8_t* img, int B, int H, int W, int Hp, int Wp, const float mean[3], const float std_[3],

@@ -1572,8 +1572,23 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
 // DIAG (groups of at most 32 channels): the 64 x 64 weight window is two 32 x 32 diagonal blocks -- LDS row blocks 0, 1 (channels 0-31 under swap_channel)
 // see only the first 32-channel half of the window, blocks 2, 3 only the second: the other half of the products is exactly zero and is not computed
 // (half the MFMAs and weight fragment reads; adding exact zeros changes no sum, so the result is the full product's bit for bit).
-template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes, const int tiles_x, const int tiles_y) {
+// FUSE3 (dense 64 -> 64 only: res2's conv2): the block's conv3 (1x1, 64 -> C3, FrozenBN, + residual, ReLU) runs in the same workgroup.  With the role-swapped MFMA
+// a lane holds, per tile row, channels [8 lq, 8 lq + 8) of each 32-channel half of conv2's output -- after FrozenBN, ReLU and the split exactly the B fragment
+// (pixel l15, k group lq) of a v_mfma_f32_16x16x32_f16 over that half: conv3's activation operand never leaves the registers, the 64-channel tensor t2 is
+// neither written nor read back (2 x 134 MB per res2 block at B = 8) and a launch disappears.  conv3's weights (C3 rows of 256 B) are staged once into the LDS the
+// patch and the tap buffers no longer need; every 64-channel chunk of the output goes through conv_epilogue_direct_rows (split residual, ReLU, split rows).
+// The halves are the ones the two-launch chain stores and reloads, the products and their order conv_split_kernel's: bit-identical to the chain.
+struct Fuse3Args {
+    const float* w3;        // [C3][64] split rows
+    const float* scale3;
+    const float* shift3;
+    const float* res;       // [M][C3] split rows
+    float* y;               // [M][C3] split rows
+    int C3;
+    unsigned int w3_bytes;
+};
+template <bool DIAG, bool FUSE3 = false>
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes, const int tiles_x, const int tiles_y, const Fuse3Args f3) {
     constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;      // 180 patch pixels
     constexpr int ROWF = 64;                                                        // floats per LDS row (256 B)
     constexpr int NINST = NPIX / 4;                                                 // 45 DMA instructions of 4 pixels x 16 chunks
@@ -1675,7 +1690,86 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(const ConvArgs a, c
         const int oy = oy0 + 2 * wave + i, ox = ox0 + l15;
         mrows[i] = (oy < a.Ho && ox < a.Wo) ? (b * a.Ho + oy) * a.Wo + ox : a.M;
     }
-    conv_epilogue_direct_rows<false, true, 2>(a, acc, lane, mrows, n0);
+    if constexpr (!FUSE3) {
+        conv_epilogue_direct_rows<false, true, 2>(a, acc, lane, mrows, n0);
+    } else {
+        // ---- conv2's epilogue in registers: FrozenBN, ReLU, split -> the B fragments of conv3 (what conv_epilogue_direct would have stored) ----
+        f16x8 t2h[2][2], t2l[2][2];
+        f32x2 chk = {0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f32x2 sc[4], sh[4];
+            const int n = 32 * g + 8 * lq;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                sc[p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
+                sh[p] = a.shift ? f32x2{a.shift[n + 2 * p], a.shift[n + 2 * p + 1]} : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4& blk = acc[i][2 * g + (p >> 1)];
+                    const f32x2 v = {blk[2 * (p & 1)], blk[2 * (p & 1) + 1]};
+                    chk = __builtin_elementwise_fma(v, f32x2{0.f, 0.f}, chk);
+                    f32x2 o = v * sc[p] + sh[p];
+                    if (a.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); }
+                    const f16x2 h = __builtin_convertvector(o, f16x2);
+                    const f32x2 hf = {(float)h[0], (float)h[1]};
+                    const f32x2 l = __builtin_elementwise_fma(hf, f32x2{-LO_SCALE, -LO_SCALE}, o * LO_SCALE);
+                    const f16x2 lh = __builtin_convertvector(l, f16x2);
+                    t2h[i][g][2 * p] = h[0]; t2h[i][g][2 * p + 1] = h[1];
+                    t2l[i][g][2 * p] = lh[0]; t2l[i][g][2 * p + 1] = lh[1];
+                }
+            }
+        }
+        if (!(chk[0] == 0.f) || !(chk[1] == 0.f)) atomicOr(a.range_flag, 1);
+        // ---- conv3's weights: C3 rows x 256 B into the LDS of the patch + tap buffers (everyone is past its last tap) ----
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f3.w3), 0, f3.w3_bytes, 0x00020000);
+        float* w3s = lds;
+        const int ninst3 = f3.C3 / 4;                    // 4 rows per DMA instruction
+        for (int it = wave; it < ninst3; it += 4) {
+            const int r = it * 4 + sub;
+            const int n = (r & ~63) + swap_channel(r & 63);
+            const unsigned int voff = (unsigned int)((size_t)n * 256 + (size_t)((chunk ^ (r & 15)) * 16));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(w3s + it * 4 * ROWF), 16, (int)voff, 0, 0, 0);
+        }
+        __syncthreads();
+        ConvArgs a3 = a;
+        a3.scale = f3.scale3; a3.shift = f3.shift3; a3.res = f3.res; a3.mask = nullptr; a3.y = f3.y;
+        a3.Cout = f3.C3; a3.relu = 1; a3.res_mode = 1; a3.res_split = 1; a3.y_split = 1; a3.out_mode = 0; a3.mask_split = 0;
+        for (int c = 0; c < f3.C3 / 64; ++c) {
+            f32x4 acc3[2][4], acx3[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc3[i][j][e] = 0.f; acx3[i][j][e] = 0.f; }
+            const float* wc = w3s + c * 64 * ROWF;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                F16x3Frags<2, 4> f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { f.ah[i] = t2h[i][g]; f.al[i] = t2l[i][g]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* row = wc + (j * 16 + l15) * ROWF;
+                    f.bh[j] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + lq) ^ l15));
+                    f.bl[j] = *reinterpret_cast<const f16x8*>(row + 4 * ((8 * g + 4 + lq) ^ l15));
+                }
+                f16x3_mfma16<2, 4, true>(f, acc3, acx3);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc3[i][j][e] = __fadd_rn(acc3[i][j][e], __fmul_rn(acx3[i][j][e], 1.0f / LO_SCALE));
+            conv_epilogue_direct_rows<false, true, 2>(a3, acc3, lane, mrows, 64 * c);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2887,8 +2981,9 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             // res2's dense 64 -> 64 layers and the ResNeXt conv2: a pixel patch staged once, nine taps read out of it (conv3x3_c64_kernel)
             const int tiles_x = amp::cdiv(a.Wo, 16), tiles_y = amp::cdiv(a.Ho, 8);
             a.ntn = a.Cout / 64; a.nblk = a.B * tiles_x * tiles_y * a.ntn;
-            if (a.grouped && cpg <= 32) AMP_TIMED_LAUNCH(conv3x3_c64_kernel<true>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
-            else AMP_TIMED_LAUNCH(conv3x3_c64_kernel<false>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
+            const Fuse3Args nofuse = Fuse3Args();
+            if (a.grouped && cpg <= 32) AMP_TIMED_LAUNCH(conv3x3_c64_kernel<true>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y, nofuse);
+            else AMP_TIMED_LAUNCH(conv3x3_c64_kernel<false>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y, nofuse);
         } else
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
@@ -2986,4 +3081,54 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
     }
     AMP_HIP_CHECK(hipGetLastError());
     return AMP_OK;
+}
+
+
+// conv2 (3x3, 64 -> 64, FrozenBN, ReLU) + conv3 (1x1, 64 -> C3, FrozenBN, + residual, ReLU) of a res2 bottleneck in one launch (conv3x3_c64_kernel<false, true>):
+// every operand in the split row format; returns 1 when the fused kernel does not apply (the caller launches the two convolutions).
+static int g_fuse23 = getenv("AMP_NO_FUSE23") ? 0 : 1;      // EXPERIMENT switch
+extern "C" void amp_debug_set_fuse23(int v) { g_fuse23 = v; }
+int amp::conv_c64_fused3_run(amp_ctx* ctx, int B, int H, int W, const float* x_split, const float* w2_split, const float* scale2, const float* shift2,
+                             const float* w3_split, const float* scale3, const float* shift3, int C3, const float* res_split, float* y_split) {
+    if (!g_fuse23 || g_patch_conv == 0 || !g_direct_epi || ctx->conv_mode != AMP_CONV_F16X3 || !w2_split || !w3_split) return 1;
+    if (C3 % 64 != 0 || C3 > 256 || B < 1 || H < 1 || W < 1) return 1;
+    const size_t x_bytes = (size_t)B * H * W * 64 * sizeof(float), w_bytes = (size_t)64 * 576 * sizeof(float), r_bytes = (size_t)B * H * W * C3 * sizeof(float);
+    const long long tiles = (long long)B * amp::cdiv(H, 8) * amp::cdiv(W, 16);
+    if (x_bytes >= (size_t)OOB_VOFF || r_bytes >= ((size_t)1 << 32) || (long long)B * H * W >= (1ll << 29) / 4 || (g_patch_conv != 2 && tiles < 512)) return 1;
+    ConvArgs a = ConvArgs();
+    a.x = x_split; a.w = w2_split; a.scale = scale2; a.shift = shift2;
+    a.B = B; a.H = H; a.W = W; a.Cin = 64; a.Cout = 64; a.KH = 3; a.KW = 3; a.stride = 1; a.pad = 1; a.Ho = H; a.Wo = W;
+    a.M = B * H * W; a.K = 576; a.nsteps = 18; a.cin_win = 64; a.grouped = 0;
+    a.relu = 1; a.in_scale = a.out_scale = 1.0f; a.y_split = 1; a.direct_epi = 1;
+    a.range_flag = ctx->d_conv_flag;
+    a.ntn = 1; a.nblk = (int)tiles;
+    set_fastdiv((unsigned int)(a.Ho * a.Wo), &a.div_howo_mul, &a.div_howo_shr);
+    set_fastdiv((unsigned int)a.Wo, &a.div_wo_mul, &a.div_wo_shr);
+    Fuse3Args f3;
+    f3.w3 = w3_split; f3.scale3 = scale3; f3.shift3 = shift3; f3.res = res_split; f3.y = y_split; f3.C3 = C3; f3.w3_bytes = (unsigned int)((size_t)C3 * 64 * sizeof(float));
+    amp_prof_rec* rec = nullptr;
+    if (ctx->prof_on) {
+        if (ctx->prof_used < ctx->prof_pool.size()) {
+            rec = &ctx->prof_pool[ctx->prof_used++];
+            rec->flops = 2.0 * (double)a.M * (64.0 * 576.0 + (double)C3 * 64.0);
+            rec->variant = 1;
+            rec->bytes = (double)x_bytes + (double)w_bytes + (double)f3.w3_bytes + 2.0 * (double)r_bytes;      // input + weights + residual + output (t2 is never in memory)
+            rec->M = a.M; rec->N = C3; rec->K = 576 + 64;
+        } else {
+            ctx->prof_truncated = true;
+        }
+    }
+    amp::ProfLaunchScope timed(rec ? rec->e0 : nullptr, rec ? rec->e1 : nullptr);
+    AMP_TIMED_LAUNCH((conv3x3_c64_kernel<false, true>), dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, amp::cdiv(W, 16), amp::cdiv(H, 8), f3);
+    AMP_HIP_CHECK(hipGetLastError());
+    return AMP_OK;
+}
+
+// C-ABI of the fused block tail (tests, and a host that drives res2 itself): all tensors split rows; AMP_ERR_STATE when the kernel does not apply.
+extern "C" int amp_bottleneck64_tail(amp_ctx* ctx, int B, int H, int W, const float* x_split, const float* w2_split, const float* scale2, const float* shift2,
+                                     const float* w3_split, const float* scale3, const float* shift3, int C3, const float* res_split, float* y_split) {
+    AMP_REQUIRE(ctx && x_split && w2_split && w3_split && res_split && y_split, "%s", "amp_bottleneck64_tail: null argument");
+    const int st = amp::conv_c64_fused3_run(ctx, B, H, W, x_split, w2_split, scale2, shift2, w3_split, scale3, shift3, C3, res_split, y_split);
+    if (st == 1) { amp::set_error("amp_bottleneck64_tail: the fused kernel does not apply (AMP_CONV_F16X3, C3 %% 64 == 0, C3 <= 256, >= 512 tiles of 8 x 16)"); return AMP_ERR_STATE; }
+    return st;
 }

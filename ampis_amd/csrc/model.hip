@@ -388,8 +388,17 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
                 // formats: the block's input / output and the shortcut follow native_all; t1 / t2 are split when their one consumer reads it
                 const bool t1s = reads_split(p + ".conv2"), t2s = reads_split(p + ".conv3");
                 AMP_TRY(launch_conv(m, CONV((p + ".conv1").c_str()), cur, B, ch, cw_, st1, 0, true, 0, nullptr, 0, t1, FMT(native_all, t1s, false)));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv2").c_str()), t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2, FMT(t1s, t2s, false)));
-                AMP_TRY(launch_conv(m, CONV((p + ".conv3").c_str()), t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out, FMT(t2s, native_all, native_all)));
+                // res2 (64 mid channels, frozen: the backward pass never reads its t2): conv2 + conv3 in one launch, t2 stays in registers
+                int fused23 = 1;
+                const ConvW &c2w = CONV((p + ".conv2").c_str()), &c3w = CONV((p + ".conv3").c_str());
+                if (s == 0 && t1s && t2s && native_all && st2 == 1 && c2w.groups == 1 && c2w.cin == 64 && c2w.cout == 64 && c2w.kh == 3 && c3w.cin == 64 && c3w.kh == 1 &&
+                    !m->split_stale && c2w.scale && c3w.scale)
+                    fused23 = amp::conv_c64_fused3_run(ctx, B, oh, ow, t1, c2w.w_split, c2w.scale, c2w.shift, c3w.w_split, c3w.scale, c3w.shift, c3w.cout, shortcut, out);
+                if (fused23 < 0) return fused23;
+                if (fused23 == 1) {
+                    AMP_TRY(launch_conv(m, c2w, t1, B, h1, w1, st2, 1, true, 0, nullptr, 0, t2, FMT(t1s, t2s, false)));
+                    AMP_TRY(launch_conv(m, c3w, t2, B, oh, ow, 1, 0, true, 1, shortcut, 0, out, FMT(t2s, native_all, native_all)));
+                }
             }
             (void)mark;
             if (m->saving) {

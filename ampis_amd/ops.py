@@ -74,6 +74,19 @@ def conv2d_nhwc(ctx, x, w, scale=None, shift=None, res=None, stride=1, pad=0, re
     return y
 
 
+def bottleneck64_tail(ctx, x_split, w2, scale2, shift2, w3, scale3, shift3, res_split):
+    """conv2 (3x3, 64 -> 64) + FrozenBN + ReLU + conv3 (1x1, 64 -> C3) + FrozenBN + shortcut + ReLU of a res2 block in one launch
+    (amp_bottleneck64_tail); x_split [B,H,W,64] and res_split [B,H,W,C3] split rows, w2 [64,3,3,64] / w3 [C3,1,1,64] fp32 -> y split rows."""
+    _f32c(x_split), _f32c(w2), _f32c(w3), _f32c(res_split)
+    B, H, W, _ = x_split.shape
+    C3 = w3.shape[0]
+    w2s, w3s = split_rows(ctx, w2.reshape(64, 576)), split_rows(ctx, w3.reshape(C3, 64))
+    y = torch.empty((B, H, W, C3), device=x_split.device, dtype=torch.float32)
+    check(lib().amp_bottleneck64_tail(ctx.handle, B, H, W, ptr(x_split), ptr(w2s), ptr(_f32c(scale2)), ptr(_f32c(shift2)), ptr(w3s), ptr(_f32c(scale3)),
+                                      ptr(_f32c(shift3)), C3, ptr(res_split), ptr(y)), "amp_bottleneck64_tail")
+    return y
+
+
 def conv2d_grouped_nhwc(ctx, x, w, groups, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, fmt=0):
     """Grouped conv (ResNeXt conv2): x [B,H,W,C], w [C,KH,KW,C/groups] (grouped OHWI) -> y [B,Ho,Wo,C].
     fmt: FMT_* bits (split-format x / y / res, AMP_CONV_F16X3 only)."""

@@ -162,6 +162,12 @@ enum { AMP_FMT_X_SPLIT = 1, AMP_FMT_Y_SPLIT = 2, AMP_FMT_RES_SPLIT = 4, AMP_FMT_
 int amp_conv2d_nhwc_fmt(amp_ctx* ctx, const amp_conv_desc* d, const float* x, const float* w, const float* scale, const float* shift,
                         const float* res, float* y, int fmt);
 int amp_unsplit_rows(amp_ctx* ctx, const float* x_split, long long rows, int C, float* out);
+/* The tail of a res2 bottleneck (detectron2 BottleneckBlock.forward, modeling/backbone/resnet.py: conv2 3x3 64 -> 64 + FrozenBN + ReLU, conv3 1x1
+ * 64 -> C3 + FrozenBN, + shortcut, ReLU) in ONE launch, every tensor in the split row format and the weights pre-split (amp_split_weights): conv2's
+ * output never reaches memory.  Bit-identical to the two amp_conv2d_nhwc_fmt calls it replaces.  AMP_ERR_STATE when it does not apply
+ * (not AMP_CONV_F16X3, C3 % 64 != 0 or > 256, fewer than 512 tiles of 8 x 16 pixels). */
+int amp_bottleneck64_tail(amp_ctx* ctx, int B, int H, int W, const float* x_split, const float* w2_split, const float* scale2, const float* shift2,
+                          const float* w3_split, const float* scale3, const float* shift3, int C3, const float* res_split, float* y_split);
 
 /* Stage a19: backward building blocks -------------------------------------------------------------------------------- */
 /* dW[Cout][KH][KW][Cin] (= or +=) scale[n] * conv-wgrad(dy [B*Ho*Wo, Cout], x [B,H,W,Cin]); `d` describes the FORWARD conv.

@@ -668,3 +668,69 @@ def test_patch_staged_3x3_over_a_64_channel_window_equals_the_implicit_gemm_kern
     ref = torch.relu(ref * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]).permute(0, 2, 3, 1)
     got = ops.unsplit_rows(gpu_ctx, outs[1]).double()
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 128, 256), (3, 61, 75, 256), (2, 72, 96, 128)])
+def test_fused_res2_block_tail_equals_the_two_launch_chain(gpu_ctx, shape):
+    """amp_bottleneck64_tail (round 4: conv3x3_c64_kernel<false, true>): conv2 + FrozenBN + ReLU + conv3 + FrozenBN + shortcut + ReLU in one launch,
+    conv2's output kept in registers as conv3's MFMA operand -- against the two amp_conv2d_nhwc_fmt launches on the same split operands: bit for
+    bit (the intermediate is the same pair of f16 halves the chain stores and reloads), on ragged image sizes, repeatably; and against fp64."""
+    import torch
+    from ampis_amd import _lib, ops
+    B, H, W, C3 = shape
+    torch.manual_seed(B * H + W)
+    x = torch.randn(B, H, W, 64, device="cuda")
+    res = torch.randn(B, H, W, C3, device="cuda")
+    w2 = torch.randn(64, 3, 3, 64, device="cuda") * 0.05
+    w3 = torch.randn(C3, 1, 1, 64, device="cuda") * 0.1
+    sc2, sh2 = torch.rand(64, device="cuda") + 0.5, torch.randn(64, device="cuda") * 0.1
+    sc3, sh3 = torch.rand(C3, device="cuda") + 0.5, torch.randn(C3, device="cuda") * 0.1
+    xs, rs = ops.split_rows(gpu_ctx, x), ops.split_rows(gpu_ctx, res)
+    S = ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT
+    t2 = ops.conv2d_nhwc(gpu_ctx, xs, w2, sc2, sh2, stride=1, pad=1, relu=True, fmt=S)
+    ref = ops.conv2d_nhwc(gpu_ctx, t2, w3, sc3, sh3, res=rs, stride=1, pad=0, relu=True, fmt=S | ops.FMT_RES_SPLIT)
+    L = _lib.lib()
+    L.amp_debug_set_patch_conv(2)           # the op-level shapes are below the 512-tile rule of the dispatch
+    try:
+        for _ in range(3):
+            y = ops.bottleneck64_tail(gpu_ctx, xs, w2, sc2, sh2, w3, sc3, sh3, rs)
+            torch.cuda.synchronize()
+            ndiff = int((y.view(torch.int32) != ref.view(torch.int32)).sum())
+            assert ndiff == 0, f"{ndiff} words differ"
+    finally:
+        L.amp_debug_set_patch_conv(1)
+    xd, rd = ops.unsplit_rows(gpu_ctx, xs).double().permute(0, 3, 1, 2), ops.unsplit_rows(gpu_ctx, rs).double().permute(0, 3, 1, 2)
+    a = torch.relu(torch.nn.functional.conv2d(xd, w2.double().permute(0, 3, 1, 2), padding=1) * sc2.double()[None, :, None, None] + sh2.double()[None, :, None, None])
+    b = torch.nn.functional.conv2d(a, w3.double().permute(0, 3, 1, 2)) * sc3.double()[None, :, None, None] + sh3.double()[None, :, None, None]
+    want = torch.relu(b + rd).permute(0, 2, 3, 1)
+    got = ops.unsplit_rows(gpu_ctx, y).double()
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
+    assert float(got.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 512, 640), (1, 1024, 1024)])
+def test_fused_res2_blocks_leave_the_trunk_bit_identical(gpu_ctx, B, H, W):
+    """The three res2 blocks with their conv2 + conv3 fused (amp_debug_set_fuse23(1), the default) against the two-launch chain (0): the res2 tap
+    bit for bit and identical detections, through the model's own launch path."""
+    from ampis_amd import params as P
+    from ampis_amd._lib import lib
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    K = 2
+    rng = np.random.default_rng(B * 1000 + H + W)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=40)
+    m.load_params(P.init_params(K, seed=3, style="spread"))
+    outs, taps = [], []
+    try:
+        for on in (1, 0):
+            lib().amp_debug_set_fuse23(on)
+            outs.append(m.infer(imgs, rle="counts"))
+            taps.append(m.tap("res2"))
+    finally:
+        lib().amp_debug_set_fuse23(1)
+    m.close()
+    assert float(np.abs(taps[0]).max()) > 0
+    assert np.array_equal(taps[0].view(np.uint32), taps[1].view(np.uint32))
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
