@@ -1216,7 +1216,9 @@ __device__ __forceinline__ void conv_epilogue_predict(const ConvArgs& a, f32x4 (
 // product right here: B = the predictor rows (16 outputs x 32 channels, split rows, straight from memory), 2 groups per wave, the four
 // N-waves' partial sums added through LDS in wave order, + bias -> pred [M][16].  Same operands as the separate 1x1 launch read from the
 // stored hidden tensor (the halves are identical), another summation order.  Replaces a 537 MB write + read at p2 and a launch per level.
-__device__ __forceinline__ void conv_epilogue_rpn(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0) {
+// row_of(i, r): the GEMM row (pixel) of row r (0..15) of the wave tile's 16-row block i, or a.M (or more) for a row outside the image
+template <class RowOf>
+__device__ __forceinline__ void conv_epilogue_rpn_rows(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int n0, RowOf row_of) {
     const int wm = wave >> 2, wn = wave & 3;
     const int l15 = lane & 15, lq = lane >> 4;
     const int nw0 = n0 + wn * 64;
@@ -1279,11 +1281,15 @@ __device__ __forceinline__ void conv_epilogue_rpn(const ConvArgs& a, f32x4 (&acc
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm * 64 + i * 16 + 4 * lq + e;
+                const int m = row_of(i, 4 * lq + e);
                 if (m < a.M) a.rpn_pred[(size_t)m * 16 + l15] = __fadd_rn(s[e], bias);
             }
         }
     }
+}
+__device__ __forceinline__ void conv_epilogue_rpn(const ConvArgs& a, f32x4 (&acc)[4][4], float* lds, int wave, int lane, int m0, int n0) {
+    const int mw0 = m0 + (wave >> 2) * 64;
+    conv_epilogue_rpn_rows(a, acc, lds, wave, lane, n0, [mw0](int i, int r) { return mw0 + i * 16 + r; });
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1301,6 +1307,9 @@ __device__ __forceinline__ void conv_epilogue_rpn(const ConvArgs& a, f32x4 (&acc
 // all workgroups: [wave][0] wait+barrier, [1] DMA issue, [2] fragment reads (issue + return), [3] MFMA issue, [4] whole loop,
 // [5] kernel entry -> loop, [6] loop end -> epilogue stores issued, [7] loop end -> past the final barrier.
 __device__ unsigned long long g_stamp[8 * 8];
+// [0] shader cycles (s_memtime) and [1] 100-MHz ticks (s_memrealtime) around the K loop of wave 0, summed over workgroups: the clock the chip held
+// in the loop = [0] / [1] * 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" item 6)
+__device__ unsigned long long g_stamp_clk[2];
 #define STAMP_T(var) const long long var = clock64()
 #define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
 #else
@@ -1460,6 +1469,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
     F16x3Frags<MB, NB> fr;
 #ifdef AMP_STAMP
     long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_mt0 = __builtin_amdgcn_s_memtime();
     const long long st_begin = clock64();
 #endif
     const float* As0 = lds + (wm * WTM + l15) * BK;
@@ -1519,6 +1529,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
         f16x3_mfma16<MB, NB, true>(fr, acc, acx);
     }
 #ifdef AMP_STAMP
+    if (wave == 0 && lane == 0) {
+        atomicAdd(&g_stamp_clk[0], __builtin_amdgcn_s_memtime() - st_mt0);
+        atomicAdd(&g_stamp_clk[1], __builtin_amdgcn_s_memrealtime() - st_rt0);
+    }
     st_acc[4] = clock64() - st_begin;
     st_acc[5] = st_begin - st_entry;
     const long long st_loop_end = clock64();
@@ -1554,6 +1568,250 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3x3_patch_kernel (round 4): the 3x3 stride-1 pad-1 convolutions of the FPN / RPN / res4 / res5 (Cin % 32 == 0, Cout % 256 == 0) with both
+// operands in the split row format -- conv_split_kernel<128, 256>'s loop (ring of three weight tiles filled by LDS-DMA two steps ahead, counted
+// vmcnt, bare barriers, the two halves of the workgroup one half-step apart), but the 128 GEMM rows of a workgroup are an 8 x 16 PIXEL tile and
+// the activation operand is not staged per K-step: the K order is channel-major (32-channel chunk c outside, tap inside) and the (8 + 2) x (16 + 2)
+// pixel patch of chunk c (180 pixels x 128 B, out-of-image pixels zero-filled by the buffer load) is staged ONCE for its nine taps -- tap (ky, kx)
+// of tile row y is the same fragment read at patch pixel (y + ky) * 18 + kx + column.  Per K-step a workgroup now moves 32 KB of weights plus a
+// ninth of 23 KB instead of 48 KB through the L2 -> LDS path, and an input pixel crosses it 1.4 times per N tile instead of nine: the implicit-GEMM
+// kernel's counter traffic was 2.6 x its algorithmic bytes on these layers (profiles/r04/traffic_per_launch_tap_major.txt), on a chip that holds
+// 1.84 GHz under this loop (tools/stamp_conv.py) because of the energy it draws.  LDS: 3 x 32 KB weight tiles + 2 x 23 KB patch chunks = 142 KB.
+// The patch of chunk c + 1 goes into the other patch buffer during the first three steps of chunk c (one 1-KB piece per wave and step, issued
+// behind the step's weight requests; the counted vmcnt in front of a step allows for them).
+// Same exact products as every AMP_CONV_F16X3 kernel, summed in conv_split_kernel<.., CHAN = true>'s order (bit-identical to it: AMP_KORDER=1).
+// ------------------------------------------------------------------------------------------------------------------
+template <int EPI>      // 1: split rows through conv_epilogue_direct_rows; 3: the fused RPN tail (conv_epilogue_rpn_rows)
+__global__ __launch_bounds__(512, 1) void conv3x3_patch_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes, const int tiles_x, const int tiles_y) {
+    constexpr int TH = 8, TW = 16, PW = TW + 2, NPIX = (TH + 2) * PW;            // 180 patch pixels
+    constexpr int NPIECE = 24;                                                      // DMA pieces of 8 rows x 128 B: 3 per wave (the last 12 rows are zero-filled padding: every wave issues the same number of requests)
+    constexpr int BT = 256 * BK;                                                    // floats per weight tile (32 KB)
+    constexpr int PT = NPIECE * 8 * BK;                                             // floats per patch chunk (23 KB)
+    constexpr int GB = 4;                                                           // weight DMA instructions per wave and step
+    static_assert(BK == 32, "128-B rows");
+    __shared__ __attribute__((aligned(16))) float lds[3 * BT + 2 * PT];
+    float* patch = lds + 3 * BT;
+#ifdef AMP_STAMP
+    const long long st_entry = clock64();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    int t = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int tile_n = t % a.ntn; t /= a.ntn;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = tile_n * 256;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+    const int srow = lane >> 3, spos = lane & 7;      // weight DMA: lane = (row of 8, 16-B position)
+    // ---- patch layout in LDS: CHUNK-MAJOR -- the 16-B piece p (0..7: hi 0-7, .., hi 24-31, lo' 0-7, ..) of patch pixel q at p * 3072 + q * 16 bytes
+    // (192 pixel slots per plane).  The 16 consecutive pixels a lane group reads for one fragment are then 256 contiguous bytes -- every bank once,
+    // whatever the alignment of the first pixel -- and a lane's address is (its own base) + (tap, tile row) * constant: the nine taps and four tile
+    // rows are immediate offsets of ds_read_b128, where a row-major swizzled patch cost ~8 VALU instructions per fragment, issued in the half-step
+    // in which the SIMD's other wave owns the vector issue with its MFMAs (stamps: 540 cycles of fragment reads per step against 251).
+    // DMA piece (wave w, j): plane p = w, pixels 64 j .. 64 j + 63 -- a lane fetches 16 B of its own pixel's row (the 8 waves read the same 64 rows).
+    unsigned int p_voff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = 64 * j + lane;
+        const int py = q / PW, px = q - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        const bool v = q < NPIX && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        p_voff[j] = v ? (unsigned int)(((size_t)(b * a.H + iy) * a.W + ix) * a.Cin * 4 + (size_t)(wave * 16)) : OOB_VOFF;
+    }
+    auto stage_patch = [&](int j, int c) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(patch + (c & 1) * PT + wave * 768 + j * 256), 16, (int)p_voff[j], c * (BK * 4), 0, 0);
+    };
+    unsigned int b_voff[GB];
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * 32 + 8 * g + srow;
+        const int n = n0 + (r & ~63) + swap_channel(r & 63);
+        b_voff[g] = (n < a.Cout) ? (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+    const int csteps = a.Cin / BK;
+    int s_c = 0, s_tap = 0;                  // the step being STAGED
+    auto stage_w = [&](int buf) {
+        const int soff = (s_tap * csteps + s_c) * (BK * 4);      // (reading the weights as [Cout][chunk][tap][32], consecutive lines step after step: no difference, measured)
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(lds + buf * BT + (wave * 32 + 8 * g) * BK), 16, (int)b_voff[g], soff, 0, 0);
+        if (++s_tap == 9) { s_tap = 0; ++s_c; }
+    };
+    f32x4 acc[4][4], acx[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+    const int qb = (4 * wm) * PW + l15;      // patch row of (tile row 4 wm, column l15) at tap (0, 0)
+
+#pragma unroll
+    for (int j = 0; j < 3; ++j) stage_patch(j, 0);
+    stage_w(0);
+    stage_w(1);
+    int cur = 0, nxt = 2;
+    int c_c = 0, c_tap = 0, c_toff = 0;      // the step being COMPUTED: chunk, tap, patch-row offset of the tap (ky * 18 + kx)
+#ifdef AMP_STAMP
+    long long st_vm = 0;
+#endif
+    auto open_step = [&](int step) {
+        // weight tile `step` (requested two steps ago) has landed once everything younger is all that is outstanding: the patch piece of step - 2
+        // (issued behind that tile's requests), the 4 weight requests of step - 1 and its patch piece -- counted exactly, an LDS-DMA request needs
+        // more than one step to land (the patch itself is requested six steps or more before its chunk begins)
+        if (step + 1 < a.nsteps) {
+            const int extra = (c_c + 1 < csteps) ? ((c_tap >= 1 && c_tap <= 3) ? 1 : 0) + ((c_tap >= 2 && c_tap <= 4) ? 1 : 0) : 0;
+            if (extra == 0) __builtin_amdgcn_s_waitcnt(0x0070 | GB);
+            else if (extra == 1) __builtin_amdgcn_s_waitcnt(0x0070 | (GB + 1));
+            else __builtin_amdgcn_s_waitcnt(0x0070 | (GB + 2));
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+#ifdef AMP_STAMP
+        st_vm = clock64();
+#endif
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    F16x3Frags<4, 4> fr;
+    const float* Pl = patch + qb * 4 + lq * 768;
+    auto load_frags = [&]() {
+        const float* P = Pl + ((c_c & 1) * PT + c_toff * 4);
+        const float* Bs = lds + cur * BT + (wn * 64 + l15) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fr.ah[i] = *reinterpret_cast<const f16x8*>(P + i * (PW * 4));
+            fr.al[i] = *reinterpret_cast<const f16x8*>(P + i * (PW * 4) + 4 * 768);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fr.bh[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo16_hi);
+            fr.bl[j] = *reinterpret_cast<const f16x8*>(Bs + j * 16 * BK + fo16_lo);
+        }
+    };
+    auto stage_next = [&](int step) {        // in compute step `step`: weight tile step + 2, then one piece of the next chunk's patch
+        if (step + 2 < a.nsteps) stage_w(nxt);
+        if (c_tap < 3 && c_c + 1 < csteps) stage_patch(c_tap, c_c + 1);
+    };
+    auto advance = [&]() {
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt = (nxt == 2) ? 0 : nxt + 1;
+        ++c_tap; ++c_toff;
+        if (c_tap == 3 || c_tap == 6) c_toff += PW - 3;
+        if (c_tap == 9) { c_tap = 0; c_toff = 0; ++c_c; }
+    };
+#ifdef AMP_STAMP
+    long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime(), st_mt0 = __builtin_amdgcn_s_memtime();
+    const long long st_begin = clock64();
+#endif
+    if (wave < 4) {
+        for (int step = 0; step < a.nsteps; ++step) {
+            STAMP_T(t0);
+            open_step(step);
+            STAMP_T(t1);
+            // the DMA requests in front of the fragment reads (the other way round in conv_split_kernel): this half reaches the second barrier ~200
+            // cycles before the multiplying half does, and every request issued earlier is a shorter vmcnt wait two steps on (-2 % on the layer)
+            stage_next(step);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t2);
+            load_frags();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t3);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(2, t2, t3); STAMP_ADD(3, t3, t4);
+#ifdef AMP_STAMP
+            st_acc[7] += st_vm - t0;
+            if (c_tap >= 3 && c_tap <= 5) st_acc[6] += t1 - t0;
+#endif
+            advance();
+        }
+    } else {
+        for (int step = 0; step < a.nsteps; ++step) {
+            STAMP_T(t0);
+            open_step(step);
+            STAMP_T(t1);
+            __builtin_amdgcn_s_setprio(1);
+            if (step > 0) f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            STAMP_T(t2);
+            stage_next(step);
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t3);
+            load_frags();
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP_T(t4);
+            STAMP_ADD(0, t0, t1); STAMP_ADD(3, t1, t2); STAMP_ADD(1, t2, t3); STAMP_ADD(2, t3, t4);
+#ifdef AMP_STAMP
+            st_acc[7] += st_vm - t0;
+            if (c_tap >= 3 && c_tap <= 5) st_acc[6] += t1 - t0;
+#endif
+            advance();
+        }
+        f16x3_mfma16<4, 4, true>(fr, acc, acx);
+    }
+#ifdef AMP_STAMP
+    if (wave == 0 && lane == 0) {
+        atomicAdd(&g_stamp_clk[0], __builtin_amdgcn_s_memtime() - st_mt0);
+        atomicAdd(&g_stamp_clk[1], __builtin_amdgcn_s_memrealtime() - st_rt0);
+    }
+    st_acc[4] = clock64() - st_begin;
+    st_acc[5] = st_begin - st_entry;
+    const long long st_loop_end = clock64();
+#endif
+    __syncthreads();
+
+    const bool scaled_in = a.out_scale != 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                if (scaled_in) acc[i][j][e] *= a.out_scale;
+            }
+    const int oyw = oy0 + 4 * wm;
+    if constexpr (EPI == 3) {
+        const int Ho = a.Ho, Wo = a.Wo, M = a.M;
+        conv_epilogue_rpn_rows(a, acc, lds, wave, lane, n0, [=](int i, int r) {
+            const int oy = oyw + i, ox = ox0 + r;
+            return (oy < Ho && ox < Wo) ? (b * Ho + oy) * Wo + ox : M;
+        });
+    } else {
+        // two tile rows at a time: the rows of an 8 x 16 tile are not consecutive GEMM rows, and four rows' hoisted residual + mask loads with
+        // their own addresses do not fit the 256 registers of a wave (312 B of scratch in the epilogue)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int mrows[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oy = oyw + 2 * h + i, ox = ox0 + l15;
+                mrows[i] = (oy < a.Ho && ox < a.Wo) ? (b * a.Ho + oy) * a.Wo + ox : a.M;
+            }
+            conv_epilogue_direct_rows<false, true, 2>(a, reinterpret_cast<f32x4 (&)[2][4]>(acc[2 * h]), lane, mrows, n0 + wn * 64);
+        }
+    }
+#ifdef AMP_STAMP
+    if (lane == 0)
+        for (int q = 0; q < 8; ++q) atomicAdd(&g_stamp[wave * 8 + q], (unsigned long long)st_acc[q]);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // conv3x3_c64_kernel (round 4): the 3x3 stride-1 convolution over a 64-channel WINDOW -- res2's dense 64 -> 64 layers and the grouped conv2
@@ -2375,11 +2633,24 @@ extern "C" int amp_debug_read_stamps(unsigned long long* out) {     // 64 values
     unsigned long long z[64] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
+extern "C" int amp_debug_read_stamp_clock(unsigned long long* out) {     // 2 values (g_stamp_clk); zeroes the device counters
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_clk), sizeof(unsigned long long) * 2) != hipSuccess) return -1;
+    unsigned long long z[2] = {0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_clk), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
 #endif
 static int g_direct_epi = getenv("AMP_DIRECT_EPI") ? atoi(getenv("AMP_DIRECT_EPI")) : 1;
 extern "C" void amp_debug_set_direct_epi(int v) { g_direct_epi = v; }
 static int g_korder = getenv("AMP_KORDER") ? atoi(getenv("AMP_KORDER")) : 0;     // EXPERIMENT switch: 1 = channel-major K order in conv_split_kernel (ConvArgs::korder)
 extern "C" void amp_debug_set_korder(int v) { g_korder = v; }
+// EXPERIMENT switch, default OFF: 1 = conv3x3_patch_kernel for the wide 3x3 layers (0: conv_split_kernel<128, 256>); 2 = whatever the grid size (tests).
+// Measured (round 4, tools/lab/time_conv.py, tools/lab/pmc_p256.sh): FETCH_SIZE per launch of the FPN output conv at p2 1.97 -> 0.44 M KiB, L2 misses
+// 35.7 -> 11.2 M -- and the SAME wall time on random operands (1410-1420 us either way; the chip holds 1.85 GHz under the ring kernel's loop and
+// 1.97-2.16 GHz under this one, which needs 2230 cycles per K-step against 1970): the layer is limited by the power the MFMAs draw, not by its
+// traffic; on all-zero operands (2.4 GHz either way) the ring kernel wins by the cycle ratio, 1049 against 1124 us.  And the channel-major sums move
+// one box of the full-size gate from 0.9e-3 to 1.01e-3 px off the fp32 oracle (bare tolerance 1e-3): not adopted.
+static int g_patch256 = getenv("AMP_PATCH256") ? atoi(getenv("AMP_PATCH256")) : 0;
+extern "C" void amp_debug_set_patch256(int v) { g_patch256 = v; }
 static int g_patch_conv = getenv("AMP_NO_PATCH_CONV") ? 0 : 1;      // EXPERIMENT switch: 0 = the implicit-GEMM kernels for the 64-channel-window 3x3 layers; 2 = conv3x3_c64_kernel whatever the grid size (tests)
 extern "C" void amp_debug_set_patch_conv(int v) { g_patch_conv = v; }
 static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
@@ -2975,6 +3246,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         // a split input that carries a 2^in_shift (scaled loss gradients): only the ring kernel undoes it (a.out_scale in its fold)
         AMP_REQUIRE(!(x_is_split && in_shift != 0) || (g_split_ring && epi != 0 && wide256 && a.out_mode != 3),
                     "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
+        const long long p256_tiles = (long long)a.B * amp::cdiv(a.Ho, 8) * amp::cdiv(a.Wo, 16) * (a.Cout / 256);
+        const bool patch256_ok = g_patch256 != 0 && x_is_split && g_split_ring && epi != 0 && !a.grouped && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 &&
+            a.Cin % 32 == 0 && a.Cin >= 64 && a.Cout % 256 == 0 && a.nsteps == 9 * (a.Cin / 32) &&
+            (a.out_mode == 4 || (a.out_mode == 0 && a.y_split && g_direct_epi && (!mask || a.mask_split) && (a.res_mode == 0 || (a.res_mode == 1 && a.res_split)))) &&
+            (g_patch256 == 2 || ((p256_tiles >= 512 || (p256_tiles >= 192 && a.nsteps >= 64)) && p256_tiles * 100 <= (long long)nblk256 * 108));
         if (g_patch_conv != 0 && x_is_split && a.y_split && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.cin_win == 64 && (a.grouped || (a.Cin == 64 && a.Cout == 64)) &&
             a.out_mode == 0 && a.res_mode == 0 && epi != 0 && g_direct_epi && (!mask || a.mask_split) && a.in_scale == 1.0f && a.Cout % 64 == 0 &&
             (g_patch_conv == 2 || (long long)a.B * amp::cdiv(a.Ho, 8) * amp::cdiv(a.Wo, 16) * (a.Cout / 64) >= 512)) {
@@ -2984,6 +3260,14 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             const Fuse3Args nofuse = Fuse3Args();
             if (a.grouped && cpg <= 32) AMP_TIMED_LAUNCH(conv3x3_c64_kernel<true>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y, nofuse);
             else AMP_TIMED_LAUNCH(conv3x3_c64_kernel<false>, dim3(a.nblk), dim3(256), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y, nofuse);
+        } else
+        if (patch256_ok) {
+            // FPN output / RPN / res4 / res5 3x3: 8 x 16 pixel tiles, the patch of a 32-channel chunk staged once for its nine taps (conv3x3_patch_kernel)
+            a.ntn = a.Cout / 256; a.nblk = (int)p256_tiles;
+            if (rec) rec->variant = 0;
+            const int tiles_x = amp::cdiv(a.Wo, 16), tiles_y = amp::cdiv(a.Ho, 8);
+            if (a.out_mode == 4) AMP_TIMED_LAUNCH(conv3x3_patch_kernel<3>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
+            else AMP_TIMED_LAUNCH(conv3x3_patch_kernel<1>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
         } else
         if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;

@@ -734,3 +734,88 @@ def test_fused_res2_blocks_leave_the_trunk_bit_identical(gpu_ctx, B, H, W):
     assert np.array_equal(taps[0].view(np.uint32), taps[1].view(np.uint32))
     for x, y in zip(outs[0], outs[1]):
         assert np.array_equal(x["boxes"], y["boxes"]) and np.array_equal(x["scores"], y["scores"])
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 64, 256, 256, False), (4, 127, 131, 128, 256, True), (4, 64, 64, 512, 512, False), (8, 96, 96, 64, 256, True), (1, 16, 16, 256, 256, False),
+                                   (3, 37, 51, 128, 256, True)])
+def test_patch_staged_wide_3x3_equals_the_channel_major_ring_kernel(gpu_ctx, shape):
+    """conv3x3_patch_kernel (round 4, AMP_PATCH256=1, not the default: the FPN / RPN / res4 / res5 3x3 layers on 8 x 16 pixel tiles, the patch of a
+    32-channel chunk staged once for its nine taps) against conv_split_kernel<128, 256, ., 3, CHAN = true> (amp_debug_set_korder(1)): the same exact products in the same
+    channel-major order -- bit for bit, with FrozenBN affine + ReLU, with a split residual, on sizes that are not multiples of the tile, with
+    two N tiles; against fp64; and close to the tap-major default (another summation order of the same products)."""
+    import torch
+    from ampis_amd import _lib, ops
+    B, H, W, Cin, Cout, with_res = shape
+    torch.manual_seed(B * H + W + Cin)
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda") * 0.03
+    sc, sh = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
+    xs = ops.split_rows(gpu_ctx, x)
+    kw = dict(stride=1, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+    res = None
+    if with_res:
+        res = torch.randn(B, H, W, Cout, device="cuda")
+        kw.update(res=ops.split_rows(gpu_ctx, res), res_mode=1, fmt=kw["fmt"] | ops.FMT_RES_SPLIT)
+    L = _lib.lib()
+    outs = {}
+    try:
+        for name, p256, korder in (("ring_chan", 0, 1), ("patch", 2, 0), ("ring_tap", 0, 0)):
+            L.amp_debug_set_patch256(p256)
+            L.amp_debug_set_korder(korder)
+            outs[name] = ops.conv2d_nhwc(gpu_ctx, xs, w, sc, sh, **kw).clone()
+            torch.cuda.synchronize()
+        L.amp_debug_set_patch256(2)
+        for _ in range(3):
+            y = ops.conv2d_nhwc(gpu_ctx, xs, w, sc, sh, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(y.view(torch.int32), outs["patch"].view(torch.int32))
+    finally:
+        L.amp_debug_set_patch256(0)
+        L.amp_debug_set_korder(0)
+    ntiles, nsteps = (B * H * W + 127) // 128 * (Cout // 256), 9 * Cin // 32
+    if ntiles >= 512 or (ntiles >= 192 and nsteps >= 64):          # the dispatch rule of the ring kernel (conv.hip wide256); smaller shapes: fp64 only
+        nd = int((outs["patch"].view(torch.int32) != outs["ring_chan"].view(torch.int32)).sum())
+        assert nd == 0, f"{nd} words differ from the channel-major ring kernel"
+        assert not torch.equal(outs["ring_chan"].view(torch.int32), outs["ring_tap"].view(torch.int32))       # the switch did switch the order
+    xd = ops.unsplit_rows(gpu_ctx, xs).double().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xd, w.double().permute(0, 3, 1, 2), padding=1) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    if with_res:
+        ref = ref + ops.unsplit_rows(gpu_ctx, kw["res"]).double().permute(0, 3, 1, 2)
+    ref = torch.relu(ref).permute(0, 2, 3, 1)
+    got = ops.unsplit_rows(gpu_ctx, outs["patch"]).double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
+    tap = ops.unsplit_rows(gpu_ctx, outs["ring_tap"]).double()
+    assert float((got - tap).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_patch_staged_wide_3x3_through_the_model(gpu_ctx):
+    """AMP_PATCH256=1 through the model's own launch path (FPN output convs, the RPN conv with its fused predictor tail -- conv_epilogue_rpn_rows on
+    8 x 16 pixel tiles --, res4 / res5): another summation order of the same products, so the same detections with boxes within 1e-3 px and
+    scores within 1e-5 of the default kernels', the RPN logits of level p2 within 2e-6 of their range."""
+    from ampis_amd import params as P
+    from ampis_amd._lib import lib
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    B, H, W, K = 2, 512, 640, 2
+    rng = np.random.default_rng(77)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=40)
+    m.load_params(P.init_params(K, seed=3, style="spread"))
+    outs, taps = [], []
+    try:
+        for on in (0, 2):
+            lib().amp_debug_set_patch256(on)
+            outs.append(m.infer(imgs, rle="counts"))
+            taps.append({k: m.tap(k) for k in ("p2", "p5", "rpn_pred2", "rpn_pred6")})
+    finally:
+        lib().amp_debug_set_patch256(0)
+    m.close()
+    for k in ("p2", "p5", "rpn_pred2", "rpn_pred6"):
+        a, b = taps[0][k], taps[1][k]
+        assert a.shape == b.shape and float(np.abs(a).max()) > 0
+        assert not np.array_equal(a, b)                                  # the other kernel did run
+        assert float(np.abs(a - b).max()) <= 5e-6 * float(np.abs(a).max()), k
+    for x, y in zip(outs[0], outs[1]):
+        assert len(x["boxes"]) == len(y["boxes"]) > 0
+        assert float(np.abs(x["boxes"] - y["boxes"]).max()) < 1e-3 and float(np.abs(x["scores"] - y["scores"]).max()) < 1e-5
+        assert np.array_equal(x["classes"], y["classes"])

@@ -7,7 +7,7 @@ from ampis_amd import ops, _lib
 
 LAYERS = {"res4.3x3": (8, 64, 64, 256, 256, 3, 1), "fpn.out.p2": (8, 256, 256, 256, 256, 3, 1), "fc1": (1, 1, 8000, 12544, 1024, 1, 0),
           "fpn.lat.p2": (8, 256, 256, 256, 256, 1, 0), "res4.1x1c": (8, 64, 64, 256, 1024, 1, 0),
-          "res2.1x1c": (8, 256, 256, 64, 256, 1, 0), "res3.1x1c": (8, 128, 128, 128, 512, 1, 0), "res4.3x3": (8, 64, 64, 256, 256, 3, 1)}
+          "res2.1x1c": (8, 256, 256, 64, 256, 1, 0), "deconv.gemm": (1, 560, 560, 256, 1024, 1, 0), "res3.1x1c": (8, 128, 128, 128, 512, 1, 0), "res4.3x3": (8, 64, 64, 256, 256, 3, 1)}
 
 def main():
     ctx = ops.torch_context(0)
@@ -26,6 +26,21 @@ def main():
             ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
         torch.cuda.synchronize()
         assert L.amp_debug_read_stamps(buf) == 0
+        if os.environ.get("AMP_STAMP_CLOCK"):      # the clock the chip holds in the K loop: >= 2 s of back-to-back launches on random data first
+            import time
+            clk = (ctypes.c_ulonglong * 2)()
+            t0 = time.time()
+            while time.time() - t0 < 2.5:
+                for _ in range(50):
+                    ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+                torch.cuda.synchronize()
+            assert L.amp_debug_read_stamp_clock(clk) == 0
+            for _ in range(200):
+                ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+            torch.cuda.synchronize()
+            assert L.amp_debug_read_stamp_clock(clk) == 0
+            print(f"{name}: in-loop clock {clk[0] / max(clk[1], 1) * 0.1:.3f} GHz (s_memtime / s_memrealtime over the K loop, 200 launches after 2.5 s of warm-up)")
+            assert L.amp_debug_read_stamps(buf) == 0
         n = 4
         ctx.timer_start()
         for _ in range(n):
@@ -36,6 +51,8 @@ def main():
         M = B * H * W
         nsteps = k * k * Cin // 32
         nwg = ((M + 127) // 128) * (Cout // 256)
+        if os.environ.get("AMP_STAMP_TILES") == "patch":      # conv3x3_patch_kernel: 8 x 16 pixel tiles
+            nwg = B * ((H + 7) // 8) * ((W + 15) // 16) * (Cout // 256)
         per = nwg * n * nsteps               # (wave slot, step) samples behind every counter
         print(f"{name}: {ms:.3f} ms, {2.0 * M * Cout * k * k * Cin / ms / 1e9:.0f} TFLOP/s, {nsteps} steps, {nwg} workgroups; cycles per step and wave:")
         print("   wave   wait+barrier   dma-issue   frag-reads   mfma-issue   | sum    loop/steps")
