@@ -59,6 +59,10 @@ def main():
         for wv in range(8):
             v = [buf[wv * 8 + q] / per for q in range(5)]
             pro, epi = buf[wv * 8 + 5] / (nwg * n), buf[wv * 8 + 6] / (nwg * n)
+            if os.environ.get("AMP_STAMP_TILES") == "patch":      # conv3x3_patch_kernel re-uses slots 6 / 7: the wait of the steps at taps 3..5, the vmcnt part of the wait
+                print(f"   {wv}      {v[0]:9.0f}   {v[1]:9.0f}   {v[2]:9.0f}   {v[3]:9.0f}      | {sum(v[:4]):6.0f}  {v[4]:6.0f}   per workgroup: prologue {pro:7.0f}  loop {v[4] * nsteps:8.0f}  "
+                      f"wait per step at taps 3..5 {buf[wv * 8 + 6] / (nwg * n) / (nsteps / 3):6.0f}, vmcnt part of the wait per step {buf[wv * 8 + 7] / per:6.0f}")
+                continue
             print(f"   {wv}      {v[0]:9.0f}   {v[1]:9.0f}   {v[2]:9.0f}   {v[3]:9.0f}      | {sum(v[:4]):6.0f}  {v[4]:6.0f}   per workgroup: prologue {pro:7.0f}  loop {v[4] * nsteps:8.0f}  epilogue {epi:7.0f} (of which final barrier {buf[wv * 8 + 7] / (nwg * n):6.0f})")
 
 main()
