@@ -1570,6 +1570,195 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, NSTAGE == 2 ? 2 : 1) vo
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// mask_tail_kernel (round 4): the mask head's tail -- ConvTranspose 2x2 s2 as a GEMM to (tap, co) = 4 x 256 columns, ReLU, the predictor row of the
+// detection's class, sigmoid -- with the FOUR taps of a 128-pixel block in ONE workgroup.  conv_split_kernel<128, 256, 3> ran one (pixel block, tap) tile
+// per workgroup: K = 256 is eight K-steps, so every workgroup paid a cold ring (3300 cycles per step against 1950 in steady state: each step waits for
+// its DMA), a prologue and an epilogue as long as the ideal loop for 5 us of MFMA work -- 17 us per tile (tools/stamp_conv.py deconv.gemm).  Here the ring
+// runs through all 32 K-steps: tap t + 1's first tiles are requested during tap t's last steps (the activation rows come out of the L2 the second time),
+// and a tap's epilogue needs no LDS staging: with the role-swapped MFMA a lane holds 16 channels of ONE pixel per row block -- the four 4-column groups
+// 8 (j >> 1) + 2 lq + (j & 1) of conv_epilogue_predict's lanes -- so its sums are that epilogue's sums in that epilogue's order (4 columns in turn, then the
+// xor tree 8, 4, 2, 1 over the groups: in-lane, lanes ^ 32, lanes ^ 16, in-lane; then the four N-waves in wave order through 2 KB of LDS behind the ring):
+// BIT-IDENTICAL probabilities.  The two halves of the workgroup (tile rows 0-63 / 64-127) exchange only within themselves, at the loop's own barriers.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 1) void mask_tail_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes) {
+    constexpr int BM = 128, BN = 256, NW = 8, GA = 2, GB = 4, NDMA = GA + GB, NTAP = 4;
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    // behind the ring: the N-waves' partial sums, the predictor rows of the (at most two) RoIs of the 128 pixels, their biases, the deconv's bias
+    __shared__ __attribute__((aligned(16))) float lds[3 * TILE_FLOATS + 4 * BM + 2 * 256 + 4 + NTAP * BN];
+    float* red = lds + 3 * TILE_FLOATS;                                   // [N-wave][128 rows]
+    float* wps = red + 4 * BM;                                            // [RoI slot][256 columns]
+    float* pbs = wps + 2 * 256;                                           // [RoI slot]
+    float* dbias = pbs + 4;                                               // [tap][256 columns]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int m0 = amp::xcd_remap(blockIdx.x, a.nblk) * BM;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned int a_voff[GA], b_voff[GB];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+        const int r = wave * (BM / NW) + 8 * g + srow;
+        const int m = m0 + r;
+        a_voff[g] = (m < a.M) ? (unsigned int)(((size_t)m * a.Cin + 4 * (spos ^ ((r >> 1) & 7))) * 4) : OOB_VOFF;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * (BN / NW) + 8 * g + srow;
+        const int n = (r & ~63) + swap_channel(r & 63);
+        b_voff[g] = (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4);
+    }
+    const int csteps = a.Cin / BK;                 // K-steps per tap (8)
+    const int total = NTAP * csteps;
+    const int tap_bytes = BN * a.K * 4;            // weight rows of one tap
+    int s_cs = 0, s_tap = 0;                       // the step being STAGED
+    auto stage = [&](int buf) {
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + BM * BK;
+        const int a_soff = s_cs * (BK * 4);
+        const int b_soff = s_tap * tap_bytes + s_cs * (BK * 4);
+#pragma unroll
+        for (int g = 0; g < GA; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK), 16, (int)a_voff[g], a_soff, 0, 0);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK), 16, (int)b_voff[g], b_soff, 0, 0);
+        if (++s_cs == csteps) { s_cs = 0; ++s_tap; }
+    };
+    f32x4 acc[4][4], acx[4][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    };
+    zero_acc();
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+    stage(0);
+    stage(1);
+    // the predictor rows of the block's RoIs (128 consecutive pixels of 196-pixel RoIs: at most two) and the deconv's bias go into LDS once, requested
+    // behind the first two tiles' DMA (the class-id load the row addresses wait for must not delay the staging)
+    const int mw0 = m0 + wm * 64;
+    const unsigned int b_first = fastdiv(min((unsigned int)m0, (unsigned int)(a.M - 1)), a.div_howo_mul, a.div_howo_shr);
+    {
+        const unsigned int b_last = fastdiv(min((unsigned int)(m0 + BM - 1), (unsigned int)(a.M - 1)), a.div_howo_mul, a.div_howo_shr);
+        const int slot = tid >> 8, col = tid & 255;
+        int c = a.pred_cls[slot ? b_last : b_first];
+        c = (c >= 0 && c < a.pred_K) ? c : 0;
+        wps[tid] = a.pred_w[(size_t)c * 256 + col];
+        if (col == 0) pbs[slot] = a.pred_b[c];
+        dbias[tid] = a.shift ? a.shift[tid] : 0.f;
+        dbias[512 + tid] = a.shift ? a.shift[512 + tid] : 0.f;
+    }
+    bool bad = false;
+    // a tap's sums of this wave: per tile row, the 64 columns of the wave against the RoI's predictor row -> red[wn][row]
+    auto partial_sums = [&](int tap) {
+        f32x4 bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = *reinterpret_cast<const f32x4*>(dbias + tap * BN + wn * 64 + 32 * (j >> 1) + 8 * lq + 4 * (j & 1));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int m = min((unsigned int)(mw0 + i * 16 + l15), (unsigned int)(a.M - 1));
+            const unsigned int b = fastdiv(m, a.div_howo_mul, a.div_howo_shr);
+            const float* wrow = wps + ((b == b_first) ? 0 : 256) + wn * 64 + 8 * lq;
+            float sj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 wp = *reinterpret_cast<const f32x4*>(wrow + 32 * (j >> 1) + 4 * (j & 1));
+                float sg = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                    bad = bad || !(fabsf(v) <= 3.0e38f);
+                    const float o = fmaxf(__fadd_rn(v, bias[j][e]), 0.f);
+                    sg = __fadd_rn(sg, __fmul_rn(o, wp[e]));
+                }
+                sj[j] = sg;
+            }
+            float u0 = __fadd_rn(sj[0], sj[2]), u1 = __fadd_rn(sj[1], sj[3]);      // xor 8 of the group index: j ^ 2, in the lane
+            u0 = __fadd_rn(u0, __shfl_xor(u0, 32)); u1 = __fadd_rn(u1, __shfl_xor(u1, 32));      // xor 4: lq ^ 2
+            u0 = __fadd_rn(u0, __shfl_xor(u0, 16)); u1 = __fadd_rn(u1, __shfl_xor(u1, 16));      // xor 2: lq ^ 1
+            const float sres = __fadd_rn(u0, u1);                                   // xor 1: j ^ 1, in the lane
+            if (lq == 0) red[wn * BM + wm * 64 + i * 16 + l15] = sres;
+        }
+    };
+    // ... and the end of a tap for the 64 rows of this half: one row per lane of its N-wave 0
+    auto finish_rows = [&](int tap) {
+        const int rl = wm * 64 + lane;
+        const int m = m0 + rl;
+        if (m < a.M) {
+            const unsigned int b = fastdiv((unsigned int)m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = (unsigned int)m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            float x = __fadd_rn(__fadd_rn(__fadd_rn(red[rl], red[BM + rl]), red[2 * BM + rl]), red[3 * BM + rl]);
+            x = __fadd_rn(x, pbs[(b == b_first) ? 0 : 1]);
+            const float p = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x)));
+            a.prob[((size_t)b * 2 * a.Ho + 2 * oy + (tap >> 1)) * (2 * a.Wo) + 2 * ox + (tap & 1)] = p;
+        }
+    };
+    int cur = 0, nxt = 2, c_cs = 0, c_tap = 0;      // ring positions; the step being COMPUTED
+    auto open_step = [&](int step) {
+        if (step + 1 < total) __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+        else __builtin_amdgcn_s_waitcnt(0x0070);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto advance = [&]() {
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt = (nxt == 2) ? 0 : nxt + 1;
+        if (++c_cs == csteps) { c_cs = 0; ++c_tap; }
+    };
+    F16x3Frags<4, 4> fr;
+    const float* As0 = lds + (wm * 64 + l15) * BK;
+    const float* Bs0 = lds + BM * BK + (wn * 64 + l15) * BK;
+    if (wave < NW / 2) {
+        for (int step = 0; step < total; ++step) {
+            open_step(step);
+            if (c_cs == 0 && c_tap > 0 && wn == 0) finish_rows(c_tap - 1);       // the previous tap's sums of this half: written before this barrier
+            f16x3_load16<4, 4>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < total) stage(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c_cs == csteps - 1) { partial_sums(c_tap); zero_acc(); }
+            advance();
+        }
+    } else {
+        for (int step = 0; step < total; ++step) {
+            open_step(step);
+            __builtin_amdgcn_s_setprio(1);
+            if (step > 0) f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool tap_done = c_cs == 0 && c_tap > 0;                         // the MFMAs above finished tap c_tap - 1
+            if (tap_done) { partial_sums(c_tap - 1); zero_acc(); __builtin_amdgcn_s_waitcnt(0xc07f); }
+            __builtin_amdgcn_s_barrier();
+            if (tap_done && wn == 0) finish_rows(c_tap - 1);
+            f16x3_load16<4, 4>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < total) stage(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+        }
+        f16x3_mfma16<4, 4, true>(fr, acc, acx);
+        partial_sums(NTAP - 1);
+    }
+    __syncthreads();
+    if (wn == 0) finish_rows(NTAP - 1);
+    if (bad) atomicOr(a.range_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // conv3x3_patch_kernel (round 4): the 3x3 stride-1 pad-1 convolutions of the FPN / RPN / res4 / res5 (Cin % 32 == 0, Cout % 256 == 0) with both
 // operands in the split row format -- conv_split_kernel<128, 256>'s loop (ring of three weight tiles filled by LDS-DMA two steps ahead, counted
 // vmcnt, bare barriers, the two halves of the workgroup one half-step apart), but the 128 GEMM rows of a workgroup are an 8 x 16 PIXEL tile and
@@ -2651,6 +2840,8 @@ extern "C" void amp_debug_set_korder(int v) { g_korder = v; }
 // one box of the full-size gate from 0.9e-3 to 1.01e-3 px off the fp32 oracle (bare tolerance 1e-3): not adopted.
 static int g_patch256 = getenv("AMP_PATCH256") ? atoi(getenv("AMP_PATCH256")) : 0;
 extern "C" void amp_debug_set_patch256(int v) { g_patch256 = v; }
+static int g_mask_tail_loop = getenv("AMP_NO_MASK_TAIL_LOOP") ? 0 : 1;      // EXPERIMENT switch: 0 = the fused mask-head tail on conv_split_kernel<128, 256, 3> (one tap per workgroup)
+extern "C" void amp_debug_set_mask_tail_loop(int v) { g_mask_tail_loop = v; }
 static int g_patch_conv = getenv("AMP_NO_PATCH_CONV") ? 0 : 1;      // EXPERIMENT switch: 0 = the implicit-GEMM kernels for the 64-channel-window 3x3 layers; 2 = conv3x3_c64_kernel whatever the grid size (tests)
 extern "C" void amp_debug_set_patch_conv(int v) { g_patch_conv = v; }
 static int g_stagger = getenv("AMP_STAGGER") ? atoi(getenv("AMP_STAGGER")) : 1;
@@ -3269,7 +3460,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             if (a.out_mode == 4) AMP_TIMED_LAUNCH(conv3x3_patch_kernel<3>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
             else AMP_TIMED_LAUNCH(conv3x3_patch_kernel<1>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
         } else
-        if (a.out_mode == 3) {                                               // fused mask-head tail: always the 128 x 256 ring kernel
+        if (a.out_mode == 3 && g_mask_tail_loop && a.Cin % BK == 0 && !a.korder) {     // fused mask-head tail: the four taps of a pixel block in one workgroup
+            a.ntn = 1; a.nblk = ntm;
+            if (rec) rec->variant = 0;
+            AMP_TIMED_LAUNCH(mask_tail_kernel, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (a.out_mode == 3) {                                        // ... one (pixel block, tap) tile per workgroup on the 128 x 256 ring kernel
             a.ntn = 4; a.nblk = ntm * 4;
             if (rec) rec->variant = 0;
             launch_split<128, 256>(a, 3, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);

@@ -819,3 +819,38 @@ def test_patch_staged_wide_3x3_through_the_model(gpu_ctx):
         assert len(x["boxes"]) == len(y["boxes"]) > 0
         assert float(np.abs(x["boxes"] - y["boxes"]).max()) < 1e-3 and float(np.abs(x["scores"] - y["scores"]).max()) < 1e-5
         assert np.array_equal(x["classes"], y["classes"])
+
+
+@pytest.mark.parametrize("B,H,W,dets", [(2, 512, 640, 40), (1, 384, 384, 7), (4, 512, 512, 100)])
+def test_mask_tail_with_four_taps_per_workgroup_is_bit_identical(gpu_ctx, B, H, W, dets):
+    """mask_tail_kernel (round 4: the fused deconv + ReLU + predictor + sigmoid with the four taps of a 128-pixel block in one workgroup, the ring
+    carried across the taps, the tap epilogue out of the role-swapped accumulators without LDS staging) against conv_split_kernel<128, 256, 3> + conv_epilogue_predict
+    (amp_debug_set_mask_tail_loop(0)): the same sums in the same order -- every mask probability bit for bit, on RoI counts whose pixel count is not a
+    multiple of the tile, repeatably; identical RLE masks."""
+    from ampis_amd import params as P
+    from ampis_amd._lib import lib
+    from ampis_amd.model import MaskRCNN
+    from test_e2e_gpu import synth_image
+    K = 3
+    rng = np.random.default_rng(B * 100 + dets)
+    imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
+    m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=dets)
+    m.load_params(P.init_params(K, seed=5, style="spread"))
+    outs, taps = [], []
+    try:
+        for on in (1, 0, 1):
+            lib().amp_debug_set_mask_tail_loop(on)
+            outs.append(m.infer(imgs, rle="counts"))
+            taps.append(m.tap("mask_prob"))
+    finally:
+        lib().amp_debug_set_mask_tail_loop(1)
+    m.close()
+    n = sum(len(o["boxes"]) for o in outs[0])
+    assert n > 0 and taps[0].shape[1:] == (28, 28)
+    p = taps[0][:n]
+    assert float(p.min()) >= 0.0 and float(p.max()) <= 1.0 and float(p.max() - p.min()) > 0.1
+    for k in (1, 2):
+        assert np.array_equal(taps[0][:n].view(np.uint32), taps[k][:n].view(np.uint32)), f"{int((taps[0][:n].view(np.uint32) != taps[k][:n].view(np.uint32)).sum())} probabilities differ"
+        for x, y in zip(outs[0], outs[k]):
+            assert np.array_equal(x["boxes"], y["boxes"]) and len(x["masks"]) == len(y["masks"])
+            assert all(np.array_equal(r["counts"], t["counts"]) for r, t in zip(x["masks"], y["masks"]))
