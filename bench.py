@@ -485,16 +485,32 @@ def main(args):
     log(f"rank {rank}/{world}: creating model")
     ctx = _lib.Context(local_rank)
     rccl = None
+    rccl_error = None
     if world > 1 and not staged:
         from ampis_amd.utils import comm
-        rccl = comm.attach_rccl(ctx)
+        try:
+            rccl = comm.attach_rccl(ctx)
+        except Exception as e:   # noqa: BLE001
+            rccl_error = f"{type(e).__name__}: {e}"[:300]
+        # the ranks agree over the side channel: one rank without a communicator puts every rank's timing collectives (barrier, max of the
+        # elapsed times -- the inference path has no data-path collective) on gloo, loudly; the training leg, whose gradient exchange IS RCCL,
+        # then reports an error object instead of a number and the line carries "rccl_error"
+        flag = torch.tensor([1 if rccl_error else 0])
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if int(flag.item()):
+            if rccl is not None:
+                comm.detach_rccl()
+                rccl = None
+            rccl_error = rccl_error or "another rank could not create its RCCL communicator"
+            log(f"rank {rank}: RCCL communicator NOT created ({rccl_error}); barrier / max-over-ranks fall back to gloo, the training leg is skipped")
+    if rccl is not None:
         # every rank says what it got, so that the first multi-GPU run explains itself from its log alone
         log(f"rank {rank}: RCCL communicator up (rank {rccl[0]} of {rccl[1]}, version {rccl[2]}, device {local_rank}"
             + (f", AMP_RCCL_LIB={os.environ['AMP_RCCL_LIB']} OVERRIDES librccl" if os.environ.get("AMP_RCCL_LIB") else "") + ")")
         if rccl[1] != world or rccl[0] != rank:
             log(f"rank {rank}: FATAL: the communicator has {rccl[1]} ranks (this is rank {rccl[0]}) but the job has {world} (this is rank {rank})")
             sys.exit(4)
-    ranks = Ranks(ctx, dev, world, staged)
+    ranks = Ranks(ctx, dev, world, staged or rccl_error is not None)
     model = MaskRCNN(ctx, K, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     params = P.init_params(K, seed=0, style="spread")
     model.load_params(params)
@@ -571,10 +587,11 @@ def main(args):
                        "batch_per_gpu": BATCH, "global_batch": BATCH * world, "image_size": [SIZE, SIZE],
                        "detections_per_image_mean": round(ndet / (args.steps * BATCH), 2),
                        "parallelism": f"image-parallel replicas x{world}, no data-path collective"
-                                      + (f"; barrier / max-over-ranks on RCCL {rccl[2]} through the C ABI" if rccl else "")},
+                                      + (f"; barrier / max-over-ranks on RCCL {rccl[2]} through the C ABI" if rccl else "")
+                                      + (f"; RCCL COMMUNICATOR NOT CREATED ({rccl_error}): barrier / max-over-ranks on gloo" if rccl_error else "")},
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_split_kernel<128x256> -- every launch of it and nothing else (tagged where it is launched: the 3x3 256->256 layers "
-                                    "of FPN / RPN / mask head / res4, fc1, the fused RPN and mask-head tails): implicit-GEMM conv on "
+                                    "of FPN / RPN / mask head / res4, fc1, the fused RPN tail; the fused mask-head tail is mask_tail_kernel since round 4 and not counted here): implicit-GEMM conv on "
                                     "v_mfma_f32_16x16x32_f16, 3 MFMAs per product, both operands pre-split and staged by LDS-DMA through a ring of "
                                     "three 48-KB tiles, the two waves of a SIMD ping-pong between loading and multiplying") if mode == "f16x3" else
                                    "conv_glds_kernel<128> (fp32 MFMA implicit-GEMM conv, 128x128x32 tiles, LDS-DMA staging)",
@@ -607,6 +624,8 @@ def main(args):
         if not emitted.acquire(blocking=False) or out is None:
             return
         out.update(extra)
+        if rccl_error:
+            out["rccl_error"] = rccl_error
         if strict is not None:
             out["f32_mfma_reference"] = strict
         if train_obj is not None:
@@ -641,7 +660,9 @@ def main(args):
                 extra["two_pipelines"] = two_pipelines_leg(local_rank, dev, rank, world, args.steps, ranks, params, imgs)
             except Exception as e:   # noqa: BLE001
                 extra["two_pipelines"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        if args.train_steps > 0:
+        if args.train_steps > 0 and rccl_error:
+            train_obj = {"error": f"not run: the gradient exchange needs the RCCL communicator ({rccl_error})"}
+        elif args.train_steps > 0:
             leg["name"] = "train"
             try:
                 train_obj = train_leg(ctx, model, dev, rank, world, args.train_warmup, args.train_steps, ranks)
