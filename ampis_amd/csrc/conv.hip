@@ -3460,7 +3460,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             if (a.out_mode == 4) AMP_TIMED_LAUNCH(conv3x3_patch_kernel<3>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
             else AMP_TIMED_LAUNCH(conv3x3_patch_kernel<1>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, tiles_x, tiles_y);
         } else
-        if (a.out_mode == 3 && g_mask_tail_loop && a.Cin % BK == 0 && !a.korder) {     // fused mask-head tail: the four taps of a pixel block in one workgroup
+        if (a.out_mode == 3 && g_mask_tail_loop && a.Cin % BK == 0 && !a.korder && a.Ho * a.Wo >= 128 /* a 128-pixel block spans at most two RoIs */) {     // fused mask-head tail: the four taps of a pixel block in one workgroup
             a.ntn = 1; a.nblk = ntm;      // (a kernel of its own: not tagged as a launch of the dominant kernel)
             AMP_TIMED_LAUNCH(mask_tail_kernel, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes);
         } else if (a.out_mode == 3) {                                        // ... one (pixel block, tap) tile per workgroup on the 128 x 256 ring kernel

@@ -25,6 +25,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip roofline.power_probe (the dominant layer on random and on all-zero operands)")
     ap.add_argument("--cpu-images", type=int, default=10)
     ap.add_argument("--train-steps", type=int, default=50, help="timed training steps of the secondary `train` object (0 = skip)")
     ap.add_argument("--train-warmup", type=int, default=10)
@@ -420,6 +421,36 @@ def host_inclusive_leg(model, imgs, dev, world, steps, ranks):
             "rle_strings_per_step": round(nm / steps, 1)}
 
 
+def power_probe_leg(ctx, dev):
+    """The dominant kernel on ONE of its layers (the FPN output conv at p2: B = 8, 256 x 256 pixels, 3x3 256 -> 256) with random operands and with
+    all-zero operands: the same instruction stream, the same bytes, without the data-dependent switching energy.  The gap between the two is what
+    the chip's power management takes (it holds ~1.8 of 2.4 GHz under this loop on random data, tools/stamp_conv.py); what is left to 833 TFLOP/s in the
+    zero-operand run is the loop itself.  A diagnostic beside `roofline`, never part of `value`."""
+    from ampis_amd import ops
+    Bp, Hp, Wp, Cp = BATCH, SIZE // 4, SIZE // 4, 256
+    flops = 2.0 * Bp * Hp * Wp * Cp * 9 * Cp
+    out = {"layer": f"3x3 {Cp}->{Cp}, stride 1, B={Bp} {Hp}x{Wp} (FPN output conv at p2), split operands in and out", "launches": 20}
+    sc, sh = torch.ones(Cp, device=dev), torch.zeros(Cp, device=dev)
+    for name in ("random", "zero"):
+        x = torch.randn(Bp, Hp, Wp, Cp, device=dev) if name == "random" else torch.zeros(Bp, Hp, Wp, Cp, device=dev)
+        w = torch.randn(Cp, 3, 3, Cp, device=dev) * 0.05 if name == "random" else torch.zeros(Cp, 3, 3, Cp, device=dev)
+        xs = ops.split_rows(ctx, x)
+        del x
+        run = lambda n: [ops.conv2d_nhwc(ctx, xs, w, sc, sh, stride=1, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT) for _ in range(n)]
+        run(10)
+        torch.cuda.synchronize(dev)
+        ctx.timer_start()
+        run(20)
+        ms = ctx.timer_stop() / 20
+        out[f"{name}_operands_us"] = round(ms * 1e3, 1)
+        out[f"{name}_operands_tflops"] = round(flops / ms / 1e9, 1)
+        del xs, w
+    out["zero_over_random"] = round(out["zero_operands_tflops"] / out["random_operands_tflops"], 3)
+    out["frac_of_peak_zero_operands"] = round(out["zero_operands_tflops"] / PEAK_F16X3_TFLOPS, 3)
+    torch.cuda.empty_cache()
+    return out
+
+
 def x101_leg(ctx, dev, rank, world, steps, ranks):
     """BASELINE configs[4] per GPU: X-101-32x8d-FPN inference on native 2048x2048 synthetic micrographs, 500 detections/image."""
     S, D, XB = 2048, 500, 2
@@ -638,7 +669,7 @@ def main(args):
     # collective that does not return (a rank died) is cut off by a watchdog that prints the headline and exits NON-ZERO, naming the leg.
     train_obj = None
     leg = {"name": None}
-    if args.train_steps > 0 or args.x101_steps > 0 or not args.no_two_pipelines or not args.no_host_inclusive:
+    if args.train_steps > 0 or args.x101_steps > 0 or not args.no_two_pipelines or not args.no_host_inclusive or not args.no_power_probe:
         def on_stall():
             msg = f"secondary leg '{leg['name']}' did not finish within {args.train_timeout} s"
             log(f"rank {rank}: {msg}; emitting the inference line without it and exiting with code 3")
@@ -648,6 +679,12 @@ def main(args):
         dog = threading.Timer(args.train_timeout, on_stall)
         dog.daemon = True
         dog.start()
+        if mode == "f16x3" and rank == 0 and out is not None and not args.no_power_probe:
+            leg["name"] = "power_probe"
+            try:
+                out["roofline"]["power_probe"] = power_probe_leg(ctx, dev)
+            except Exception as e:   # noqa: BLE001
+                out["roofline"]["power_probe"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_host_inclusive:
             leg["name"] = "host_inclusive"
             try:
