@@ -2809,6 +2809,11 @@ void set_fastdiv(unsigned int d, unsigned int* mul, int* shr) {
 
 static int g_f16x3_bn256 = 1;   // EXPERIMENT switch: 256-wide 8-wave tiles where Cout % 256 == 0
 extern "C" void amp_debug_set_f16x3_bn256(int v) { g_f16x3_bn256 = v; }
+// one round of 128 x 256 tiles (192 ... 511 of them) is taken from this many K-steps on.  Round 4 measured the alternative's bound -- two 128 x 128 workgroups
+// per CU move 64 KB per 1536 MFMA cycles through an L2 -> LDS path that gives a CU ~33 B/clk -- and AMP_WIDE_NSTEPS=16: res4's conv1 (M = 32768, K = 1024)
+// 54 -> 49 us, fc2 55 -> 47 us, res4.0 conv1 32 -> 29 us in the per-launch table (bit-identical), 506.3 / 507.7 against 509.0 / 506.0 images/s for the step:
+// nothing outside the noise, so the rule stays at 64
+static int g_wide_nsteps = getenv("AMP_WIDE_NSTEPS") ? atoi(getenv("AMP_WIDE_NSTEPS")) : 64;
 static int g_short_k_steps = getenv("AMP_SHORT_K_STEPS") ? atoi(getenv("AMP_SHORT_K_STEPS")) : 16;     // K <= 512 (2: K <= 64 only)
 static int g_short_k = getenv("AMP_NO_SHORT_K") ? 0 : 1;      // EXPERIMENT switch: K <= 64 layers on 128 x 128 tiles, two workgroups per CU (0: the 128 x 256 ring tiles)
 extern "C" void amp_debug_set_short_k(int v) { g_short_k = v; }
@@ -3432,7 +3437,7 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         // 256-wide tiles (8 waves, one workgroup per CU) when they fill the chip twice -- or once, if the K loop is long enough to
         // amortise a single round (fc1: M = 8000, K = 12544: 64-wide tiles re-read the 400 MB activation matrix from HBM)
         const int nblk256 = (a.Cout % 256 == 0) ? ntm * (a.Cout / 256) : 0;
-        const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= 64));
+        const bool wide256 = g_f16x3_bn256 && !a.grouped && !stem && (nblk256 >= 512 || (nblk256 >= 192 && a.nsteps >= g_wide_nsteps));
         const int ntm256 = amp::cdiv(a.M, 256);
         // a split input that carries a 2^in_shift (scaled loss gradients): only the ring kernel undoes it (a.out_scale in its fold)
         AMP_REQUIRE(!(x_is_split && in_shift != 0) || (g_split_ring && epi != 0 && wide256 && a.out_mode != 3),
