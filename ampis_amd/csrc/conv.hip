@@ -459,7 +459,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // this lane in row block i (any value >= a.M: not stored) -- consecutive rows for the GEMM tiles, rows of a 2-D pixel patch for the patch kernel
 template <bool SPATIAL, bool CHECK, int MBR>
 __device__ __forceinline__ void conv_epilogue_direct_rows(const ConvArgs& a, f32x4 (&acc)[MBR][4], int lane, const int (&mrow_in)[MBR], int nw0) {
-    const int l15 = lane & 15, lq = lane >> 4;
+    const int lq = lane >> 4;
     const bool has_res = a.res_mode != 0, has_mask = a.mask != nullptr;
     const bool deconv = SPATIAL && a.out_mode == 1;
     const int C2 = a.Cout >> 2;
