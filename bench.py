@@ -360,7 +360,7 @@ def two_pipelines_leg(local_rank, dev, rank, world, steps, ranks, params, imgs):
     step, bit-identical results (tests/test_pipeline_gpu.py) -- only consecutive batches overlap, which is how a serving process runs.
     (Splitting ONE call into micro-batches on several streams does not help: tools/exp_halfbatch.py)"""
     from ampis_amd.model import InferPipeline
-    depth = 2
+    depth = int(os.environ.get("AMP_BENCH_PIPE_DEPTH", "2"))      # (3 in flight: measured, no better than 2 -- DESIGN §6)
     pipe = InferPipeline(local_rank, K, depth=depth, max_batch=BATCH, max_h=SIZE, max_w=SIZE, max_out_hw=SIZE, detections_per_image=DETS)
     pipe.load_params(params)
     c = _lib.Context(local_rank)
@@ -396,7 +396,7 @@ def two_pipelines_leg(local_rank, dev, rank, world, steps, ranks, params, imgs):
         pipe.close()
         c.free(d)
         c.close()
-    return {"what": "same workload, two batches of 8 in flight per GPU: amp_pipeline depth 2 (one handle, one calling thread; every batch's results on the host inside the timed region)",
+    return {"what": f"same workload, {depth} batches of 8 in flight per GPU: amp_pipeline depth {depth} (one handle, one calling thread; every batch's results on the host inside the timed region)",
             "value": round(world * BATCH * n / el, 3), "unit": "images/s", "steps": n, "pipeline_depth": depth,
             "ms_per_step": round(el / n * 1e3, 3), "detections_per_image_mean": round(nd / (n * BATCH), 2)}
 
