@@ -670,7 +670,7 @@ def test_patch_staged_3x3_over_a_64_channel_window_equals_the_implicit_gemm_kern
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 128, 256), (3, 61, 75, 256), (2, 72, 96, 128)])
+@pytest.mark.parametrize("shape", [(2, 64, 128, 256), (3, 61, 75, 256), (2, 72, 96, 128), (1, 9, 17, 64), (1, 8, 16, 192)])
 def test_fused_res2_block_tail_equals_the_two_launch_chain(gpu_ctx, shape):
     """amp_bottleneck64_tail (round 4: conv3x3_c64_kernel<false, true>): conv2 + FrozenBN + ReLU + conv3 + FrozenBN + shortcut + ReLU in one launch,
     conv2's output kept in registers as conv3's MFMA operand -- against the two amp_conv2d_nhwc_fmt launches on the same split operands: bit for
@@ -821,8 +821,8 @@ def test_patch_staged_wide_3x3_through_the_model(gpu_ctx):
         assert np.array_equal(x["classes"], y["classes"])
 
 
-@pytest.mark.parametrize("B,H,W,dets", [(2, 512, 640, 40), (1, 384, 384, 7), (4, 512, 512, 100)])
-def test_mask_tail_with_four_taps_per_workgroup_is_bit_identical(gpu_ctx, B, H, W, dets):
+@pytest.mark.parametrize("B,H,W,dets,K", [(2, 512, 640, 40, 3), (1, 384, 384, 7, 3), (4, 512, 512, 100, 3), (1, 256, 320, 1, 80), (2, 320, 256, 33, 80)])
+def test_mask_tail_with_four_taps_per_workgroup_is_bit_identical(gpu_ctx, B, H, W, dets, K):
     """mask_tail_kernel (round 4: the fused deconv + ReLU + predictor + sigmoid with the four taps of a 128-pixel block in one workgroup, the ring
     carried across the taps, the tap epilogue out of the role-swapped accumulators without LDS staging) against conv_split_kernel<128, 256, 3> + conv_epilogue_predict
     (amp_debug_set_mask_tail_loop(0)): the same sums in the same order -- every mask probability bit for bit, on RoI counts whose pixel count is not a
@@ -831,7 +831,6 @@ def test_mask_tail_with_four_taps_per_workgroup_is_bit_identical(gpu_ctx, B, H, 
     from ampis_amd._lib import lib
     from ampis_amd.model import MaskRCNN
     from test_e2e_gpu import synth_image
-    K = 3
     rng = np.random.default_rng(B * 100 + dets)
     imgs = np.stack([synth_image(rng, H, W) for _ in range(B)])
     m = MaskRCNN(gpu_ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), detections_per_image=dets)
