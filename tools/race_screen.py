@@ -75,6 +75,60 @@ def main():
                     mism += 1
             print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
             bad += mism
+        # round 4: the fused res2 tail (conv3x3_c64_kernel<false, true>: patch + two weight buffers by LDS-DMA, conv3's weights staged into the dead patch)
+        for name, B, H, W, C3 in (("res2 tail 64->64->256 @128x160", 4, 128, 160, 256), ("res2 tail, ragged 61x75, 128 outputs", 3, 61, 75, 128)):
+            g = torch.Generator().manual_seed(B + H + C3)
+            xs = ops.split_rows(ctx, torch.randn(B, H, W, 64, generator=g).cuda())
+            rs = ops.split_rows(ctx, torch.randn(B, H, W, C3, generator=g).cuda())
+            w2, w3 = (torch.randn(64, 3, 3, 64, generator=g) * 0.05).cuda(), (torch.randn(C3, 1, 1, 64, generator=g) * 0.1).cuda()
+            sc2, sh2 = torch.rand(64, generator=g).cuda() + 0.5, torch.randn(64, generator=g).cuda() * 0.1
+            sc3, sh3 = torch.rand(C3, generator=g).cuda() + 0.5, torch.randn(C3, generator=g).cuda() * 0.1
+            _lib.lib().amp_debug_set_patch_conv(2)
+            first = ops.bottleneck64_tail(ctx, xs, w2, sc2, sh2, w3, sc3, sh3, rs).clone()
+            torch.cuda.synchronize()
+            mism = 0
+            for _ in range(reps):
+                y = ops.bottleneck64_tail(ctx, xs, w2, sc2, sh2, w3, sc3, sh3, rs)
+                torch.cuda.synchronize()
+                mism += int(not torch.equal(y.view(torch.int32), first.view(torch.int32)))
+            _lib.lib().amp_debug_set_patch_conv(1)
+            print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
+            bad += mism
+        # ... the patch-staged wide 3x3 (conv3x3_patch_kernel, AMP_PATCH256: two patch buffers + ring of three weight tiles, counted vmcnt with patch pieces in the queue)
+        for name, B, H, W, Cin, Cout in (("patch256 3x3 256->256 @64", 8, 64, 64, 256, 256), ("patch256 3x3 128->256, ragged 37x51", 3, 37, 51, 128, 256), ("patch256 3x3 512->512 @32", 4, 32, 32, 512, 512)):
+            g = torch.Generator().manual_seed(Cin + Cout + H)
+            x = ops.split_rows(ctx, torch.randn(B, H, W, Cin, generator=g).cuda())
+            w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.03).cuda()
+            sc, sh = torch.rand(Cout, generator=g).cuda() + 0.5, torch.randn(Cout, generator=g).cuda()
+            kw = dict(stride=1, pad=1, relu=True, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+            _lib.lib().amp_debug_set_patch256(2)
+            first = ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw).clone()
+            torch.cuda.synchronize()
+            mism = 0
+            for _ in range(reps):
+                y = ops.conv2d_nhwc(ctx, x, w, sc, sh, **kw)
+                torch.cuda.synchronize()
+                mism += int(not torch.equal(y.view(torch.int32), first.view(torch.int32)))
+            _lib.lib().amp_debug_set_patch256(0)
+            print(f"{name:52s} {reps} repetitions, {mism} mismatches", flush=True)
+            bad += mism
+        # ... and the mask head's tail through the model (mask_tail_kernel: ring carried across four taps, the halves' sums exchanged at the loop's barriers)
+        import numpy as np
+        from ampis_amd import params as P, synth
+        from ampis_amd.model import MaskRCNN
+        Bm, S = 4, 512
+        imgs, _ = synth.batch(Bm, S, S, first_index=3)
+        m = MaskRCNN(ctx, 2, max_batch=Bm, max_h=S, max_w=S, max_out_hw=S, detections_per_image=100)
+        m.load_params(P.init_params(2, seed=0, style="spread"))
+        m.infer(imgs, rle="counts")
+        first_p, first_r = m.tap("mask_prob").copy(), m.tap("res2").copy()
+        mism = 0
+        for _ in range(max(20, reps // 4)):
+            m.infer(imgs, rle="counts")
+            mism += int(not (np.array_equal(m.tap("mask_prob").view(np.uint32), first_p.view(np.uint32)) and np.array_equal(m.tap("res2").view(np.uint32), first_r.view(np.uint32))))
+        m.close()
+        print(f"{'model: mask_prob + res2 taps, B=4 512x512':52s} {max(20, reps // 4)} repetitions, {mism} mismatches", flush=True)
+        bad += mism
     finally:
         stop.set()
         th.join()
