@@ -457,10 +457,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // through LDS (1048 us at 1.96 TB/s before).
 // MBR row blocks of 16 per wave tile (4: the 64 x 64 wave tiles of conv_split_kernel; 2: conv3x3_c64_kernel); mrow_in[i] + (nothing): the GEMM row of
 // this lane in row block i (any value >= a.M: not stored) -- consecutive rows for the GEMM tiles, rows of a 2-D pixel patch for the patch kernel
-template <bool SPATIAL, bool CHECK, int MBR>
-__device__ __forceinline__ void conv_epilogue_direct_rows(const ConvArgs& a, f32x4 (&acc)[MBR][4], int lane, const int (&mrow_in)[MBR], int nw0) {
+// AFFINE_LDS: scale / shift come from LDS copies indexed by the channel relative to nrel0 (conv1x1_nloop_kernel: a global load between two K-steps
+// would wait for the ring's prefetched tiles -- vector-memory operations retire in order)
+// PLAIN: the layer has neither residual nor mask, known at compile time -- behind a RUN-TIME "has residual" branch the compiler waits for the branch's
+// loads with vmcnt(0) at the join, on both paths, which inside conv1x1_nloop_kernel's loop would drain the ring at every tile
+template <bool SPATIAL, bool CHECK, int MBR, bool AFFINE_LDS = false, bool PLAIN = false>
+__device__ __forceinline__ void conv_epilogue_direct_rows(const ConvArgs& a, f32x4 (&acc)[MBR][4], int lane, const int (&mrow_in)[MBR], int nw0,
+                                                          const float* lsc = nullptr, const float* lsh = nullptr, int nrel0 = 0) {
     const int lq = lane >> 4;
-    const bool has_res = a.res_mode != 0, has_mask = a.mask != nullptr;
+    const bool has_res = !PLAIN && a.res_mode != 0, has_mask = !PLAIN && a.mask != nullptr;
     const bool deconv = SPATIAL && a.out_mode == 1;
     const int C2 = a.Cout >> 2;
     const int tap = deconv ? nw0 / C2 : 0, ncol0 = deconv ? nw0 - tap * C2 : nw0;      // column of this wave inside an output row
@@ -474,8 +479,14 @@ __device__ __forceinline__ void conv_epilogue_direct_rows(const ConvArgs& a, f32
         colb[g] = (size_t)(nc >> 5) * 128 + (size_t)(nc & 31) * 2;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            sc[g][p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
-            sh[g][p] = a.shift ? f32x2{a.shift[n + 2 * p], a.shift[n + 2 * p + 1]} : f32x2{0.f, 0.f};
+            if constexpr (AFFINE_LDS) {
+                const int nr = nrel0 + 32 * g + 8 * lq + 2 * p;
+                sc[g][p] = f32x2{lsc[nr], lsc[nr + 1]};
+                sh[g][p] = f32x2{lsh[nr], lsh[nr + 1]};
+            } else {
+                sc[g][p] = a.scale ? f32x2{a.scale[n + 2 * p], a.scale[n + 2 * p + 1]} : f32x2{1.f, 1.f};
+                sh[g][p] = a.shift ? f32x2{a.shift[n + 2 * p], a.shift[n + 2 * p + 1]} : f32x2{0.f, 0.f};
+            }
         }
     }
     f32x2 chk = {0.f, 0.f};
@@ -1759,6 +1770,170 @@ __global__ __launch_bounds__(512, 1) void mask_tail_kernel(const ConvArgs a, con
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// conv1x1_nloop_kernel (round 4): the short-K 1x1 layers that run one 128 x 256 tile per CU (stride-2 shortcuts, conv1 of a stage's first block, their
+// data gradients, the mask head's deconv in a training step: K = 64 ... 512, two to sixteen K-steps) with SEVERAL N tiles of a 128-pixel block in one
+// workgroup -- mask_tail_kernel's loop with conv_epilogue_direct_rows as the tile epilogue.  A workgroup of conv_split_kernel pays a cold ring, a prologue and
+// an epilogue per tile for 5 us of MFMA work (K = 256); here the ring runs on across the tiles (tile t + 1's first weight tiles and the pixel block's rows,
+// now in the L2, are requested during tile t's last steps) and a half's epilogue -- loads of residual / mask, 16 stores per wave -- sits between two steps.
+// Those stores are YOUNGER than the requests already in flight, so the counted wait in front of a step allows for them exactly where they are in the queue:
+//   early half (epilogue after the last MFMAs of step e):   step e + 1 needs D(e+1); younger: D(e+2), E      -> vmcnt(6 + 16)
+//                                                            step e + 2 needs D(e+2); younger: E, D(e+3)      -> vmcnt(6 + 16)
+//   late half  (epilogue in step e + 1, before its requests): step e + 1 needs D(e+1); younger: D(e+2)         -> vmcnt(6)
+//                                                            step e + 2 needs D(e+2); younger: E, D(e+3)      -> vmcnt(6 + 16)
+// and vmcnt(6) from then on (which also retires E).  16 is a LOWER bound on a full tile's stores (more younger operations only make the wait stricter);
+// a partial tile (rows beyond M: stores skipped) waits with vmcnt(6).  Same products, same order, same epilogue: bit-identical to conv_split_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool SPATIAL>
+__global__ __launch_bounds__(512, 1) void conv1x1_nloop_kernel(const ConvArgs a, const unsigned int x_bytes, const unsigned int w_bytes, const int NT) {
+    constexpr int BM = 128, BN = 256, NW = 8, GA = 2, GB = 4, NDMA = GA + GB, NST = 16;
+    constexpr int TILE_FLOATS = (BM + BN) * BK;
+    constexpr int NT_MAX = 8;                      // scale + shift of NT_MAX * 256 channels: the 16 KB behind the ring
+    __shared__ __attribute__((aligned(16))) float lds[3 * TILE_FLOATS + 2 * NT_MAX * BN];
+    float* lsc = lds + 3 * TILE_FLOATS;
+    float* lsh = lsc + NT_MAX * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ngrp = a.ntn / NT;                   // groups of NT consecutive N tiles
+    const int wg = amp::xcd_remap(blockIdx.x, a.nblk);
+    const int grp = wg % ngrp;
+    const int m0 = (wg / ngrp) * BM;
+    const int n_first = grp * NT * BN;
+    const bool full = m0 + BM <= a.M;
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_bytes, 0x00020000);
+    const int srow = lane >> 3, spos = lane & 7;
+    unsigned int a_voff[GA], b_voff[GB];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+        const int r = wave * (BM / NW) + 8 * g + srow;
+        const int m = m0 + r;
+        a_voff[g] = OOB_VOFF;
+        if (m < a.M) {                             // 1x1, pad 0: output pixel (b, oy, ox) reads input pixel (oy, ox) * stride
+            const unsigned int b = fastdiv((unsigned int)m, a.div_howo_mul, a.div_howo_shr);
+            const unsigned int rem = (unsigned int)m - b * (unsigned int)(a.Ho * a.Wo);
+            const unsigned int oy = fastdiv(rem, a.div_wo_mul, a.div_wo_shr);
+            const unsigned int ox = rem - oy * (unsigned int)a.Wo;
+            a_voff[g] = (unsigned int)((((size_t)(b * a.H + oy * a.stride) * a.W + ox * a.stride) * a.Cin + 4 * (spos ^ ((r >> 1) & 7))) * 4);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+        const int r = wave * (BN / NW) + 8 * g + srow;
+        const int n = n_first + (r & ~63) + swap_channel(r & 63);
+        b_voff[g] = (unsigned int)(((size_t)n * a.K + 4 * (spos ^ ((r >> 1) & 7))) * 4);
+    }
+    const int csteps = a.Cin / BK;                 // K-steps per tile
+    const int total = NT * csteps;
+    const int tile_bytes = BN * a.K * 4;           // weight rows of one N tile
+    int s_cs = 0, s_tile = 0;                      // the step being STAGED
+    auto stage = [&](int buf) {
+        float* As = lds + buf * TILE_FLOATS;
+        float* Bs = As + BM * BK;
+        const int a_soff = s_cs * (BK * 4);
+        const int b_soff = s_tile * tile_bytes + s_cs * (BK * 4);
+#pragma unroll
+        for (int g = 0; g < GA; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + (wave * (BM / NW) + 8 * g) * BK), 16, (int)a_voff[g], a_soff, 0, 0);
+#pragma unroll
+        for (int g = 0; g < GB; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Bs + (wave * (BN / NW) + 8 * g) * BK), 16, (int)b_voff[g], b_soff, 0, 0);
+        if (++s_cs == csteps) { s_cs = 0; ++s_tile; }
+    };
+    f32x4 acc[4][4], acx[4][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[i][j][e] = 0.f; acx[i][j][e] = 0.f; }
+    };
+    zero_acc();
+    const int fo16_hi = 4 * (lq ^ (l15 >> 1)), fo16_lo = 4 * ((4 + lq) ^ (l15 >> 1));
+    stage(0);
+    stage(1);
+    // FrozenBN scale / shift (or 1 / bias) of the group's channels: once, into LDS (visible behind the first step's barrier)
+    for (int c = tid; c < NT * BN; c += 512) {
+        lsc[c] = a.scale ? a.scale[n_first + c] : 1.0f;
+        lsh[c] = a.shift ? a.shift[n_first + c] : 0.0f;
+    }
+    const int mw0 = m0 + wm * 64;
+    const bool scaled_in = a.out_scale != 1.0f;
+    auto tile_epilogue = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[i][j][e] = __fadd_rn(acc[i][j][e], __fmul_rn(acx[i][j][e], 1.0f / LO_SCALE));
+                    if (scaled_in) acc[i][j][e] *= a.out_scale;
+                }
+        // one 16-row block at a time: the loop's state stays live across this epilogue, and two blocks' hoisted residual / mask rows beside it spill
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mrows[1] = {mw0 + 16 * i + l15};
+            conv_epilogue_direct_rows<SPATIAL, true, 1, true, true>(a, reinterpret_cast<f32x4 (&)[1][4]>(acc[i]), lane, mrows, n_first + tile * BN + wn * 64, lsc, lsh, tile * BN + wn * 64);
+        }
+    };
+    int cur = 0, nxt = 2, c_cs = 0, c_tile = 0;    // ring positions; the step being COMPUTED
+    const bool early = wave < NW / 2;
+    auto open_step = [&](int step) {
+        // the stores of the previous tile's epilogue in the queue (see the table above); exact for full tiles only
+        const bool behind_epilogue = full && c_tile > 0 && (early ? c_cs <= 1 : c_cs == 1);
+        if (step + 1 >= total) __builtin_amdgcn_s_waitcnt(0x0070);
+        else if (behind_epilogue) __builtin_amdgcn_s_waitcnt(0x0070 | ((NDMA + NST) & 15) | (((NDMA + NST) >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0070 | NDMA);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto advance = [&]() {
+        cur = (cur == 2) ? 0 : cur + 1;
+        nxt = (nxt == 2) ? 0 : nxt + 1;
+        if (++c_cs == csteps) { c_cs = 0; ++c_tile; }
+    };
+    F16x3Frags<4, 4> fr;
+    const float* As0 = lds + (wm * 64 + l15) * BK;
+    const float* Bs0 = lds + BM * BK + (wn * 64 + l15) * BK;
+    if (early) {
+        for (int step = 0; step < total; ++step) {
+            open_step(step);
+            f16x3_load16<4, 4>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < total) stage(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c_cs == csteps - 1) { tile_epilogue(c_tile); zero_acc(); __builtin_amdgcn_sched_barrier(0); }
+            advance();
+        }
+    } else {
+        for (int step = 0; step < total; ++step) {
+            open_step(step);
+            __builtin_amdgcn_s_setprio(1);
+            if (step > 0) f16x3_mfma16<4, 4, true>(fr, acc, acx);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c_cs == 0 && c_tile > 0) { tile_epilogue(c_tile - 1); zero_acc(); __builtin_amdgcn_sched_barrier(0); }      // the MFMAs above finished tile c_tile - 1
+            __builtin_amdgcn_s_barrier();
+            f16x3_load16<4, 4>(As0 + cur * TILE_FLOATS, Bs0 + cur * TILE_FLOATS, fo16_hi, fo16_lo, fr);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < total) stage(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+        }
+        f16x3_mfma16<4, 4, true>(fr, acc, acx);
+        tile_epilogue(NT - 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // conv3x3_patch_kernel (round 4): the 3x3 stride-1 pad-1 convolutions of the FPN / RPN / res4 / res5 (Cin % 32 == 0, Cout % 256 == 0) with both
 // operands in the split row format -- conv_split_kernel<128, 256>'s loop (ring of three weight tiles filled by LDS-DMA two steps ahead, counted
 // vmcnt, bare barriers, the two halves of the workgroup one half-step apart), but the 128 GEMM rows of a workgroup are an 8 x 16 PIXEL tile and
@@ -2845,6 +3020,13 @@ extern "C" void amp_debug_set_korder(int v) { g_korder = v; }
 // one box of the full-size gate from 0.9e-3 to 1.01e-3 px off the fp32 oracle (bare tolerance 1e-3): not adopted.
 static int g_patch256 = getenv("AMP_PATCH256") ? atoi(getenv("AMP_PATCH256")) : 0;
 extern "C" void amp_debug_set_patch256(int v) { g_patch256 = v; }
+// EXPERIMENT switch, default OFF (AMP_NLOOP=1): several N tiles per workgroup for the short-K 1x1 layers (conv1x1_nloop_kernel).  Measured (round 4,
+// tools/lab/time_nloop.py, A/B in one process, bit-identical): the training step's deconv 930-970 -> 856 us, res3.0's stride-2 shortcut 315 -> 291 us at B = 16
+// and 154 -> 151 at B = 8, res4.0's shortcut 223 -> 240 us (WORSE), an inference step 16.16 against 16.12 ms: what bounds these layers is not the ring's
+// cold start (that was the mask tail's case: four taps over the SAME pixels and a store-free epilogue) but their bytes; 0.1 ms of a 74-ms training step
+// does not pay for a second loop structure on the training path.
+static int g_nloop = getenv("AMP_NLOOP") ? atoi(getenv("AMP_NLOOP")) : 0;
+extern "C" void amp_debug_set_nloop(int v) { g_nloop = v; }
 static int g_mask_tail_loop = getenv("AMP_NO_MASK_TAIL_LOOP") ? 0 : 1;      // EXPERIMENT switch: 0 = the fused mask-head tail on conv_split_kernel<128, 256, 3> (one tap per workgroup)
 extern "C" void amp_debug_set_mask_tail_loop(int v) { g_mask_tail_loop = v; }
 static int g_patch_conv = getenv("AMP_NO_PATCH_CONV") ? 0 : 1;      // EXPERIMENT switch: 0 = the implicit-GEMM kernels for the 64-channel-window 3x3 layers; 2 = conv3x3_c64_kernel whatever the grid size (tests)
@@ -3442,6 +3624,14 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
         // a split input that carries a 2^in_shift (scaled loss gradients): only the ring kernel undoes it (a.out_scale in its fold)
         AMP_REQUIRE(!(x_is_split && in_shift != 0) || (g_split_ring && epi != 0 && wide256 && a.out_mode != 3),
                     "conv: a scaled split input needs a layer the 128 x 256 ring kernel takes (Cout %% 256 == 0, enough tiles)");
+        // N tiles per workgroup for the short-K 1x1 layers on the ring kernel (0: not such a layer): as many as leave a full round of workgroups
+        int nloop_nt = 0;
+        if (a.KH == 1 && a.KW == 1 && a.pad == 0 && !a.grouped && a.Cout % 256 == 0 && a.Cout >= 512 && a.Cin % BK == 0 && a.nsteps >= 2 && a.nsteps <= 16 && !a.korder &&
+            a.y_split && g_direct_epi && !mask && a.res_mode == 0 && (a.out_mode == 0 || a.out_mode == 1)) {      // (no residual, no mask: see conv_epilogue_direct_rows PLAIN)
+            const int ntn_ = a.Cout / 256;
+            nloop_nt = ntn_ < 8 ? ntn_ : 8;
+            while (nloop_nt > 1 && (ntn_ % nloop_nt != 0 || (long long)ntm * (ntn_ / nloop_nt) < 256)) --nloop_nt;
+        }
         const long long p256_tiles = (long long)a.B * amp::cdiv(a.Ho, 8) * amp::cdiv(a.Wo, 16) * (a.Cout / 256);
         const bool patch256_ok = g_patch256 != 0 && x_is_split && g_split_ring && epi != 0 && !a.grouped && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 &&
             a.Cin % 32 == 0 && a.Cin >= 64 && a.Cout % 256 == 0 && a.nsteps == 9 * (a.Cin / 32) &&
@@ -3485,6 +3675,11 @@ int amp::conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float*
             a.ntn = a.Cout / 128; a.nblk = ntm * a.ntn;
             a.stagger = 0;
             launch_split_short(a, epi, ctx->stream, (unsigned int)x_bytes, (unsigned int)w_bytes);
+        } else if (g_nloop && nloop_nt >= 2 && x_is_split && g_split_ring && epi != 0 && (wide256 || deconv_split)) {
+            // short-K 1x1 layers: several N tiles of a pixel block in one workgroup, the ring carried across them (conv1x1_nloop_kernel)
+            a.ntn = a.Cout / 256; a.nblk = ntm * (a.ntn / nloop_nt);
+            if (a.out_mode == 1) AMP_TIMED_LAUNCH(conv1x1_nloop_kernel<true>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, nloop_nt);
+            else AMP_TIMED_LAUNCH(conv1x1_nloop_kernel<false>, dim3(a.nblk), dim3(512), 0, ctx->stream, a, (unsigned int)x_bytes, (unsigned int)w_bytes, nloop_nt);
         } else if (x_is_split && g_split_ring && epi != 0 && (wide256 || deconv_split)) {            // 128 x 256 tiles, 3-buffer ring
             // (the K = 256 deconv with its scatter epilogue on two-buffer 128 x 128 tiles, two workgroups per CU: 1009 against 931 us -- measured, not kept)
             a.ntn = a.Cout / 256; a.nblk = ntm * a.ntn;

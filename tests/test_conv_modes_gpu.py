@@ -853,3 +853,43 @@ def test_mask_tail_with_four_taps_per_workgroup_is_bit_identical(gpu_ctx, B, H, 
         for x, y in zip(outs[0], outs[k]):
             assert np.array_equal(x["boxes"], y["boxes"]) and len(x["masks"]) == len(y["masks"])
             assert all(np.array_equal(r["counts"], t["counts"]) for r, t in zip(x["masks"], y["masks"]))
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 256, 512, 2, False), (8, 128, 128, 512, 1024, 2, False), (5, 120, 121, 256, 512, 1, False), (8, 64, 64, 64, 2048, 1, False),
+                                   (400, 14, 14, 256, 1024, 1, True), (37, 14, 14, 256, 1024, 1, True)])
+def test_n_tile_loop_for_short_k_layers_is_bit_identical(gpu_ctx, shape):
+    """conv1x1_nloop_kernel (round 4, AMP_NLOOP=1, not the default: several N tiles of a 128-pixel block in one workgroup, the ring carried across them, the tile epilogue between two
+    K-steps with its stores counted into the ring's vmcnt waits) against conv_split_kernel<128, 256> (amp_debug_set_nloop(0)) on the short-K 1x1 layers it
+    takes -- stride-2 shortcuts, a ragged last pixel block, K = 64, the mask head's deconv with its 2x2 scatter: bit for bit, repeatably; and against fp64."""
+    import torch
+    from ampis_amd import _lib, ops
+    B, H, W, Cin, Cout, stride, deconv = shape
+    torch.manual_seed(B + H + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, device="cuda")
+    w = torch.randn(Cout, 1, 1, Cin, device="cuda") * 0.05
+    sc = None if deconv else torch.rand(Cout, device="cuda") + 0.5
+    sh = torch.randn(Cout // (4 if deconv else 1), device="cuda").repeat(4 if deconv else 1) * 0.1
+    xs = ops.split_rows(gpu_ctx, x)
+    kw = dict(stride=stride, pad=0, relu=deconv, deconv2x2=deconv, fmt=ops.FMT_X_SPLIT | ops.FMT_Y_SPLIT)
+    L = _lib.lib()
+    try:
+        L.amp_debug_set_nloop(0)
+        ref = ops.conv2d_nhwc(gpu_ctx, xs, w, sc, sh, **kw).clone()
+        L.amp_debug_set_nloop(1)
+        for _ in range(4):
+            y = ops.conv2d_nhwc(gpu_ctx, xs, w, sc, sh, **kw)
+            torch.cuda.synchronize()
+            nd = int((y.view(torch.int32) != ref.view(torch.int32)).sum())
+            assert nd == 0, f"{nd} words differ"
+    finally:
+        L.amp_debug_set_nloop(0)      # (not the default: AMP_NLOOP=1)
+    xd = ops.unsplit_rows(gpu_ctx, xs).double()[:, ::stride, ::stride]
+    want = torch.einsum("bhwc,nc->bhwn", xd, w.double().view(Cout, Cin))
+    if sc is not None:
+        want = want * sc.double()
+    want = want + sh.double()
+    got = ops.unsplit_rows(gpu_ctx, y).double()
+    if deconv:      # [B, H, W, (ky, kx, co)] -> [B, 2H, 2W, co]
+        want = torch.relu(want).view(B, H, W, 2, 2, Cout // 4).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, Cout // 4)
+    assert got.shape == want.shape
+    assert float((got - want).abs().max() / want.abs().max()) < 2e-6
