@@ -170,6 +170,27 @@ struct RpnFuse {                  // the RPN head's 1x1 predictors fused into th
     const float* bias;            // [16]
     float* pred;                  // [M][16]
 };
+// rpn_sparse.hip: the RPN head's backward pass over the sampled anchors' pixels only (every other entry of the predictor gradients is an exact zero)
+struct RpnSparseArgs {
+    int B, batch, ld, K, C;                    // images, RPN.BATCH_SIZE_PER_IMAGE, predictor row length (16) and real rows, hidden channels (256)
+    int fh[5], fw[5];
+    const int* sampled;                        // [B][batch] sampled anchor indices (amp_rpn_sample_loss)
+    const int* counts;                         // [B][2] positives, negatives
+    const float* dpred[5];                     // d loss / d predictions [B * h * w][ld], zero except at the sampled anchors
+    const float* t[5];                         // hidden activations [B * h * w][C]
+    const float* feat[5];                      // FPN features [B * h * w][C]
+    int t_split, feat_split;                   // ... in the split row format
+    const float* w_pred;                       // [K][C]
+    const float* w_conv;                       // [C][3][3][C]
+    const float* conv_scale;                   // FrozenBN scale of the conv or null
+    float* gw_pred; float* gb_pred; float* gw_conv; float* gb_conv;      // gradients (written, not accumulated)
+    float* dfeat[5];                           // gradient maps of the FPN features (accumulated in place)
+    unsigned int* rows; int* nrows;            // workspace: [B * batch], [B]
+    float* dpred_rows; float* act_rows; float* dt_rows;                  // [B * batch][16], [..][C], [..][C]
+    float* xg; float* G; float* wt;            // [B * batch][9 C], [B * batch][9 C], [9 C][C]
+    float* wg_scratch; size_t wg_scratch_floats;
+};
+int rpn_sparse_backward(amp_ctx* ctx, const RpnSparseArgs& a);
 int conv_run(amp_ctx* ctx, const amp_conv_desc* d, int groups, const float* x, const float* w, const float* w_split, int force_f32,
              const float* scale, const float* shift, const float* res, const float* mask, float* y, int in_shift = 0, int fmt = 0,
              const PredictFuse* fuse = nullptr, const RpnFuse* rpn = nullptr);

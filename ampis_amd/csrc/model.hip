@@ -102,6 +102,7 @@ struct amp_model {
     float* varena = nullptr;            // SGD momentum buffers, same offsets
     bool saving = false;                // run_trunk keeps every activation the backward pass needs
     bool acts_split = false;            // ... and kept them in the split row format (training on the native trunk, AMP_CONV_F16X3)
+    int last_rpn_sparse = -1;           // 1: the last backward pass ran the RPN head's gradients over the sampled pixels only (rpn_sparse.hip)
     int last_chain = -1;                // the last backward pass's backbone chain: 0 fp32 storage, 1 split activations + fp32 gradients, 2 scaled split gradients (R50 / R101), 3 the same for ResNeXt blocks
     bool gs_chain_ok = false;           // ... and the backbone's backward chain can run on scaled split gradients (dense 3x3, stride in conv1: R50 / R101)
     bool mask_acts_split = false;       // the mask head's pooled input and fcn1..3 outputs of the last training forward likewise
@@ -140,11 +141,14 @@ struct amp_model {
 
 static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
 extern "C" void amp_debug_set_split_chain(int on) { g_split_chain = on; }
+static int g_rpn_sparse = -1;        // -1: from the environment (AMP_NO_RPN_SPARSE), 0 / 1: set by amp_debug_set_rpn_sparse (tests)
+extern "C" void amp_debug_set_rpn_sparse(int on) { g_rpn_sparse = on; }
 static int g_mask_tail_split = -1;   // -1: from the environment (AMP_NO_MASK_TAIL_SPLIT), 0 / 1: set by amp_debug_set_mask_tail_split (tests)
 extern "C" void amp_debug_set_mask_tail_split(int on) { g_mask_tail_split = on; }
 static int g_gx = -1;                // -1: from the environment (AMP_NO_GX), 0 / 1: ResNeXt blocks on fp32 gradients / on the scaled split chain (tests)
 extern "C" void amp_debug_set_gx(int on) { g_gx = on; }
 extern "C" int amp_debug_last_backward_chain(amp_model* m) { return m ? m->last_chain : -1; }
+extern "C" int amp_debug_last_rpn_sparse(amp_model* m) { return m ? m->last_rpn_sparse : -1; }
 
 namespace {
 
@@ -1303,9 +1307,44 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_TRY(issue_bucket(m, 1));
 
     // ---- RPN head (shared weights: gradients accumulate over the 5 levels) ----
+    // The losses touch <= RPN.BATCH_SIZE_PER_IMAGE anchors per image: the head's gradients over those pixels only (rpn_sparse.hip), all levels in one list
+    const int SRR = B * c.rpn_batch;
+    AMP_ALLOC(sr_rows, unsigned int, (size_t)SRR);
+    AMP_ALLOC(sr_nrows, int, (size_t)B);
+    AMP_ALLOC(sr_dpred, float, (size_t)SRR * 16);
+    AMP_ALLOC(sr_act, float, (size_t)SRR * 256);
+    AMP_ALLOC(sr_dt, float, (size_t)SRR * 256);
+    AMP_ALLOC(sr_xg, float, (size_t)SRR * 2304);
+    AMP_ALLOC(sr_G, float, (size_t)SRR * 2304);
+    AMP_ALLOC(sr_wt, float, (size_t)2304 * 256);
+    bool SR = false;
+    if (!dry) {
+        static const bool no_rpn_sparse = getenv("AMP_NO_RPN_SPARSE") != nullptr;      // EXPERIMENT switch: the dense backward of the RPN head
+        const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
+        const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
+        SR = (g_rpn_sparse < 0 ? !no_rpn_sparse : g_rpn_sparse != 0) && T.lv.ld == 16 && cpred.cout <= 16 && cpred.cin == 256 && cpred.scale == nullptr && c.rpn_batch <= 512 &&
+             cconv.cout == 256 && cconv.cin == 256 && cconv.kh == 3 && cconv.kw == 3;
+        if (SR) {
+            amp::RpnSparseArgs sa;
+            sa.B = B; sa.batch = c.rpn_batch; sa.ld = T.lv.ld; sa.K = cpred.cout; sa.C = 256;
+            for (int l = 0; l < 5; ++l) {
+                sa.fh[l] = T.fh[l]; sa.fw[l] = T.fw[l];
+                sa.dpred[l] = d_rpn_pred[l]; sa.t[l] = m->rpn_t[l]; sa.feat[l] = T.feat[l]; sa.dfeat[l] = d_feat[l];
+            }
+            sa.sampled = rpn_sampled; sa.counts = rpn_counts;
+            sa.t_split = AS ? 1 : 0; sa.feat_split = AS ? 1 : 0;
+            sa.w_pred = cpred.w; sa.w_conv = cconv.w; sa.conv_scale = cconv.scale;
+            sa.gw_pred = GW(cpred); sa.gb_pred = GB(cpred); sa.gw_conv = GW(cconv); sa.gb_conv = GB(cconv);
+            sa.rows = sr_rows; sa.nrows = sr_nrows; sa.dpred_rows = sr_dpred; sa.act_rows = sr_act; sa.dt_rows = sr_dt; sa.xg = sr_xg; sa.G = sr_G; sa.wt = sr_wt;
+            sa.wg_scratch = wg_scratch; sa.wg_scratch_floats = WG_SCRATCH;
+            AMP_TRY(amp::rpn_sparse_backward(ctx, sa));
+            dys_of = nullptr;
+        }
+        m->last_rpn_sparse = SR ? 1 : 0;
+    }
     for (int l = 0; l < 5; ++l) {
         AMP_ALLOC(d_t, float, (size_t)B * T.fh[l] * T.fw[l] * 256);
-        if (dry) continue;
+        if (dry || SR) continue;
         const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
         const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
         AMP_TRY(wgrad(cpred, m->rpn_t[l], B, T.fh[l], T.fw[l], 1, 0, d_rpn_pred[l], l > 0, true, AS));

@@ -318,7 +318,9 @@ def train_leg(ctx, infer_model, dev, rank, world, warmup, steps, ranks):
            "steps": steps, "warmup": warmup, "batch_per_gpu": TRAIN_BATCH, "global_batch": TRAIN_BATCH * world,
            "dtype": "f32 (forward, data-gradient and weight-gradient convs: f16x3 split-operand MFMA, fp32 accumulate)" if f16 else "f32",
            "workload": "BASELINE configs[2] (N=1) / configs[3] (N=8): K=2, ~480 GT instances/image (polygons), 256 anchors + 512 RoIs "
-                       "sampled per image, seeded random-init weights, uint8 images resident in HBM, annotations (boxes, classes, polygons) passed from the host each step",
+                       "sampled per image, seeded random-init weights, uint8 images resident in HBM, annotations (boxes, classes, polygons) passed from the host each step; "
+                       "every gradient of every trainable tensor is produced -- the RPN head's four gradient GEMMs run over the <= 256 sampled anchors' pixels per image, "
+                       "the only rows of its loss gradient that are not exact zeros (csrc/rpn_sparse.hip; AMP_NO_RPN_SPARSE=1: over every pixel, same gradients to 6e-7)",
            # the dominant kernel of a training step is the forward / data-gradient convolution (conv_split_kernel<128x256>: ~46 of 81 ms);
            # the weight-gradient kernels (~23 ms) are reported beside it
            "roofline": {"bound": "mfma",

@@ -337,3 +337,51 @@ def test_mask_tail_on_presplit_operands_agrees_with_the_fp32_storage_path():
     assert changed > 0, "the switch changed nothing: the split mask tail did not run"
     m.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("B,S,mode", [(4, 1024, "f16x3"), (2, 512, "f16x3"), (2, 512, "f32")])
+def test_sparse_rpn_backward_equals_the_dense_one(B, S, mode):
+    """The RPN head's backward pass over the sampled anchors' pixels only (round 4, rpn_sparse.hip: <= 256 rows per image instead of every pixel of
+    five maps; every term it leaves out is an exact zero) against the dense pass (amp_debug_set_rpn_sparse(0)): the same losses bit for bit (the forward
+    pass does not change), every trainable gradient -- the head's own four tensors and everything upstream of the FPN maps it scatters into -- equal up
+    to the order of the fp32 sums, the step repeats bit for bit, and the switch did switch."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    ctx.conv_mode = mode
+    K = 2
+    imgs, gts = synth.batch(B, S, S, first_index=410)
+    npp = P.init_params(K, seed=0, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 800, max_poly_doubles=B * 800 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    out, ran = {}, {}
+    try:
+        for on in (0, 1, 1):
+            _lib.lib().amp_debug_set_rpn_sparse(on)
+            losses = m.forward_losses(imgs, gts, seed=7, backward=True)
+            got = (losses, {k: m.get_tensor(k, grad=True) for k in names})
+            if on in out:      # the sparse step again: bit for bit
+                assert got[0] == out[on][0]
+                for k in names:
+                    assert np.array_equal(got[1][k], out[on][1][k]), k
+            out[on] = got
+            ran[on] = _lib.lib().amp_debug_last_rpn_sparse(m._h)
+    finally:
+        _lib.lib().amp_debug_set_rpn_sparse(-1)
+    assert ran == {0: 0, 1: 1}
+    assert not ctx.conv_range_flag()
+    assert out[0][0] == out[1][0]
+    worst, changed = {}, 0
+    for k in names:
+        r, g = out[0][1][k], out[1][1][k]
+        assert float(np.abs(r).max()) > 0, k
+        err = float(np.abs(g - r).max()) / float(np.abs(r).max())
+        worst[k] = err
+        assert err < (2e-5 if mode == "f16x3" else 1e-4), (k, err)
+        changed += int(not np.array_equal(r, g))
+    head = [k for k in names if k.startswith("proposal_generator.rpn_head")]
+    assert len(head) == 6 and changed >= 6, (head, changed)
+    print("worst relative differences:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    m.close()
+    ctx.close()
