@@ -114,14 +114,14 @@ __global__ __launch_bounds__(256) void rpn_dt_rows_kernel(const RowArgs a) {
     if (c < 16) a.dpred_rows[(size_t)r * 16 + c] = dp;
 }
 
-// the predictor's gradients and the conv's bias gradient: sums over the rows in ascending order, 8 row slices in parallel then added in slice order
-// blocks 0 .. 15: dW_pred[k][c]; block 16: db_conv[c]; block 17: db_pred[k]
+// the predictor's gradients and the conv's bias gradient: sums over the rows in ascending order -- 32 row slices in parallel (8 workgroups x 4 quarter
+// slices each), added in slice order by rpn_head_sums_final_kernel.  blockIdx.x 0 .. 15: dW_pred[k][c]; 16: db_conv[c]; 17: db_pred[k]
+constexpr int SUM_SLICES = 8;
 __global__ __launch_bounds__(1024) void rpn_head_sums_kernel(const float* __restrict__ dpred_rows, const float* __restrict__ act_rows, const float* __restrict__ dt_rows,
-                                                             int R, int K, float* __restrict__ gw_pred, float* __restrict__ gb_pred, float* __restrict__ gb_conv) {
-    __shared__ float part[4][256];
-    const int c = threadIdx.x & 255, s = threadIdx.x >> 8;       // 4 slices of the rows
-    const int blk = blockIdx.x;
-    const int r0 = (int)((long long)R * s / 4), r1 = (int)((long long)R * (s + 1) / 4);
+                                                             int R, int K, float* __restrict__ partial) {      // partial [18][SUM_SLICES * 4][256]
+    const int c = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int blk = blockIdx.x, s = blockIdx.y * 4 + q, ns = SUM_SLICES * 4;
+    const int r0 = (int)((long long)R * s / ns), r1 = (int)((long long)R * (s + 1) / ns);
     float acc = 0.f;
     if (blk < 16) {
         if (blk < K) for (int r = r0; r < r1; ++r) acc = __fadd_rn(acc, __fmul_rn(dpred_rows[(size_t)r * 16 + blk], act_rows[(size_t)r * 256 + c]));
@@ -130,14 +130,16 @@ __global__ __launch_bounds__(1024) void rpn_head_sums_kernel(const float* __rest
     } else {
         if (c < K) for (int r = r0; r < r1; ++r) acc = __fadd_rn(acc, dpred_rows[(size_t)r * 16 + c]);
     }
-    part[s][c] = acc;
-    __syncthreads();
-    if (s == 0) {
-        const float t = __fadd_rn(__fadd_rn(__fadd_rn(part[0][c], part[1][c]), part[2][c]), part[3][c]);
-        if (blk < 16) { if (blk < K) gw_pred[(size_t)blk * 256 + c] = t; }
-        else if (blk == 16) gb_conv[c] = t;
-        else if (c < K) gb_pred[c] = t;
-    }
+    partial[((size_t)blk * ns + s) * 256 + c] = acc;
+}
+__global__ __launch_bounds__(256) void rpn_head_sums_final_kernel(const float* __restrict__ partial, int K, float* __restrict__ gw_pred, float* __restrict__ gb_pred,
+                                                                   float* __restrict__ gb_conv) {
+    const int c = threadIdx.x, blk = blockIdx.x, ns = SUM_SLICES * 4;
+    float t = partial[((size_t)blk * ns) * 256 + c];
+    for (int s = 1; s < ns; ++s) t = __fadd_rn(t, partial[((size_t)blk * ns + s) * 256 + c]);
+    if (blk < 16) { if (blk < K) gw_pred[(size_t)blk * 256 + c] = t; }
+    else if (blk == 16) gb_conv[c] = t;
+    else if (c < K) gb_pred[c] = t;
 }
 
 struct GatherArgs {
@@ -213,7 +215,9 @@ int rpn_sparse_backward(amp_ctx* ctx, const RpnSparseArgs& A) {
     ra.dpred_rows = A.dpred_rows; ra.act_rows = A.act_rows; ra.dt_rows = A.dt_rows;
     for (int l = 0; l < NLV; ++l) { ra.dpred[l] = A.dpred[l]; ra.t[l] = A.t[l]; }
     hipLaunchKernelGGL(rpn_dt_rows_kernel, dim3(R), dim3(256), 0, ctx->stream, ra);
-    hipLaunchKernelGGL(rpn_head_sums_kernel, dim3(18), dim3(1024), 0, ctx->stream, A.dpred_rows, A.act_rows, A.dt_rows, R, A.K, A.gw_pred, A.gb_pred, A.gb_conv);
+    // (the partial sums live in G, which the data-gradient GEMM overwrites further down: 18 x 32 x 256 floats)
+    hipLaunchKernelGGL(rpn_head_sums_kernel, dim3(18, SUM_SLICES), dim3(1024), 0, ctx->stream, A.dpred_rows, A.act_rows, A.dt_rows, R, A.K, A.G);
+    hipLaunchKernelGGL(rpn_head_sums_final_kernel, dim3(18), dim3(256), 0, ctx->stream, A.G, A.K, A.gw_pred, A.gb_pred, A.gb_conv);
     GatherArgs ga;
     ga.g = g; ga.rows = A.rows; ga.batch = A.batch; ga.feat_split = A.feat_split; ga.xg = A.xg;
     for (int l = 0; l < NLV; ++l) ga.feat[l] = A.feat[l];
