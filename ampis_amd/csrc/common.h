@@ -180,6 +180,9 @@ struct RpnSparseArgs {
     const float* t[5];                         // hidden activations [B * h * w][C]
     const float* feat[5];                      // FPN features [B * h * w][C]
     int t_split, feat_split;                   // ... in the split row format
+    int recompute_t;                           // 1: t was not saved (the forward pass ran the fused head): the rows' hidden activations = relu(patch . W_conv + shift), recomputed
+    const float* w_conv_split;                 // the conv's weights in the split operand layout (or null: split per call)
+    const float* conv_shift;                   // the conv's bias (FrozenBN shift) or null
     const float* w_pred;                       // [K][C]
     const float* w_conv;                       // [C][3][3][C]
     const float* conv_scale;                   // FrozenBN scale of the conv or null

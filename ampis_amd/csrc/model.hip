@@ -112,6 +112,7 @@ struct amp_model {
     std::vector<BlockAct> blocks;
     float* lat[4] = {nullptr, nullptr, nullptr, nullptr};
     float* rpn_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool rpn_train_fused = false;       // this training step's RPN head ran with the predictors in the conv's epilogue (no hidden tensor saved): the sparse backward recomputes its rows
     struct Trainable { float* p; size_t n; };
     std::vector<Trainable> trainable;
     unsigned long long* sgd_chunks = nullptr;   // device table for amp::sgd_chunks_run, built at the first amp_model_sgd_step
@@ -141,6 +142,8 @@ struct amp_model {
 
 static int g_split_chain = -1;   // -1: from the environment (AMP_NO_SPLIT_CHAIN), 0 / 1: set by amp_debug_set_split_chain (tests)
 extern "C" void amp_debug_set_split_chain(int on) { g_split_chain = on; }
+static int g_rpn_train_fuse = -1;    // -1: from the environment (AMP_NO_RPN_TRAIN_FUSE), 0 / 1: set by amp_debug_set_rpn_train_fuse (tests)
+extern "C" void amp_debug_set_rpn_train_fuse(int on) { g_rpn_train_fuse = on; }
 static int g_rpn_sparse = -1;        // -1: from the environment (AMP_NO_RPN_SPARSE), 0 / 1: set by amp_debug_set_rpn_sparse (tests)
 extern "C" void amp_debug_set_rpn_sparse(int on) { g_rpn_sparse = on; }
 static int g_mask_tail_split = -1;   // -1: from the environment (AMP_NO_MASK_TAIL_SPLIT), 0 / 1: set by amp_debug_set_mask_tail_split (tests)
@@ -462,13 +465,16 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
         AMP_ALLOC(pred, float, (size_t)B * fh[l] * fw[l] * ld_rpn);
         const size_t keep = ws.off;
         AMP_ALLOC(t, float, (size_t)B * fh[l] * fw[l] * 256);
+        bool fused_rpn = false;
         if (!dry) {
             const ConvW& rc = CONV("proposal_generator.rpn_head.conv");
             const ConvW& rp = CONV("proposal_generator.rpn_head.pred");
             static const bool no_rpn_fuse = getenv("AMP_NO_RPN_FUSE") != nullptr;      // EXPERIMENT switch
             const long long Ml = (long long)B * fh[l] * fw[l];
-            if (native_all && !m->saving && !no_rpn_fuse && rc.cout == 256 && rc.w_split && rp.w_split && rp.cout == 16 && rp.cin == 256 && Ml >= 24576) {
-                // inference on the native trunk: the predictors run in the 3x3 conv's epilogue, the hidden tensor is never written
+            if (native_all && (!m->saving || m->rpn_train_fused) && !m->split_stale && !no_rpn_fuse && rc.cout == 256 && rc.w_split && rp.w_split && rp.cout == 16 && rp.cin == 256 && Ml >= 24576) {
+                // inference on the native trunk -- and a training step whose backward pass takes the sparse route (it recomputes the hidden rows it needs):
+                // the predictors run in the 3x3 conv's epilogue, the hidden tensor is never written
+                fused_rpn = true;
                 amp_conv_desc d;
                 d.B = B; d.H = fh[l]; d.W = fw[l]; d.Cin = rc.cin; d.Cout = rc.cout; d.KH = rc.kh; d.KW = rc.kw; d.stride = 1; d.pad = 1; d.relu = 1; d.res_mode = 0; d.out_mode = 0;
                 amp::RpnFuse rf{rp.w_split, rp.shift, pred};
@@ -479,7 +485,8 @@ int run_trunk(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, Trunk& T
             }
         }
         (void)mark;
-        if (m->saving) m->rpn_t[l] = t; else ws.off = keep;
+        if (m->saving && !fused_rpn) m->rpn_t[l] = t;
+        else { if (m->saving) m->rpn_t[l] = nullptr; if (!m->saving) ws.off = keep; }
         lv.pred[l] = pred; lv.h[l] = fh[l]; lv.w[l] = fw[l]; lv.stride[l] = fstride[l]; lv.anchor_size[l] = asz[l];
         max_n = std::max(max_n, fh[l] * fw[l] * 3);
         if (!dry) {
@@ -873,8 +880,22 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     static const bool no_dgrad_batch = getenv("AMP_NO_DGRAD_BATCH") != nullptr;      // EXPERIMENT switch: transpose + split in front of every data-gradient conv
     const bool dgrad_batch = !dry && backward && !no_dgrad_batch && m->ctx->conv_mode == AMP_CONV_F16X3;
     if (dgrad_batch) AMP_TRY(refresh_dgrad_weights(m));
+    // the RPN head's backward pass runs over the sampled anchors' pixels only (rpn_sparse.hip) -- and then the forward pass need not save the head's hidden
+    // tensor: the predictors run in the conv's epilogue as in inference, the backward pass recomputes the rows it needs from the gathered patches
+    bool sr_ok = false;
+    if (!dry) {      // (the plan run comes before the parameters: no layer table yet)
+        static const bool no_rpn_sparse = getenv("AMP_NO_RPN_SPARSE") != nullptr;          // EXPERIMENT switch: the dense backward of the RPN head
+        static const bool no_rpn_train_fuse = getenv("AMP_NO_RPN_TRAIN_FUSE") != nullptr;  // EXPERIMENT switch: the head's hidden tensor saved by the forward pass
+        const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
+        const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
+        sr_ok = backward && (g_rpn_sparse < 0 ? !no_rpn_sparse : g_rpn_sparse != 0) && cpred.cout <= 16 && cpred.cin == 256 && cpred.scale == nullptr && c.rpn_batch <= 512 &&
+                cconv.cout == 256 && cconv.cin == 256 && cconv.kh == 3 && cconv.kw == 3;
+        m->rpn_train_fused = !dry && sr_ok && (g_rpn_train_fuse < 0 ? !no_rpn_train_fuse : g_rpn_train_fuse != 0) && m->ctx->conv_mode == AMP_CONV_F16X3;
+    }
     const int trunk_status = run_trunk(m, imgs_d, B, H, W, T);
     m->saving = false;
+    const bool rpn_fused = m->rpn_train_fused;
+    m->rpn_train_fused = false;
     AMP_TRY(trunk_status);
     const int total_gt = dry ? c.max_gt : gt->gt_off[B];
     const int npoly = dry ? c.max_poly_doubles : gt->poly_off[gt->inst_poly_off ? gt->inst_poly_off[total_gt] : total_gt];
@@ -1319,11 +1340,10 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
     AMP_ALLOC(sr_wt, float, (size_t)2304 * 256);
     bool SR = false;
     if (!dry) {
-        static const bool no_rpn_sparse = getenv("AMP_NO_RPN_SPARSE") != nullptr;      // EXPERIMENT switch: the dense backward of the RPN head
         const ConvW& cpred = CONV("proposal_generator.rpn_head.pred");
         const ConvW& cconv = CONV("proposal_generator.rpn_head.conv");
-        SR = (g_rpn_sparse < 0 ? !no_rpn_sparse : g_rpn_sparse != 0) && T.lv.ld == 16 && cpred.cout <= 16 && cpred.cin == 256 && cpred.scale == nullptr && c.rpn_batch <= 512 &&
-             cconv.cout == 256 && cconv.cin == 256 && cconv.kh == 3 && cconv.kw == 3;
+        SR = sr_ok && T.lv.ld == 16;
+        AMP_REQUIRE(SR || !rpn_fused, "%s", "backward: the RPN head's hidden tensor was not saved and the sparse backward pass does not apply");
         if (SR) {
             amp::RpnSparseArgs sa;
             sa.B = B; sa.batch = c.rpn_batch; sa.ld = T.lv.ld; sa.K = cpred.cout; sa.C = 256;
@@ -1333,6 +1353,7 @@ int run_train(amp_model* m, const uint8_t* imgs_d, int B, int H, int W, const am
             }
             sa.sampled = rpn_sampled; sa.counts = rpn_counts;
             sa.t_split = AS ? 1 : 0; sa.feat_split = AS ? 1 : 0;
+            sa.recompute_t = rpn_fused ? 1 : 0; sa.w_conv_split = cconv.w_split; sa.conv_shift = cconv.shift;
             sa.w_pred = cpred.w; sa.w_conv = cconv.w; sa.conv_scale = cconv.scale;
             sa.gw_pred = GW(cpred); sa.gb_pred = GB(cpred); sa.gw_conv = GW(cconv); sa.gb_conv = GB(cconv);
             sa.rows = sr_rows; sa.nrows = sr_nrows; sa.dpred_rows = sr_dpred; sa.act_rows = sr_act; sa.dt_rows = sr_dt; sa.xg = sr_xg; sa.G = sr_G; sa.wt = sr_wt;

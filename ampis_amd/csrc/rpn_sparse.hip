@@ -81,6 +81,7 @@ struct RowArgs {
     const float* dpred[NLV];                   // [B * hw][ld]
     const float* t[NLV];                       // hidden activation (after ReLU) [B * hw][256], split rows or fp32
     int t_split;
+    const float* t_rows;                       // the rows' hidden activations recomputed ([R][256] fp32) or null: read from t
     const float* w_pred;                       // [K][256]
     float* dpred_rows;                         // [R][16]
     float* act_rows;                           // [R][256]
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void rpn_dt_rows_kernel(const RowArgs a) {
         const int b = r / a.batch, lvl = (int)(key >> 26);
         const size_t row = (size_t)b * a.g.hw[lvl] + (key & 0x3ffffffu);
         const float* dl = a.dpred[lvl] + row * a.ld;
-        act = load_ch(a.t[lvl], row, c, a.t_split);
+        act = a.t_rows ? a.t_rows[(size_t)r * 256 + c] : load_ch(a.t[lvl], row, c, a.t_split);
         float v = 0.f;
         for (int k = 0; k < a.K; ++k) v = __fadd_rn(v, __fmul_rn(dl[k], a.w_pred[(size_t)k * 256 + c]));
         dt = act > 0.f ? v : 0.f;
@@ -210,19 +211,28 @@ int rpn_sparse_backward(amp_ctx* ctx, const RpnSparseArgs& A) {
     }
     const int R = A.B * A.batch;
     hipLaunchKernelGGL(rpn_nz_rows_kernel, dim3(A.B), dim3(512), 0, ctx->stream, g, A.sampled, A.counts, A.batch, A.rows, A.nrows);
+    GatherArgs ga;
+    ga.g = g; ga.rows = A.rows; ga.batch = A.batch; ga.feat_split = A.feat_split; ga.xg = A.xg;
+    for (int l = 0; l < NLV; ++l) ga.feat[l] = A.feat[l];
+    hipLaunchKernelGGL(rpn_gather_x_kernel, dim3(R, 9), dim3(256), 0, ctx->stream, ga);
+    AMP_HIP_CHECK(hipGetLastError());
+    if (A.recompute_t) {
+        // the rows' hidden activations: relu(patch . W_conv + shift) -- the 3x3 conv's own products in its own K order ((tap, channel): the patch row IS the
+        // conv's im2col row, decoded from the split feature it was computed from), as a 1x1 layer 2304 -> 256 over the 1 x R image; G holds them until the
+        // row kernel has copied them into act_rows
+        amp_conv_desc dt;
+        dt.B = 1; dt.H = 1; dt.W = R; dt.Cin = 9 * A.C; dt.Cout = A.C; dt.KH = 1; dt.KW = 1; dt.stride = 1; dt.pad = 0; dt.relu = 1; dt.res_mode = 0; dt.out_mode = 0;
+        AMP_TRY_STATUS(amp::conv_run(ctx, &dt, 1, A.xg, A.w_conv, A.w_conv_split, 0, A.conv_scale, A.conv_shift, nullptr, nullptr, A.G, 0, 0));
+    }
     RowArgs ra;
     ra.g = g; ra.rows = A.rows; ra.batch = A.batch; ra.ld = A.ld; ra.K = A.K; ra.t_split = A.t_split; ra.w_pred = A.w_pred;
+    ra.t_rows = A.recompute_t ? A.G : nullptr;
     ra.dpred_rows = A.dpred_rows; ra.act_rows = A.act_rows; ra.dt_rows = A.dt_rows;
     for (int l = 0; l < NLV; ++l) { ra.dpred[l] = A.dpred[l]; ra.t[l] = A.t[l]; }
     hipLaunchKernelGGL(rpn_dt_rows_kernel, dim3(R), dim3(256), 0, ctx->stream, ra);
     // (the partial sums live in G, which the data-gradient GEMM overwrites further down: 18 x 32 x 256 floats)
     hipLaunchKernelGGL(rpn_head_sums_kernel, dim3(18, SUM_SLICES), dim3(1024), 0, ctx->stream, A.dpred_rows, A.act_rows, A.dt_rows, R, A.K, A.G);
     hipLaunchKernelGGL(rpn_head_sums_final_kernel, dim3(18), dim3(256), 0, ctx->stream, A.G, A.K, A.gw_pred, A.gb_pred, A.gb_conv);
-    GatherArgs ga;
-    ga.g = g; ga.rows = A.rows; ga.batch = A.batch; ga.feat_split = A.feat_split; ga.xg = A.xg;
-    for (int l = 0; l < NLV; ++l) ga.feat[l] = A.feat[l];
-    hipLaunchKernelGGL(rpn_gather_x_kernel, dim3(R, 9), dim3(256), 0, ctx->stream, ga);
-    AMP_HIP_CHECK(hipGetLastError());
     // dW_conv[n][tap][c] = sum_r d_t[r][n] * X[r][tap][c]: the weight gradient of a 1x1 layer 2304 -> 256 over a 1 x R image (gradients of 1e-9 .. 1e-4: * 2^16 in front of the f16 split)
     amp_conv_desc dw;
     dw.B = 1; dw.H = 1; dw.W = R; dw.Cin = 9 * A.C; dw.Cout = A.C; dw.KH = 1; dw.KW = 1; dw.stride = 1; dw.pad = 0; dw.relu = 0; dw.res_mode = 0; dw.out_mode = 0;

@@ -357,6 +357,7 @@ def test_sparse_rpn_backward_equals_the_dense_one(B, S, mode):
     names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
     out, ran = {}, {}
     try:
+        _lib.lib().amp_debug_set_rpn_train_fuse(0)      # the same forward pass in both (the dense backward needs the head's hidden tensor saved)
         for on in (0, 1, 1):
             _lib.lib().amp_debug_set_rpn_sparse(on)
             losses = m.forward_losses(imgs, gts, seed=7, backward=True)
@@ -369,6 +370,7 @@ def test_sparse_rpn_backward_equals_the_dense_one(B, S, mode):
             ran[on] = _lib.lib().amp_debug_last_rpn_sparse(m._h)
     finally:
         _lib.lib().amp_debug_set_rpn_sparse(-1)
+        _lib.lib().amp_debug_set_rpn_train_fuse(-1)
     assert ran == {0: 0, 1: 1}
     assert not ctx.conv_range_flag()
     assert out[0][0] == out[1][0]
@@ -383,5 +385,62 @@ def test_sparse_rpn_backward_equals_the_dense_one(B, S, mode):
     head = [k for k in names if k.startswith("proposal_generator.rpn_head")]
     assert len(head) == 6 and changed >= 6, (head, changed)
     print("worst relative differences:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    m.close()
+    ctx.close()
+
+
+def test_training_forward_with_the_fused_rpn_head_and_recomputed_hidden_rows():
+    """A training step whose forward pass runs the RPN head like inference does -- the predictors in the 3x3 conv's epilogue, the hidden tensor never
+    written -- and whose sparse backward pass recomputes the <= 256 hidden rows per image it needs from the gathered patches (round 4), against the step
+    that saves the hidden tensor (amp_debug_set_rpn_train_fuse(0)): the predictor maps agree to 2e-6 of their range (another order of the same sums), the
+    losses to 1e-5, every gradient to 5e-3 of its tensor's largest entry (proposals are a discrete function of the logits), the fused step repeats bit for
+    bit, and after an SGD step both forward passes see the new predictor weights."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    K, B, S = 2, 4, 1024
+    imgs, gts = synth.batch(B, S, S, first_index=520)
+    npp = P.init_params(K, seed=0, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=S, max_w=S, max_out_hw=S, train=True, max_gt=B * 800, max_poly_doubles=B * 800 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    out = {}
+    try:
+        for fuse in (0, 1, 1):
+            _lib.lib().amp_debug_set_rpn_train_fuse(fuse)
+            losses = m.forward_losses(imgs, gts, seed=9, backward=True)
+            got = (losses, {k: m.get_tensor(k, grad=True) for k in names}, m.tap("rpn_pred2"), m.tap("rpn_pred4"))
+            if fuse in out:
+                assert got[0] == out[fuse][0] and all(np.array_equal(got[1][k], out[fuse][1][k]) for k in names)
+            out[fuse] = got
+    finally:
+        _lib.lib().amp_debug_set_rpn_train_fuse(-1)
+    assert not ctx.conv_range_flag()
+    for t in (2, 3):
+        a, b = out[0][t], out[1][t]
+        assert float(np.abs(a - b).max()) <= 2e-6 * float(np.abs(a).max())
+    assert not np.array_equal(out[0][2], out[1][2])          # p2 did take the fused head (p4 at this size is below its threshold: the same launches either way)
+    for k in out[0][0]:
+        assert out[1][0][k] == pytest.approx(out[0][0][k], rel=1e-5), (k, out[0][0], out[1][0])
+    worst = {}
+    for k in names:
+        r, g = out[0][1][k], out[1][1][k]
+        worst[k] = float(np.abs(g - r).max()) / float(np.abs(r).max())
+        # (1e-3 on the box head here: logits that moved by 1e-7 let near-duplicate proposals trade places in the top-k / NMS -- the RoI sets are discrete
+        # functions of the logits; the backward pass itself is held to 6e-7 by test_sparse_rpn_backward_equals_the_dense_one on ONE forward pass)
+        assert worst[k] < 5e-3, (k, worst[k])
+    print("worst relative differences:", {k: f"{v:.1e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]})
+    # ... and after an SGD step both forward passes see the NEW predictor weights (the fused head reads their split copy, refreshed at the start of a step)
+    m.sgd_step(0.05, 0.9, 1e-4)
+    after = {}
+    try:
+        for fuse in (1, 0):
+            _lib.lib().amp_debug_set_rpn_train_fuse(fuse)
+            after[fuse] = m.forward_losses(imgs, gts, seed=9, backward=True)
+    finally:
+        _lib.lib().amp_debug_set_rpn_train_fuse(-1)
+    assert abs(after[1]["loss_rpn_cls"] - out[1][0]["loss_rpn_cls"]) > 1e-4          # the step did move the head
+    for k in after[0]:
+        assert after[1][k] == pytest.approx(after[0][k], rel=2e-5), (k, after)
     m.close()
     ctx.close()
