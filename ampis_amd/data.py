@@ -395,7 +395,10 @@ def _prefetched(plans, mapper, workers, depth=PREFETCH_DEPTH, upload=None):
                 yield item.result()
         finally:
             stop.set()
-            pool.shutdown(wait=False, cancel_futures=True)
-            collator.shutdown(wait=False, cancel_futures=True)
+            for ex in (pool, collator):
+                try:
+                    ex.shutdown(wait=False, cancel_futures=True)
+                except Exception:   # noqa: BLE001 -- a generator finalised while the interpreter shuts down finds queue / threading torn down already
+                    pass
 
     return consume()
