@@ -444,3 +444,42 @@ def test_training_forward_with_the_fused_rpn_head_and_recomputed_hidden_rows():
         assert after[1][k] == pytest.approx(after[0][k], rel=2e-5), (k, after)
     m.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["one_small_image", "no_ground_truth_in_one_image", "ragged_maps"])
+def test_sparse_rpn_backward_edge_cases(case):
+    """The sparse RPN backward on inputs away from the bench's: one 256 x 320 image (maps down to 4 x 5 pixels, most sampled anchors on the coarse levels),
+    a batch in which one image has no ground truth at all (256 negatives, no box loss there), image sizes that are not multiples of 64 (ragged level
+    sizes) -- against the dense pass on the same forward pass: every gradient to 2e-5 of its tensor's largest entry."""
+    from ampis_amd import _lib, params as P, synth
+    from ampis_amd.model import MaskRCNN
+    ctx = _lib.Context(0)
+    K = 2
+    B, H, W = {"one_small_image": (1, 256, 320), "no_ground_truth_in_one_image": (2, 384, 384), "ragged_maps": (2, 328, 440)}[case]
+    imgs, gts = synth.batch(B, H, W, first_index=610)
+    if case == "no_ground_truth_in_one_image":
+        gts[1] = dict(boxes=gts[1]["boxes"][:0], classes=gts[1]["classes"][:0], polygons=gts[1]["polygons"][:0])
+    npp = P.init_params(K, seed=1, style="spread")
+    m = MaskRCNN(ctx, K, max_batch=B, max_h=H, max_w=W, max_out_hw=max(H, W), train=True, max_gt=B * 800, max_poly_doubles=B * 800 * 64)
+    m.load_params(npp)
+    names = [k for k in npp if ".norm." not in k and not k.startswith("backbone.bottom_up.stem") and not k.startswith("backbone.bottom_up.res2")]
+    out = {}
+    try:
+        _lib.lib().amp_debug_set_rpn_train_fuse(0)
+        for on in (0, 1):
+            _lib.lib().amp_debug_set_rpn_sparse(on)
+            losses = m.forward_losses(imgs, gts, seed=5, backward=True)
+            out[on] = (losses, {k: m.get_tensor(k, grad=True) for k in names})
+            assert _lib.lib().amp_debug_last_rpn_sparse(m._h) == on
+    finally:
+        _lib.lib().amp_debug_set_rpn_sparse(-1)
+        _lib.lib().amp_debug_set_rpn_train_fuse(-1)
+    assert out[0][0] == out[1][0] and all(np.isfinite(v) for v in out[1][0].values())
+    for k in names:
+        r, g = out[0][1][k], out[1][1][k]
+        scale = float(np.abs(r).max())
+        assert np.isfinite(g).all() and (scale > 0 or not g.any()), k
+        if scale > 0:
+            assert float(np.abs(g - r).max()) / scale < 2e-5, (k, float(np.abs(g - r).max()) / scale)
+    m.close()
+    ctx.close()
